@@ -81,6 +81,88 @@ int tce_segment_accrew_f32(const float* rewards, const int64_t* pairs, int P,
 int tce_segment_accrew_f64(const double* rewards, const int64_t* pairs, int P,
                            double* out, int64_t N, int T, double gamma, void* stream);
 
+/* ---- ProDMP trajectory generator ---------------------------------------
+ * The arithmetic of mp_pytorch==0.1.4 (third-party, un-vendored; pinned at
+ * conda_env.sh:41) behind the reference's call sites
+ *   mprl/util/util_mp.py:11-46 (constructor surface),
+ *   mprl/rl/policy/temporal_correlated_policy.py:74-102 (sample),
+ *   mprl/rl/sampler/temporal_correlated_sampler.py:64-78 (time grid).
+ * `tab` [M, 4 + 2*nbg]: host pre-computed table (y1, y2, dy1, dy2, scaled
+ * position basis, scaled velocity basis) on a grid of step `scaled_dt` in
+ * scaled time; nbg = num_basis + 1 <= 16; dof <= 8.
+ * times [N,T]; times_general != 0: rows may differ arbitrarily (per-element
+ * basis evaluation); otherwise the rows are the sampler's affine grid and the
+ * kernels share one basis table when all init_time are equal (checked on the
+ * device, no host sync).  basis_ws: real [T, 4 + 2*nbg] workspace, flag_ws:
+ * int[1] workspace.  out [N, T, 2*dof] = cat[pos, vel].
+ */
+int tce_times_f32(const float* init_time, float off_first, float off_last,
+                  float* times, int64_t N, int T, void* stream);
+int tce_times_f64(const double* init_time, double off_first, double off_last,
+                  double* times, int64_t N, int T, void* stream);
+/* params = mean + L eps (MultivariateNormal(loc, scale_tril).rsample with the
+ * noise passed in; black_box_policy.py:80-93).  L_stride: elements between
+ * consecutive matrices, 0 = one shared [K,K] matrix. */
+int tce_mvn_rsample_f32(const float* mean, const float* L, int64_t L_stride,
+                        const float* eps, float* out, int64_t N, int K, void* stream);
+int tce_mvn_rsample_f64(const double* mean, const double* L, int64_t L_stride,
+                        const double* eps, double* out, int64_t N, int K, void* stream);
+int tce_prodmp_traj_f32(const float* tab, int M, int nbg, float tau, float delay,
+                        float scaled_dt, float inv_scale_g, int rel_goal,
+                        const float* times, int times_general, const float* params,
+                        const float* init_time, const float* init_pos,
+                        const float* init_vel, float* out, float* basis_ws,
+                        int* flag_ws, int64_t N, int T, int dof, void* stream);
+int tce_prodmp_traj_f64(const double* tab, int M, int nbg, double tau, double delay,
+                        double scaled_dt, double inv_scale_g, int rel_goal,
+                        const double* times, int times_general, const double* params,
+                        const double* init_time, const double* init_pos,
+                        const double* init_vel, double* out, double* basis_ws,
+                        int* flag_ws, int64_t N, int T, int dof, void* stream);
+
+/* ---- pair-wise trajectory log-probability -------------------------------
+ * TemporalCorrelatedPolicy.log_prob
+ *   (mprl/rl/policy/temporal_correlated_policy.py:104-203): logp [N,P] of the
+ * 2*dof positions at the two times of every pair under N(H theta + c,
+ * H L L^T H^T + reg I).  traj [N,T,2*dof], mean [N,K], L [.,K,K] with
+ * L_stride (0 = shared), pairs int64 [P,2].  bwd: grad_mean [N,K] and
+ * grad_L [N,K,K] (per env, lower triangle) for grad_logp [N,P]; the forward
+ * is recomputed, nothing is saved between the two calls.
+ */
+int tce_pair_logprob_fwd_f32(
+    const float* traj, const float* mean, const float* L, int64_t L_stride,
+    const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
+    float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
+    int times_general, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, float* logp, float* basis_ws, int* flag_ws,
+    int64_t N, int T, int P, int dof, void* stream);
+int tce_pair_logprob_fwd_f64(
+    const double* traj, const double* mean, const double* L, int64_t L_stride,
+    const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
+    double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
+    int times_general, const double* init_time, const double* init_pos,
+    const double* init_vel, double reg, double* logp, double* basis_ws, int* flag_ws,
+    int64_t N, int T, int P, int dof, void* stream);
+int tce_pair_logprob_bwd_f32(
+    const float* traj, const float* mean, const float* L, int64_t L_stride,
+    const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
+    float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
+    int times_general, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, const float* grad_logp, float* grad_mean,
+    float* grad_L, float* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,
+    void* stream);
+int tce_pair_logprob_bwd_f64(
+    const double* traj, const double* mean, const double* L, int64_t L_stride,
+    const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
+    double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
+    int times_general, const double* init_time, const double* init_pos,
+    const double* init_vel, double reg, const double* grad_logp, double* grad_mean,
+    double* grad_L, double* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,
+    void* stream);
+/* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs */
+int tce_sum_dim0_f32(const float* x, float* out, int64_t N, int64_t M, void* stream);
+int tce_sum_dim0_f64(const double* x, double* out, int64_t N, int64_t M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,352 @@
+// Pair-wise trajectory log-probability (forward + backward) for gfx950.
+//
+// Replaces TemporalCorrelatedPolicy.log_prob
+//   (mprl/rl/policy/temporal_correlated_policy.py:104-203): for each (env n,
+// pair p=(a,b)) the Gaussian over the R = 2*dof positions at the two pair
+// times, dof-major (d0@a, d0@b, d1@a, ...):
+//     y  = traj[n, {a,b}, :dof]
+//     mu = H_p theta_n + c_p(y0, v0),  C = (H_p L_n)(H_p L_n)^T + reg I
+//     logp = -1/2 |Lc^-1 (y-mu)|^2 - sum log diag Lc - R/2 log 2pi
+// The reference materialises H Sigma H^T [N,P,R,R] and the expanded
+// [N,P,K,K] Cholesky factors; here one workgroup owns one env, keeps L_n in
+// LDS and walks the pairs in chunks: M = H_p L (block structure of H_p: row
+// (d,j) only touches rows d*nbg..d*nbg+nbg-1 of L), C = M M^T, an R x R
+// Cholesky per pair, all in LDS.  The backward kernel recomputes the forward
+// (nothing but logp is stored) and produces dL/dmean [N,K] and dL/dL [N,K,K]:
+//     alpha = C^-1 (y-mu),  dmu = g alpha,  G = g (alpha alpha^T - C^-1)
+//     dmean += H_p^T dmu,   dL += H_p^T (G M)       (lower triangle)
+// Small-matrix VALU/LDS work, not HBM-bound: L_n (K^2) is read once per env.
+#include "prodmp.h"
+
+namespace {
+
+constexpr int PL_BT = 256;
+constexpr int PL_MAXR = 16;   // 2 * dof <= 16
+
+struct PLShape {
+  int K, R, P, PC, nbg, dof;
+};
+
+// LDS carve (in reals): Ls[K][K+1] | ms[K] | Hs[P][2][nbg] | cs[P][2][2] |
+// Ms[PC][R][K+1] | Cs[PC][R][R+1] | dv[PC][R] | Li[PC][R][R+1] | al[PC][R] | gs[PC]
+__host__ __device__ inline size_t pl_lds_reals(const PLShape& s, bool bwd) {
+  size_t n = (size_t)s.K * (s.K + 1) + s.K + (size_t)s.P * 2 * s.nbg + (size_t)s.P * 4;
+  n += (size_t)s.PC * s.R * (s.K + 1) + (size_t)s.PC * s.R * (s.R + 1) + (size_t)s.PC * s.R;
+  if (bwd) n += (size_t)s.PC * s.R * (s.R + 1) + (size_t)s.PC * s.R + s.PC;
+  return n;
+}
+
+template <typename real, bool BWD>
+__global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
+    const real* __restrict__ traj, const real* __restrict__ mean,
+    const real* __restrict__ L, int64_t sL, const int64_t* __restrict__ pairs,
+    const real* __restrict__ B, const int* __restrict__ nonuniform,
+    MPParams<real> mp, const real* __restrict__ times, int times_general,
+    const real* __restrict__ t0, const real* __restrict__ y0,
+    const real* __restrict__ v0, real reg, real* __restrict__ logp,
+    const real* __restrict__ gout, real* __restrict__ gmean,
+    real* __restrict__ gL, int T, PLShape s) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  const int K = s.K, R = s.R, P = s.P, PC = s.PC, nbg = s.nbg, dof = s.dof;
+  const int KP = K + 1, RP = R + 1;
+  real* Ls = smem;
+  real* ms = Ls + K * KP;
+  real* Hs = ms + K;
+  real* cs = Hs + P * 2 * nbg;
+  real* Ms = cs + P * 4;
+  real* Cs = Ms + PC * R * KP;
+  real* dv = Cs + PC * R * RP;
+  real* Li = dv + PC * R;                 // BWD only
+  real* al = Li + (BWD ? PC * R * RP : 0);
+  real* gs = al + (BWD ? PC * R : 0);
+
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const real* Ln = L + n * sL;
+  const bool general = times_general || (*nonuniform != 0);
+
+  for (int i = tid; i < K * K; i += PL_BT) {
+    const int r = i / K, c = i - r * K;
+    Ls[r * KP + c] = (c <= r) ? Ln[i] : real(0);
+  }
+  for (int i = tid; i < K; i += PL_BT) ms[i] = mean[n * K + i];
+  for (int i = tid; i < P * 2; i += PL_BT) {
+    const int ti = (int)pairs[i];          // pairs[p][j], i = 2p + j
+    real row[TCE_ROWLEN];
+    if (general) prodmp_row(mp, times[n * T + ti], t0[n], row);
+    else mp_row_load(B + (int64_t)ti * (4 + 2 * nbg), nbg, row);
+#pragma unroll
+    for (int b = 0; b < TCE_MAXB; ++b)
+      if (b < nbg) Hs[i * nbg + b] = row[4 + b];
+    cs[i * 2 + 0] = row[0];
+    cs[i * 2 + 1] = row[1];
+  }
+
+  // backward accumulators: entry e = tid + i*256 of the K x K gradient
+  real accL[16];
+  real accm = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accL[i] = 0;
+  __syncthreads();
+
+  for (int p0 = 0; p0 < P; p0 += PC) {
+    const int npc = min(PC, P - p0);
+    // 1. M = H_p L (lower triangle of L), d = y - mu
+    for (int i = tid; i < npc * R * K; i += PL_BT) {
+      const int k = i % K;
+      const int pr = i / K;
+      const int r = pr % R, pc = pr / R;
+      const int d = r >> 1, j = r & 1;
+      const real* h = Hs + ((p0 + pc) * 2 + j) * nbg;
+      real acc = 0;
+      for (int b = 0; b < nbg; ++b) acc += h[b] * Ls[(d * nbg + b) * KP + k];
+      Ms[(pc * R + r) * KP + k] = acc;
+    }
+    for (int i = tid; i < npc * R; i += PL_BT) {
+      const int r = i % R, pc = i / R;
+      const int d = r >> 1, j = r & 1;
+      const int pj = (p0 + pc) * 2 + j;
+      const real* h = Hs + pj * nbg;
+      real mu = cs[pj * 2] * y0[n * dof + d] + cs[pj * 2 + 1] * v0[n * dof + d];
+      for (int b = 0; b < nbg; ++b) mu += h[b] * ms[d * nbg + b];
+      const real y = traj[(n * T + (int)pairs[pj]) * (int64_t)(2 * dof) + d];
+      dv[i] = y - mu;
+    }
+    if (BWD) for (int i = tid; i < npc; i += PL_BT) gs[i] = gout[n * P + p0 + i];
+    __syncthreads();
+    // 2. C = M M^T + reg I (lower triangle)
+    for (int i = tid; i < npc * R * R; i += PL_BT) {
+      const int c = i % R;
+      const int pr = i / R;
+      const int r = pr % R, pc = pr / R;
+      if (c <= r) {
+        const real* a = Ms + (pc * R + r) * KP;
+        const real* b = Ms + (pc * R + c) * KP;
+        real acc = 0;
+        for (int k = 0; k < K; ++k) acc += a[k] * b[k];
+        if (c == r) acc += reg;
+        Cs[(pc * R + r) * RP + c] = acc;
+      }
+    }
+    __syncthreads();
+    // 3. per pair: Cholesky (in place), z = Lc^-1 d, logp
+    if (tid < npc) {
+      real* C = Cs + tid * R * RP;
+      real* d = dv + tid * R;
+      real logdet = 0, quad = 0;
+      for (int jx = 0; jx < R; ++jx) {
+        real sdiag = C[jx * RP + jx];
+        for (int k = 0; k < jx; ++k) sdiag -= C[jx * RP + k] * C[jx * RP + k];
+        const real ljj = sqrt(sdiag);
+        C[jx * RP + jx] = ljj;
+        const real inv = real(1) / ljj;
+        for (int i = jx + 1; i < R; ++i) {
+          real v = C[i * RP + jx];
+          for (int k = 0; k < jx; ++k) v -= C[i * RP + k] * C[jx * RP + k];
+          C[i * RP + jx] = v * inv;
+        }
+        real z = d[jx];
+        for (int k = 0; k < jx; ++k) z -= C[jx * RP + k] * d[k];
+        z *= inv;
+        d[jx] = z;                       // d now holds z
+        quad += z * z;
+        logdet += log(ljj);
+      }
+      if (!BWD)
+        logp[n * P + p0 + tid] =
+            real(-0.5) * quad - logdet - real(0.5) * (real)R * real(1.8378770664093453);
+    }
+    if (BWD) {
+      __syncthreads();
+      // 3b. Linv column c of pair pc (forward substitution on e_c), alpha = Lc^-T z
+      for (int i = tid; i < npc * R; i += PL_BT) {
+        const int c = i % R, pc = i / R;
+        const real* C = Cs + pc * R * RP;
+        real* X = Li + pc * R * RP;
+        for (int r = 0; r < R; ++r) {
+          real v = (r == c) ? real(1) : real(0);
+          for (int k = c; k < r; ++k) v -= C[r * RP + k] * X[k * RP + c];
+          X[r * RP + c] = (r < c) ? real(0) : v / C[r * RP + r];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < npc * R; i += PL_BT) {
+        const int r = i % R, pc = i / R;
+        const real* X = Li + pc * R * RP;
+        const real* z = dv + pc * R;
+        real a = 0;
+        for (int m = r; m < R; ++m) a += X[m * RP + r] * z[m];   // (Linv^T z)_r
+        al[i] = a;
+      }
+      __syncthreads();
+      // G = g (alpha alpha^T - Linv^T Linv) -> Cs (full R x R)
+      for (int i = tid; i < npc * R * R; i += PL_BT) {
+        const int c = i % R;
+        const int pr = i / R;
+        const int r = pr % R, pc = pr / R;
+        const real* X = Li + pc * R * RP;
+        real cinv = 0;
+        for (int m = max(r, c); m < R; ++m) cinv += X[m * RP + r] * X[m * RP + c];
+        Cs[(pc * R + r) * RP + c] = gs[pc] * (al[pc * R + r] * al[pc * R + c] - cinv);
+      }
+      __syncthreads();
+      // 4. GM = G M, in place per column k
+      for (int i = tid; i < npc * K; i += PL_BT) {
+        const int k = i % K, pc = i / K;
+        real m[PL_MAXR];
+#pragma unroll
+        for (int r = 0; r < PL_MAXR; ++r) m[r] = r < R ? Ms[(pc * R + r) * KP + k] : real(0);
+#pragma unroll
+        for (int r = 0; r < PL_MAXR; ++r) {
+          if (r < R) {
+            const real* g = Cs + (pc * R + r) * RP;
+            real acc = 0;
+#pragma unroll
+            for (int c = 0; c < PL_MAXR; ++c)
+              if (c < R) acc += g[c] * m[c];
+            Ms[(pc * R + r) * KP + k] = acc;
+          }
+        }
+      }
+      __syncthreads();
+      // 5. dL[row][k] += sum_pc sum_j H[p][j][b] GM[pc][(d,j)][k]; dmean likewise
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * PL_BT;
+        if (e < K * K) {
+          const int row = e / K, k = e - row * K;
+          if (k <= row) {
+            const int d = row / nbg, b = row - d * nbg;
+            real acc = 0;
+            for (int pc = 0; pc < npc; ++pc) {
+              const real* h = Hs + (p0 + pc) * 2 * nbg;
+              acc += h[b] * Ms[(pc * R + 2 * d) * KP + k] +
+                     h[nbg + b] * Ms[(pc * R + 2 * d + 1) * KP + k];
+            }
+            accL[i] += acc;
+          }
+        }
+      }
+      if (tid < K) {
+        const int d = tid / nbg, b = tid - d * nbg;
+        real acc = 0;
+        for (int pc = 0; pc < npc; ++pc) {
+          const real* h = Hs + (p0 + pc) * 2 * nbg;
+          acc += gs[pc] * (h[b] * al[pc * R + 2 * d] + h[nbg + b] * al[pc * R + 2 * d + 1]);
+        }
+        accm += acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + i * PL_BT;
+      if (e < K * K) gL[n * (int64_t)K * K + e] = accL[i];
+    }
+    if (tid < K) gmean[n * K + tid] = accm;
+  }
+}
+
+// out[j] = sum_n x[n, j]   (x [N, M] row-major): one block per 256 columns
+template <typename real>
+__global__ __launch_bounds__(256) void sum_dim0_kernel(const real* __restrict__ x,
+                                                       real* __restrict__ out,
+                                                       int64_t N, int64_t M) {
+  __shared__ real part[4][64];
+  // 64 columns per block, 4 row-groups
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  real acc = 0;
+  if (col < M)
+    for (int64_t r = g; r < N; r += 4) acc += x[r * M + col];
+  part[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && col < M) out[col] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+}
+
+template <typename real>
+int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64_t sL,
+              const int64_t* pairs, const real* tab, int M, int nbg, real tau, real delay,
+              real scaled_dt, real inv_scale_g, int rel_goal, const real* times,
+              int times_general, const real* t0, const real* y0, const real* v0, real reg,
+              real* logp, const real* gout, real* gmean, real* gL, real* B, int* flag,
+              int64_t N, int T, int P, int dof, hipStream_t stream) {
+  TCE_CHECK_ARG(traj && mean && L && pairs && tab && times && t0 && y0 && v0 && B && flag,
+                "pair_logprob: null buffer");
+  TCE_CHECK_ARG(bwd ? (gout && gmean && gL) : (logp != nullptr), "pair_logprob: null output");
+  TCE_CHECK_ARG(N > 0 && T > 0 && P > 0, "pair_logprob: bad sizes");
+  TCE_CHECK_ARG(nbg >= 1 && nbg <= TCE_MAXB && dof >= 1 && 2 * dof <= PL_MAXR,
+                "pair_logprob: num_basis + 1 <= 16 and num_dof <= 8");
+  const int K = dof * nbg;
+  TCE_CHECK_ARG(K <= 64, "pair_logprob: dof * (num_basis + 1) must be <= 64");
+  MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
+  (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)),
+                     dim3(256), 0, stream, mp, times, t0, N, T, B, flag);
+  TCE_LAUNCH_CHECK();
+  PLShape s{K, 2 * dof, P, P, nbg, dof};
+  const size_t budget = 60 * 1024;
+  while (s.PC > 1 && pl_lds_reals(s, bwd) * sizeof(real) > budget) --s.PC;
+  const size_t lds = pl_lds_reals(s, bwd) * sizeof(real);
+  TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: problem too large for LDS");
+  auto kern = bwd ? pair_logprob_kernel<real, true> : pair_logprob_kernel<real, false>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  TCE_CHECK_ARG(N < (1ll << 31), "pair_logprob: too many envs");
+  hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(PL_BT), lds, stream, traj, mean, L, sL,
+                     pairs, B, flag, mp, times, times_general, t0, y0, v0, reg, logp, gout,
+                     gmean, gL, T, s);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define DEFINE_PL(SFX, REAL)                                                     \
+  int tce_pair_logprob_fwd_##SFX(                                                \
+      const REAL* traj, const REAL* mean, const REAL* L, int64_t L_stride,       \
+      const int64_t* pairs, const REAL* tab, int M, int nbg, REAL tau,           \
+      REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal,                \
+      const REAL* times, int times_general, const REAL* init_time,               \
+      const REAL* init_pos, const REAL* init_vel, REAL reg, REAL* logp,          \
+      REAL* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,            \
+      void* stream) {                                                            \
+    return pl_launch<REAL>(false, traj, mean, L, L_stride, pairs, tab, M, nbg,   \
+                           tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
+                           times_general, init_time, init_pos, init_vel, reg,    \
+                           logp, nullptr, nullptr, nullptr, basis_ws, flag_ws, N, \
+                           T, P, dof, (hipStream_t)stream);                      \
+  }                                                                              \
+  int tce_pair_logprob_bwd_##SFX(                                                \
+      const REAL* traj, const REAL* mean, const REAL* L, int64_t L_stride,       \
+      const int64_t* pairs, const REAL* tab, int M, int nbg, REAL tau,           \
+      REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal,                \
+      const REAL* times, int times_general, const REAL* init_time,               \
+      const REAL* init_pos, const REAL* init_vel, REAL reg,                      \
+      const REAL* grad_logp, REAL* grad_mean, REAL* grad_L, REAL* basis_ws,      \
+      int* flag_ws, int64_t N, int T, int P, int dof, void* stream) {            \
+    return pl_launch<REAL>(true, traj, mean, L, L_stride, pairs, tab, M, nbg,    \
+                           tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
+                           times_general, init_time, init_pos, init_vel, reg,    \
+                           nullptr, grad_logp, grad_mean, grad_L, basis_ws,      \
+                           flag_ws, N, T, P, dof, (hipStream_t)stream);          \
+  }                                                                              \
+  int tce_sum_dim0_##SFX(const REAL* x, REAL* out, int64_t N, int64_t M,         \
+                         void* stream) {                                         \
+    TCE_CHECK_ARG(x && out && N > 0 && M > 0, "sum_dim0: bad arguments");        \
+    hipLaunchKernelGGL(sum_dim0_kernel<REAL>, dim3((unsigned)ceil_div(M, 64)),   \
+                       dim3(256), 0, (hipStream_t)stream, x, out, N, M);         \
+    TCE_LAUNCH_CHECK();                                                          \
+    return 0;                                                                    \
+  }
+
+DEFINE_PL(f32, float)
+DEFINE_PL(f64, double)
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// ProDMP trajectory generation for gfx950 (MI355X):
+//   times grid (k3), parameter sampling w = mean + L eps (k4/k6),
+//   uniform-init-time basis table, and the trajectory kernel (k4) that
+//   replaces TemporalCorrelatedPolicy.sample
+//   (mprl/rl/policy/temporal_correlated_policy.py:34-102 ->
+//    mp_pytorch ProDMP.sample_trajectories / get_traj_pos / get_traj_vel).
+//
+// prodmp_traj_kernel is write-bound: per env it writes T*2*dof reals and reads
+// dof*(nb+1) parameters + 2*dof initial conditions.  Lane <-> time step: each
+// lane keeps its basis row (4 + 2*(nb+1) values) in registers across the envs
+// of its block, the per-env parameters are wave-uniform (scalar loads), and
+// the 2*dof outputs of a lane are contiguous in memory (16-byte stores).
+#include "prodmp.h"
+
+namespace {
+
+template <typename real>
+__global__ __launch_bounds__(256) void times_kernel(
+    const real* __restrict__ t0, real off_first, real off_last,
+    real* __restrict__ times, int64_t N, int T) {
+  const int64_t total = N * (int64_t)T;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / T;
+    times[i] = sampler_time_at<real>(t0[n], off_first, off_last, T, (int)(i - n * T));
+  }
+}
+
+// w[n, i] = mean[n, i] + sum_{j<=i} L[n, i, j] eps[n, j]   (L batch stride sL: 0 = shared)
+template <typename real>
+__global__ __launch_bounds__(256) void mvn_rsample_kernel(
+    const real* __restrict__ mean, const real* __restrict__ L, int64_t sL,
+    const real* __restrict__ eps, real* __restrict__ out, int64_t N, int K) {
+  const int64_t total = N * (int64_t)K;
+  for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t n = idx / K;
+    const int i = (int)(idx - n * K);
+    const real* Lr = L + n * sL + (int64_t)i * K;
+    const real* e = eps + n * K;
+    real acc = 0;
+    for (int j = 0; j <= i; ++j) acc += Lr[j] * e[j];
+    out[idx] = mean[idx] + acc;
+  }
+}
+
+template <typename real, int NV>
+__device__ inline void store_vec(real* dst, const real* src) {
+  typedef real vec __attribute__((ext_vector_type(NV), aligned(sizeof(real))));
+  vec v;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = src[i];
+  *reinterpret_cast<vec*>(dst) = v;
+}
+
+template <typename real, int DOF>
+__global__ __launch_bounds__(256) void prodmp_traj_kernel(
+    const real* __restrict__ B, const int* __restrict__ nonuniform,
+    MPParams<real> mp, const real* __restrict__ times, int times_general,
+    const real* __restrict__ w, const real* __restrict__ t0,
+    const real* __restrict__ y0, const real* __restrict__ v0,
+    real* __restrict__ out, int64_t N, int T, int epb) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_begin = (int64_t)blockIdx.y * epb;
+  const int64_t n_end = tmin<int64_t>(N, n_begin + epb);
+  const int nbg = mp.nbg;
+  const bool general = times_general || (*nonuniform != 0);
+  const int tc = t < T ? t : T - 1;
+  real row[TCE_ROWLEN];
+  if (!general) mp_row_load(B + (int64_t)tc * (4 + 2 * nbg), nbg, row);
+  for (int64_t n = n_begin; n < n_end; ++n) {
+    if (general) prodmp_row(mp, times[n * T + tc], t0[n], row);
+    real o[2 * DOF];
+    const real* wn = w + n * (int64_t)(DOF * nbg);
+#pragma unroll
+    for (int d = 0; d < DOF; ++d) {
+      const real yd = y0[n * DOF + d], vd = v0[n * DOF + d];
+      real pos = row[0] * yd + row[1] * vd;
+      real vel = row[2] * yd + row[3] * vd;
+#pragma unroll
+      for (int b = 0; b < TCE_MAXB; ++b) {
+        if (b < nbg) {
+          const real th = wn[d * nbg + b];
+          pos += row[4 + b] * th;
+          vel += row[4 + TCE_MAXB + b] * th;
+        }
+      }
+      o[d] = pos;
+      o[DOF + d] = vel;
+    }
+    if (t < T) {
+      real* dst = out + (n * T + t) * (int64_t)(2 * DOF);
+      constexpr int C = 2 * DOF;
+      if (C % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) store_vec<real, 4>(dst + 4 * i, o + 4 * i);
+      } else if (C % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) store_vec<real, 2>(dst + 2 * i, o + 2 * i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) dst[i] = o[i];
+      }
+    }
+  }
+}
+
+template <typename real>
+int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scaled_dt,
+                real inv_scale_g, int rel_goal, const real* times, int times_general,
+                const real* w, const real* t0, const real* y0, const real* v0,
+                real* out, real* B, int* flag, int64_t N, int T, int dof,
+                hipStream_t stream) {
+  TCE_CHECK_ARG(tab && times && w && t0 && y0 && v0 && out && B && flag,
+                "prodmp_traj: null buffer");
+  TCE_CHECK_ARG(N > 0 && T > 0 && M >= 2, "prodmp_traj: bad sizes");
+  TCE_CHECK_ARG(nbg >= 1 && nbg <= TCE_MAXB, "prodmp_traj: num_basis + 1 must be <= 16");
+  TCE_CHECK_ARG(dof >= 1 && dof <= 8, "prodmp_traj: num_dof must be <= 8");
+  MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
+  (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
+  const int tb = (int)ceil_div(T, 256);
+  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3(tb), dim3(256), 0, stream, mp,
+                     times, t0, N, T, B, flag);
+  TCE_LAUNCH_CHECK();
+  // ~2048 workgroups: each keeps its basis rows for `epb` envs
+  int epb = (int)tmax<int64_t>(1, (N * tb) / 2048);
+  const int64_t gy = ceil_div(N, epb);
+  TCE_CHECK_ARG(gy <= 65535, "prodmp_traj: too many envs");
+  dim3 grid(tb, (unsigned)gy);
+#define TRAJ_GO(D)                                                              \
+  hipLaunchKernelGGL((prodmp_traj_kernel<real, D>), grid, dim3(256), 0, stream, \
+                     B, flag, mp, times, times_general, w, t0, y0, v0, out, N, T, epb)
+  switch (dof) {
+    case 1: TRAJ_GO(1); break;
+    case 2: TRAJ_GO(2); break;
+    case 3: TRAJ_GO(3); break;
+    case 4: TRAJ_GO(4); break;
+    case 5: TRAJ_GO(5); break;
+    case 6: TRAJ_GO(6); break;
+    case 7: TRAJ_GO(7); break;
+    default: TRAJ_GO(8); break;
+  }
+#undef TRAJ_GO
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define DEFINE_PRODMP(SFX, REAL)                                                 \
+  int tce_times_##SFX(const REAL* t0, REAL off_first, REAL off_last, REAL* times, \
+                      int64_t N, int T, void* stream) {                          \
+    TCE_CHECK_ARG(t0 && times && N > 0 && T > 0, "times: bad arguments");        \
+    const int64_t nb = tmin<int64_t>(ceil_div(N * T, 256), 4096);                \
+    hipLaunchKernelGGL(times_kernel<REAL>, dim3((unsigned)nb), dim3(256), 0,     \
+                       (hipStream_t)stream, t0, off_first, off_last, times, N, T); \
+    TCE_LAUNCH_CHECK();                                                          \
+    return 0;                                                                    \
+  }                                                                              \
+  int tce_mvn_rsample_##SFX(const REAL* mean, const REAL* L, int64_t L_stride,   \
+                            const REAL* eps, REAL* out, int64_t N, int K,        \
+                            void* stream) {                                      \
+    TCE_CHECK_ARG(mean && L && eps && out && N > 0 && K > 0,                     \
+                  "mvn_rsample: bad arguments");                                 \
+    const int64_t nb = tmin<int64_t>(ceil_div(N * K, 256), 4096);                \
+    hipLaunchKernelGGL(mvn_rsample_kernel<REAL>, dim3((unsigned)nb), dim3(256),  \
+                       0, (hipStream_t)stream, mean, L, L_stride, eps, out, N, K); \
+    TCE_LAUNCH_CHECK();                                                          \
+    return 0;                                                                    \
+  }                                                                              \
+  int tce_prodmp_traj_##SFX(const REAL* tab, int M, int nbg, REAL tau,           \
+                            REAL delay, REAL scaled_dt, REAL inv_scale_g,        \
+                            int rel_goal, const REAL* times, int times_general,  \
+                            const REAL* params, const REAL* init_time,           \
+                            const REAL* init_pos, const REAL* init_vel,          \
+                            REAL* out, REAL* basis_ws, int* flag_ws, int64_t N,  \
+                            int T, int dof, void* stream) {                      \
+    return traj_launch<REAL>(tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,    \
+                             rel_goal, times, times_general, params, init_time,  \
+                             init_pos, init_vel, out, basis_ws, flag_ws, N, T,   \
+                             dof, (hipStream_t)stream);                          \
+  }
+
+DEFINE_PRODMP(f32, float)
+DEFINE_PRODMP(f64, double)
+
+}  // extern "C"

@@ -141,3 +141,138 @@ def segment_advantage(mode, rewards, values, advantages, pred_pairs, gamma,
              float(gamma), stream())
         return out
     raise NotImplementedError(mode)
+
+
+# ---------------------------------------------------------------------------
+# shared (non-contextual) Cholesky factors
+# ---------------------------------------------------------------------------
+def expand_shared(L_base, N):
+    """[K,K] / [1,K,K] -> stride-0 [N,K,K] view that remembers its base, so the
+    ops run on the single matrix and autograd never materialises N copies."""
+    base = L_base.reshape(L_base.shape[-2], L_base.shape[-1])
+    out = base.unsqueeze(0).expand(N, -1, -1)
+    out._tce_base = base
+    return out
+
+
+def split_L(L):
+    """-> (L2d_or_3d contiguous tensor carrying the autograd graph, stride).
+    stride 0: one matrix shared by all envs."""
+    base = getattr(L, "_tce_base", None)
+    if base is not None:
+        return _c(base), 0
+    if L.dim() == 2:
+        return _c(L), 0
+    if L.stride(0) == 0:
+        return _c(L[0]), 0
+    L = _c(L)
+    return L, L.shape[-1] * L.shape[-2]
+
+
+# ---------------------------------------------------------------------------
+# time grid, parameter sampling, ProDMP trajectories
+# ---------------------------------------------------------------------------
+def times(init_time, dt, num_times):
+    """TemporalCorrelatedSampler.get_times: [N, T], bit-identical to the
+    reference's tensor_linspace formula.  The result is tagged as the affine
+    grid the kernels may share a basis table for."""
+    check_dev(init_time)
+    t0 = _c(init_time)
+    N = t0.shape[0]
+    out = torch.empty(N, num_times, dtype=t0.dtype, device=t0.device)
+    # Python scalars exactly as the reference forms them (dt, num_times * dt)
+    call("tce_times_" + sfx(t0.dtype), ptr(t0), float(dt),
+         float(num_times * dt), ptr(out), N, int(num_times), stream())
+    out._tce_affine = True
+    return out
+
+
+def mvn_rsample(mean, L, eps):
+    """loc + scale_tril @ eps (the noise of MultivariateNormal.rsample is
+    passed in explicitly)."""
+    check_dev(mean, L, eps)
+    mean, eps = _c(mean), _c(eps)
+    Lc, sL = split_L(L)
+    N, K = mean.shape
+    out = torch.empty_like(mean)
+    call("tce_mvn_rsample_" + sfx(mean.dtype), ptr(mean), ptr(Lc), sL,
+         ptr(eps), ptr(out), N, K, stream())
+    return out
+
+
+def _mp_ws(mp, T, device):
+    ws = getattr(mp, "_ws", None)
+    if ws is None or ws[0].shape[0] < T or ws[0].device != device:
+        ws = (torch.empty(T, 4 + 2 * mp.num_basis_g, dtype=mp.dtype,
+                          device=device),
+              torch.zeros(1, dtype=torch.int32, device=device))
+        mp._ws = ws
+    return ws
+
+
+def prodmp_traj(mp, times_, params, init_time, init_pos, init_vel):
+    """cat[pos, vel] [N, T, 2*dof] of the ProDMP with parameters [N, K]."""
+    check_dev(times_, params, init_time, init_pos, init_vel)
+    general = 0 if getattr(times_, "_tce_affine", False) else 1
+    t, p = _c(times_), _c(mp.pad_params(params))
+    t0, y0, v0 = _c(init_time), _c(init_pos), _c(init_vel)
+    N, T = t.shape
+    assert p.shape == (N, mp.num_dof * mp.num_basis_g)
+    out = torch.empty(N, T, 2 * mp.num_dof, dtype=p.dtype, device=p.device)
+    B, flag = _mp_ws(mp, T, p.device)
+    call("tce_prodmp_traj_" + sfx(p.dtype), *mp.c_args(), ptr(t), general,
+         ptr(p), ptr(t0), ptr(y0), ptr(v0), ptr(out), ptr(B), ptr(flag), N, T,
+         mp.num_dof, stream())
+    return out
+
+
+class _PairLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, Lc, sL, mp, traj, times_, general, t0, y0, v0,
+                pairs):
+        N, T = times_.shape
+        P = pairs.shape[0]
+        logp = torch.empty(N, P, dtype=mean.dtype, device=mean.device)
+        B, flag = _mp_ws(mp, T, mean.device)
+        call("tce_pair_logprob_fwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
+             ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), general,
+             ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(logp), ptr(B),
+             ptr(flag), N, T, P, mp.num_dof, stream())
+        ctx.save_for_backward(mean, Lc, traj, times_, t0, y0, v0, pairs)
+        ctx.mp, ctx.sL, ctx.general = mp, sL, general
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        mean, Lc, traj, times_, t0, y0, v0, pairs = ctx.saved_tensors
+        mp, sL = ctx.mp, ctx.sL
+        N, T = times_.shape
+        P, K = pairs.shape[0], mean.shape[1]
+        g = _c(g)
+        gmean = torch.empty_like(mean)
+        gL = torch.empty(N, K, K, dtype=mean.dtype, device=mean.device)
+        B, flag = _mp_ws(mp, T, mean.device)
+        call("tce_pair_logprob_bwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
+             ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), ctx.general,
+             ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(g), ptr(gmean),
+             ptr(gL), ptr(B), ptr(flag), N, T, P, mp.num_dof, stream())
+        if sL == 0:
+            gLs = torch.empty(K, K, dtype=mean.dtype, device=mean.device)
+            call("tce_sum_dim0_" + sfx(mean.dtype), ptr(gL), ptr(gLs), N,
+                 K * K, stream())
+            gL = gLs
+        return (gmean, gL) + (None,) * 9
+
+
+def pair_log_prob(mp, traj, mean, L, times_, init_time, init_pos, init_vel,
+                  pred_pairs):
+    """TemporalCorrelatedPolicy.log_prob -> [N, P]; differentiable w.r.t. mean
+    and L (hand-written backward kernel)."""
+    check_dev(traj, mean, L, times_, init_time, init_pos, init_vel, pred_pairs)
+    assert not (mp.disable_goal or mp.disable_weights), \
+        "pair log-prob needs the full [weights, goal] parameterisation"
+    general = 0 if getattr(times_, "_tce_affine", False) else 1
+    Lc, sL = split_L(L)
+    return _PairLogProb.apply(_c(mean), Lc, sL, mp, _c(traj), _c(times_),
+                              general, _c(init_time), _c(init_pos),
+                              _c(init_vel), _c(pred_pairs.to(torch.int64)))
