@@ -163,6 +163,63 @@ int tce_pair_logprob_bwd_f64(
 int tce_sum_dim0_f32(const float* x, float* out, int64_t N, int64_t M, void* stream);
 int tce_sum_dim0_f64(const double* x, double* out, int64_t N, int64_t M, void* stream);
 
+/* ---- Gaussian policy head / param-space Gaussian / KL trust region -------
+ * chol_build: AbstractGaussianPolicy._vector_to_cholesky
+ *   (mprl/rl/policy/abstract_policy.py:166-187 -> util_matrix.py:12-33,
+ *    util_numerical.py:44-68): vec [B, nvec] (nvec = K diag-only or
+ *   K + K(K-1)/2) -> L [B,K,K], diag = softplus(v) + min_std, strict lower
+ *   triangle filled row-major.
+ * vec_env: per-env triangular-solve ops, L [.,K,K] with L_stride (0 = shared):
+ *   mode 0  maha(x, y, L) = |L^-1 (x-y)|^2            (black_box_policy.py:205-224)
+ *   mode 1  KL mean projection of x towards y with bound eps
+ *           (trust_region_projections mean_projection; call site
+ *            temporal_correlated_agent.py:530-533)
+ *   mode 2  log N(x; mean = y, L L^T)                  (black_box_policy.py:95-128)
+ *   bwd = 0: out ([N] or [N,K]); bwd = 1: grad_x [N,K] from grad_out (mode 2:
+ *   gradient w.r.t. the mean y, plus per-env grad_L [N,K,K] when non-NULL).
+ * kl_cov_part: 1/2 (tr(S_old^-1 S) - K + logdet S_old - logdet S) per matrix
+ *   (gaussian_kl of trust_region_projections; temporal_correlated_agent.py:641-661).
+ * kl_cov_proj: differentiable KL projection of the covariance (the job of the
+ *   C++ cpp_projection / ITPAL solver, conda_env.sh:34) followed by the entropy
+ *   control scaling; beta: device scalar or NULL.  ctx: double
+ *   [B, tce_kl_cov_proj_ctx_len(K)] saved for the backward call.  K <= 64.
+ */
+int tce_chol_build_fwd_f32(const float* vec, float* L, int64_t B, int K, int nvec,
+                           float min_std, void* stream);
+int tce_chol_build_fwd_f64(const double* vec, double* L, int64_t B, int K, int nvec,
+                           double min_std, void* stream);
+int tce_chol_build_bwd_f32(const float* vec, const float* grad_L, float* grad_vec,
+                           int64_t B, int K, int nvec, void* stream);
+int tce_chol_build_bwd_f64(const double* vec, const double* grad_L, double* grad_vec,
+                           int64_t B, int K, int nvec, void* stream);
+int tce_vec_env_f32(int mode, int bwd, const float* x, const float* y, const float* L,
+                    int64_t L_stride, float eps, const float* grad_out, float* out,
+                    float* grad_x, float* grad_L, int64_t N, int K, void* stream);
+int tce_vec_env_f64(int mode, int bwd, const double* x, const double* y, const double* L,
+                    int64_t L_stride, double eps, const double* grad_out, double* out,
+                    double* grad_x, double* grad_L, int64_t N, int K, void* stream);
+int tce_kl_cov_part_f32(int bwd, const float* L, const float* L_old,
+                        int64_t L_old_stride, const float* grad_out, float* out,
+                        float* grad_L, int64_t B, int K, void* stream);
+int tce_kl_cov_part_f64(int bwd, const double* L, const double* L_old,
+                        int64_t L_old_stride, const double* grad_out, double* out,
+                        double* grad_L, int64_t B, int K, void* stream);
+int64_t tce_kl_cov_proj_ctx_len(int K);
+int tce_kl_cov_proj_fwd_f32(const float* L, const float* L_old, int64_t L_old_stride,
+                            double eps_cov, const float* beta, int entropy_eq,
+                            float* proj_L, double* ctx, int64_t B, int K, void* stream);
+int tce_kl_cov_proj_fwd_f64(const double* L, const double* L_old, int64_t L_old_stride,
+                            double eps_cov, const double* beta, int entropy_eq,
+                            double* proj_L, double* ctx, int64_t B, int K, void* stream);
+int tce_kl_cov_proj_bwd_f32(const float* L, const float* L_old, int64_t L_old_stride,
+                            const float* proj_L, const double* ctx,
+                            const float* grad_proj, float* grad_L, int64_t B, int K,
+                            void* stream);
+int tce_kl_cov_proj_bwd_f64(const double* L, const double* L_old, int64_t L_old_stride,
+                            const double* proj_L, const double* ctx,
+                            const double* grad_proj, double* grad_L, int64_t B, int K,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

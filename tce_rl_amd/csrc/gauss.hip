@@ -1,0 +1,555 @@
+// Gaussian-policy linear algebra for gfx950: Cholesky head, Mahalanobis / KL
+// parts, param-space log-prob, and the differentiable KL trust-region
+// projection (mean: closed form; covariance: dual multiplier eta + implicit
+// gradient).
+//
+// Reference surface:
+//   AbstractGaussianPolicy._vector_to_cholesky   mprl/rl/policy/abstract_policy.py:166-187
+//   BlackBoxPolicy.log_prob / maha / ...         mprl/rl/policy/black_box_policy.py:95-224
+//   KLProjectionLayer (third-party trust_region_projections + C++ cpp_projection)
+//        call sites mprl/rl/projection/__init__.py:18-40,
+//        mprl/rl/agent/temporal_correlated_agent.py:530-567
+// The covariance projection is ONE workgroup per K x K matrix (K <= 64), all
+// in LDS and in double precision like the reference's C++ solver: whiten with
+// the old Cholesky factor, one-sided Jacobi eigen-decomposition, scalar root
+// find for eta on the eigenvalues, reassemble, Cholesky; the backward pass is
+// the closed-form implicit gradient in the eigenbasis.
+#include "smallmat.h"
+
+namespace {
+
+constexpr double LOG_2PI = 1.8378770664093453;
+
+// ---------------------------------------------------------------------------
+// Cholesky head: vec [B, K (+ K(K-1)/2)] -> L [B, K, K]
+//   diag = softplus(v[:K]) + min_std (torch threshold 20), off-diagonal filled
+//   row-major over tril_indices(K, K, -1).
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ __launch_bounds__(256) void chol_build_kernel(const real* __restrict__ vec,
+                                                         real* __restrict__ L, int64_t B, int K,
+                                                         int nvec, real min_std) {
+  const int64_t total = B * (int64_t)K * K;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / (K * K);
+    const int rc = (int)(e - b * K * K);
+    const int r = rc / K, c = rc - r * K;
+    const real* v = vec + b * nvec;
+    real out = 0;
+    if (r == c) {
+      const real x = v[r];
+      out = (x > real(20) ? x : log1p(exp(x))) + min_std;
+    } else if (c < r && nvec > K) {
+      out = v[K + r * (r - 1) / 2 + c];
+    }
+    L[e] = out;
+  }
+}
+template <typename real>
+__global__ __launch_bounds__(256) void chol_build_bwd_kernel(const real* __restrict__ vec,
+                                                             const real* __restrict__ gL,
+                                                             real* __restrict__ gvec, int64_t B,
+                                                             int K, int nvec) {
+  const int64_t total = B * (int64_t)nvec;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / nvec;
+    const int i = (int)(e - b * nvec);
+    const real* g = gL + b * (int64_t)K * K;
+    if (i < K) {
+      const real x = vec[e];
+      const real sig = x > real(20) ? real(1) : real(1) / (real(1) + exp(-x));
+      gvec[e] = g[i * K + i] * sig;
+    } else {
+      // invert i = K + r(r-1)/2 + c
+      const int t = i - K;
+      int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+      while (r * (r - 1) / 2 > t) --r;
+      while ((r + 1) * r / 2 <= t) ++r;
+      const int c = t - r * (r - 1) / 2;
+      gvec[e] = g[r * K + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-env vector ops with a lower-triangular L (batch stride sL, 0 = shared):
+//   d = L^-1 (x - y),  q = L^-T d
+// MODE 0: maha = |d|^2                     bwd: dx = 2 g q (dy = -dx)
+// MODE 1: mean projection (KL trust region on the mean)
+//           m = 1/2 |d|^2 ; if m > eps: s = sqrt(m/eps),
+//           out = (x + (s-1) y) / (s + 1e-16) else out = x
+//         bwd: dx = g/s - (g.delta) q / (2 eps s^3)   (active), g (inactive)
+// MODE 2: log N(x; y, L L^T)               bwd: dy = g q (dx unused), and
+//           dL = g (q d^T - diag(1/L_ii)) per env (lower triangle)
+// One thread per env; a shared L is staged in LDS.
+// ---------------------------------------------------------------------------
+constexpr int VE_MAXK = 64;
+
+template <typename real, int MODE, bool BWD>
+__global__ __launch_bounds__(64) void vec_env_kernel(
+    const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
+    int64_t sL, real eps, const real* __restrict__ gout, real* __restrict__ out,
+    real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* Ls = reinterpret_cast<real*>(smem_raw);
+  const bool shared = (sL == 0);
+  if (shared) {
+    for (int e = threadIdx.x; e < K * K; e += 64) Ls[e] = L[e];
+    __syncthreads();
+  }
+  const int64_t n = blockIdx.x * 64ll + threadIdx.x;
+  if (n >= N) return;
+  const real* Ln = shared ? Ls : L + n * sL;
+  real d[VE_MAXK];
+  real quad = 0, logdet = 0;
+#pragma unroll 1
+  for (int r = 0; r < K; ++r) {
+    real v = x[n * K + r] - y[n * K + r];
+    for (int k = 0; k < r; ++k) v -= Ln[r * K + k] * d[k];
+    const real lrr = Ln[r * K + r];
+    v /= lrr;
+    d[r] = v;
+    quad += v * v;
+    if (MODE == 2) logdet += log(lrr);
+  }
+  if (!BWD) {
+    if (MODE == 0) out[n] = quad;
+    if (MODE == 2) out[n] = real(-0.5) * quad - logdet - real(0.5 * LOG_2PI) * (real)K;
+    if (MODE == 1) {
+      const real m = real(0.5) * quad;
+      if (m > eps) {
+        const real s = sqrt(m / eps);
+        const real om = s - real(1);
+        for (int r = 0; r < K; ++r)
+          out[n * K + r] = (x[n * K + r] + om * y[n * K + r]) / (real(1) + om + real(1e-16));
+      } else {
+        for (int r = 0; r < K; ++r) out[n * K + r] = x[n * K + r];
+      }
+    }
+    return;
+  }
+  // backward: q = L^-T d (in place into q[])
+  real q[VE_MAXK];
+#pragma unroll 1
+  for (int r = K - 1; r >= 0; --r) {
+    real v = d[r];
+    for (int k = r + 1; k < K; ++k) v -= Ln[k * K + r] * q[k];
+    q[r] = v / Ln[r * K + r];
+  }
+  if (MODE == 0) {
+    const real g = gout[n];
+    for (int r = 0; r < K; ++r) gx[n * K + r] = real(2) * g * q[r];
+  } else if (MODE == 1) {
+    const real m = real(0.5) * quad;
+    if (m > eps) {
+      const real s = sqrt(m / eps);
+      real gd = 0;
+      for (int r = 0; r < K; ++r) gd += gout[n * K + r] * (x[n * K + r] - y[n * K + r]);
+      const real coef = gd / (real(2) * eps * s * s * s);
+      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r] / s - coef * q[r];
+    } else {
+      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r];
+    }
+  } else {
+    const real g = gout[n];
+    for (int r = 0; r < K; ++r) gx[n * K + r] = g * q[r];      // d logp / d mean
+    if (gLout) {
+      real* gl = gLout + n * (int64_t)K * K;
+      for (int r = 0; r < K; ++r)
+        for (int c = 0; c < K; ++c) {
+          real v = 0;
+          if (c <= r) v = g * (q[r] * d[c] - (r == c ? real(1) / Ln[r * K + r] : real(0)));
+          gl[r * K + c] = v;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KL covariance part  c(L, Lo) = 1/2 (|Lo^-1 L|_F^2 - K - 2 sum log A_ii),
+// A = Lo^-1 L; one workgroup per matrix.  bwd: dL = g (Lo^-T A - diag(1/L_ii)).
+// ---------------------------------------------------------------------------
+template <typename real, bool BWD>
+__global__ __launch_bounds__(SM_BT) void kl_cov_part_kernel(
+    const real* __restrict__ L, const real* __restrict__ Lo, int64_t sLo,
+    const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gL, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);
+  const int KP = K + 1;
+  double* Los = A + K * KP;
+  __shared__ double red[4];
+  const int64_t b = blockIdx.x;
+  sm_load(A, L + b * (int64_t)K * K, K, KP, true);
+  sm_load(Los, Lo + b * sLo, K, KP, true);
+  sm_trsm_l(A, Los, K, KP);
+  if (!BWD) {
+    double loc = 0;
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      const double a = A[i * KP + j];
+      loc += a * a;
+      if (i == j) loc -= 2.0 * log(a);
+    }
+    const double tot = sm_block_sum(loc, red);
+    if (threadIdx.x == 0) out[b] = (real)(0.5 * (tot - (double)K));
+  } else {
+    sm_trsm_lt(A, Los, K, KP);           // Lo^-T A
+    const double g = (double)gout[b];
+    const real* Lb = L + b * (int64_t)K * K;
+    real* gb = gL + b * (int64_t)K * K;
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      double v = 0;
+      if (j <= i) v = g * (A[i * KP + j] - (i == j ? 1.0 / (double)Lb[e] : 0.0));
+      gb[e] = (real)v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KL covariance projection.  ctx (double) per matrix: [Vt K*K | lam K | eta,
+// active, alpha, pad].
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int64_t klp_ctx_len(int K) { return (int64_t)K * K + K + 4; }
+
+// h(eta) = 1/2 sum (mu - 1 - log mu), mu = (eta+1) lam / (eta lam + 1); one wave.
+__device__ inline double klp_h(double eta, double lam, bool live) {
+  double t = 0;
+  if (live) {
+    const double mu = (eta + 1.0) * lam / (eta * lam + 1.0);
+    t = mu - 1.0 - log(mu);
+  }
+  return 0.5 * wave_sum(t);
+}
+
+template <typename real>
+__global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
+    const real* __restrict__ L, const real* __restrict__ Lo, int64_t sLo, double eps,
+    const real* __restrict__ beta, int entropy_eq, real* __restrict__ projL,
+    double* __restrict__ ctx, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int KP = K + 1;
+  double* A = reinterpret_cast<double*>(smem_raw);   // A -> rotated -> Y
+  double* Vt = A + K * KP;
+  double* Los = Vt + K * KP;                          // Lo -> S -> Lp
+  __shared__ double lam[64];
+  __shared__ double red[4];
+  __shared__ double s_eta;
+  __shared__ int s_flag;
+  const int64_t b = blockIdx.x;
+  const real* Lb = L + b * (int64_t)K * K;
+  double* cb = ctx + b * klp_ctx_len(K);
+
+  sm_load(A, Lb, K, KP, true);
+  sm_load(Los, Lo + b * sLo, K, KP, true);
+  sm_trsm_l(A, Los, K, KP);                           // A = Lo^-1 L (lower)
+  double loc = 0;
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    const double a = A[i * KP + j];
+    loc += a * a;
+    if (i == j) loc -= 2.0 * log(a);
+  }
+  const double kl0 = 0.5 * (sm_block_sum(loc, red) - (double)K);
+  const bool active = kl0 > eps;                      // block-uniform
+  double eta = 0;
+  if (active) {
+    sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP);
+    if (threadIdx.x < 64) {
+      const bool live = threadIdx.x < K;
+      const double lm = live ? lam[threadIdx.x] : 1.0;
+      double lo = 0.0, hi = 1.0;
+      for (int i = 0; i < 200 && klp_h(hi, lm, live) > eps; ++i) { lo = hi; hi *= 2.0; }
+      for (int i = 0; i < 100; ++i) {
+        const double mid = 0.5 * (lo + hi);
+        if (klp_h(mid, lm, live) > eps) lo = mid; else hi = mid;
+      }
+      if (threadIdx.x == 0) s_eta = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    eta = s_eta;
+    // ctx: Vt, lam
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) cb[e] = Vt[(e / K) * KP + (e % K)];
+    if (threadIdx.x < K) cb[(int64_t)K * K + threadIdx.x] = lam[threadIdx.x];
+    // Y[r][k] = sum_{i<=r} Lo[r][i] Vt[k][i] sqrt(mu_k)      -> A
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int r = e / K, k = e - r * K;
+      const double mu = (eta + 1.0) * lam[k] / (eta * lam[k] + 1.0);
+      double acc = 0;
+      for (int i = 0; i <= r; ++i) acc += Los[r * KP + i] * Vt[k * KP + i];
+      A[r * KP + k] = acc * sqrt(mu);
+    }
+    __syncthreads();
+    sm_mm_nt(Los, A, A, K, KP);                       // S = Y Y^T
+    sm_cholesky(Los, K, KP);                          // Lp
+  } else {
+    sm_load(Los, Lb, K, KP, true);                    // Lp = L
+  }
+  // entropy control: alpha = exp((beta - H)/K) if H < beta (or equality form)
+  double alpha = 1.0;
+  if (beta != nullptr) {
+    double ld = 0;
+    for (int i = threadIdx.x; i < K; i += SM_BT) ld += log(Los[i * KP + i]);
+    const double H = 0.5 * K * (1.0 + LOG_2PI) + sm_block_sum(ld, red);
+    const double bt = (double)beta[0];
+    if (entropy_eq || H < bt) alpha = exp((bt - H) / (double)K);
+  }
+  sm_store(projL + b * (int64_t)K * K, Los, K, KP, true, alpha);
+  if (threadIdx.x == 0) {
+    double* tail = cb + (int64_t)K * K + K;
+    tail[0] = eta;
+    tail[1] = active ? 1.0 : 0.0;
+    tail[2] = alpha;
+    tail[3] = kl0;
+  }
+}
+
+template <typename real>
+__global__ __launch_bounds__(SM_BT) void kl_cov_proj_bwd_kernel(
+    const real* __restrict__ L, const real* __restrict__ Lo, int64_t sLo,
+    const real* __restrict__ projL, const double* __restrict__ ctx,
+    const real* __restrict__ gproj, real* __restrict__ gL, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int KP = K + 1;
+  double* M0 = reinterpret_cast<double*>(smem_raw);
+  double* M1 = M0 + K * KP;
+  double* M2 = M1 + K * KP;
+  double* M3 = M2 + K * KP;
+  __shared__ double lam[64], wv[64], mup[64], hB[64];
+  __shared__ double red[4];
+  const int64_t b = blockIdx.x;
+  const double* cb = ctx + b * klp_ctx_len(K);
+  const double* tail = cb + (int64_t)K * K + K;
+  const double eta = tail[0], alpha = tail[2];
+  const bool active = tail[1] != 0.0;
+  const real* Lb = L + b * (int64_t)K * K;
+  real* gb = gL + b * (int64_t)K * K;
+
+  // Lp = projL / alpha (M0), G (M1)
+  sm_load(M0, projL + b * (int64_t)K * K, K, KP, true);
+  sm_load(M1, gproj + b * (int64_t)K * K, K, KP, true);
+  if (alpha != 1.0) {
+    // out = alpha(Lp) Lp: dLp = alpha G - (alpha/K) <G, Lp> diag(1/Lp_ii)
+    double loc = 0;
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      M0[i * KP + j] /= alpha;
+      loc += M1[i * KP + j] * M0[i * KP + j];
+    }
+    const double dot = sm_block_sum(loc, red);       // <G, Lp>
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      double v = alpha * M1[i * KP + j];
+      if (i == j) v -= (alpha / (double)K) * dot / M0[i * KP + i];
+      M1[i * KP + j] = v;
+    }
+    __syncthreads();
+  }
+  if (!active) {
+    sm_store(gb, M1, K, KP, true, 1.0);
+    return;
+  }
+  // Cholesky backward: Sbar = 1/2 (Z + Z^T), Z = Lp^-T Phi(Lp^T G) Lp^-1
+  sm_mm_tn(M2, M0, M1, K, KP);                        // Lp^T G
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    if (j > i) M2[i * KP + j] = 0;
+    else if (j == i) M2[i * KP + j] *= 0.5;
+  }
+  __syncthreads();
+  sm_trsm_lt(M2, M0, K, KP);                          // Lp^-T Phi
+  sm_trsm_r(M2, M0, K, KP);                           // ... Lp^-1  = Z
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    M1[i * KP + j] = 0.5 * (M2[i * KP + j] + M2[j * KP + i]);   // Sbar
+  }
+  __syncthreads();
+  // Gw = Lo^T Sbar Lo
+  sm_load(M0, Lo + b * sLo, K, KP, true);             // Lo
+  sm_mm_nn(M2, M1, M0, K, KP);                        // Sbar Lo
+  sm_mm_tn(M1, M0, M2, K, KP);                        // Lo^T (Sbar Lo) = Gw
+  // Ghat = Vt Gw Vt^T
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) M3[(e / K) * KP + (e % K)] = cb[e];   // Vt
+  if (threadIdx.x < K) {
+    const double lm = cb[(int64_t)K * K + threadIdx.x];
+    lam[threadIdx.x] = lm;
+    const double w = 1.0 / (eta * lm + 1.0);
+    wv[threadIdx.x] = w;
+    const double mu = (eta + 1.0) * lm * w;
+    mup[threadIdx.x] = lm * (1.0 - lm) * w * w;
+    hB[threadIdx.x] = 0.5 * (eta + 1.0) * (1.0 - 1.0 / mu) * w * w;
+  }
+  __syncthreads();
+  sm_mm_nn(M2, M3, M1, K, KP);                        // Vt Gw
+  sm_mm_nt(M1, M2, M3, K, KP);                        // (Vt Gw) Vt^T = Ghat
+  double l1 = 0, l2 = 0;
+  for (int i = threadIdx.x; i < K; i += SM_BT) {
+    const double mu = (eta + 1.0) * lam[i] * wv[i];
+    l1 += (1.0 - 1.0 / mu) * mup[i];                  // 2 h_eta
+    l2 += M1[i * KP + i] * mup[i];                    // c_eta
+  }
+  const double h_eta = 0.5 * sm_block_sum(l1, red);
+  const double c_eta = sm_block_sum(l2, red);
+  const double ratio = c_eta / h_eta;
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    double v = (eta + 1.0) * wv[i] * M1[i * KP + j] * wv[j];
+    if (i == j) v -= ratio * hB[i];
+    M1[i * KP + j] = v;                               // Bhat
+  }
+  __syncthreads();
+  // Bbar = Vt^T Bhat Vt
+  sm_mm_nn(M2, M1, M3, K, KP);                        // Bhat Vt
+  sm_mm_tn(M1, M3, M2, K, KP);                        // Vt^T (Bhat Vt) = Bbar
+  // A = Lo^-1 L ; Abar = (Bbar + Bbar^T) A ; Lbar = tril(Lo^-T Abar)
+  sm_load(M2, Lb, K, KP, true);
+  sm_trsm_l(M2, M0, K, KP);                           // A
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    double acc = 0;
+    for (int k = 0; k < K; ++k) acc += (M1[i * KP + k] + M1[k * KP + i]) * M2[k * KP + j];
+    M3[i * KP + j] = acc;
+  }
+  __syncthreads();
+  sm_trsm_lt(M3, M0, K, KP);
+  sm_store(gb, M3, K, KP, true, 1.0);
+}
+
+template <typename F>
+int set_lds(F kern, size_t lds) {
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
+
+#define DEFINE_GAUSS(SFX, REAL)                                                   \
+  int tce_chol_build_fwd_##SFX(const REAL* vec, REAL* L, int64_t B, int K,        \
+                               int nvec, REAL min_std, void* stream) {            \
+    TCE_CHECK_ARG(vec && L && B > 0 && K > 0 &&                                   \
+                      (nvec == K || nvec == K + K * (K - 1) / 2),                 \
+                  "chol_build: bad arguments");                                   \
+    const int64_t nb = tmin<int64_t>(ceil_div(B * K * K, 256), 4096);             \
+    hipLaunchKernelGGL(chol_build_kernel<REAL>, dim3((unsigned)nb), dim3(256), 0, \
+                       (hipStream_t)stream, vec, L, B, K, nvec, min_std);         \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }                                                                               \
+  int tce_chol_build_bwd_##SFX(const REAL* vec, const REAL* grad_L,               \
+                               REAL* grad_vec, int64_t B, int K, int nvec,        \
+                               void* stream) {                                    \
+    TCE_CHECK_ARG(vec && grad_L && grad_vec && B > 0 && K > 0,                    \
+                  "chol_build_bwd: bad arguments");                               \
+    const int64_t nb = tmin<int64_t>(ceil_div(B * nvec, 256), 4096);              \
+    hipLaunchKernelGGL(chol_build_bwd_kernel<REAL>, dim3((unsigned)nb),           \
+                       dim3(256), 0, (hipStream_t)stream, vec, grad_L, grad_vec,  \
+                       B, K, nvec);                                               \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }                                                                               \
+  /* mode 0 maha, 1 mean projection, 2 log-prob; bwd != 0: backward */            \
+  int tce_vec_env_##SFX(int mode, int bwd, const REAL* x, const REAL* y,          \
+                        const REAL* L, int64_t L_stride, REAL eps,                \
+                        const REAL* grad_out, REAL* out, REAL* grad_x,            \
+                        REAL* grad_L, int64_t N, int K, void* stream) {           \
+    TCE_CHECK_ARG(x && y && L && N > 0 && K > 0 && K <= VE_MAXK,                  \
+                  "vec_env: bad arguments (K <= 64)");                            \
+    TCE_CHECK_ARG(bwd ? (grad_out && grad_x) : (out != nullptr),                  \
+                  "vec_env: null output");                                        \
+    const unsigned nb = (unsigned)ceil_div(N, 64);                                \
+    const size_t lds = L_stride == 0 ? (size_t)K * K * sizeof(REAL) : 0;          \
+    hipStream_t st = (hipStream_t)stream;                                         \
+    if (mode == 0 && !bwd)                                                        \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 0, false>), dim3(nb), dim3(64),    \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else if (mode == 0)                                                           \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 0, true>), dim3(nb), dim3(64),     \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else if (mode == 1 && !bwd)                                                   \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 1, false>), dim3(nb), dim3(64),    \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else if (mode == 1)                                                           \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 1, true>), dim3(nb), dim3(64),     \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else if (mode == 2 && !bwd)                                                   \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 2, false>), dim3(nb), dim3(64),    \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else if (mode == 2)                                                           \
+      hipLaunchKernelGGL((vec_env_kernel<REAL, 2, true>), dim3(nb), dim3(64),     \
+                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
+                         grad_L, N, K);                                           \
+    else {                                                                        \
+      tce_set_error("vec_env: unknown mode");                                     \
+      return 1;                                                                   \
+    }                                                                             \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }                                                                               \
+  int tce_kl_cov_part_##SFX(int bwd, const REAL* L, const REAL* L_old,            \
+                            int64_t L_old_stride, const REAL* grad_out,           \
+                            REAL* out, REAL* grad_L, int64_t B, int K,            \
+                            void* stream) {                                       \
+    TCE_CHECK_ARG(L && L_old && B > 0 && K > 0 && K <= 64,                        \
+                  "kl_cov_part: bad arguments (K <= 64)");                        \
+    const size_t lds = 2 * (size_t)K * (K + 1) * sizeof(double);                  \
+    if (bwd) {                                                                    \
+      TCE_CHECK_ARG(grad_out && grad_L, "kl_cov_part: null gradient buffers");    \
+      set_lds(kl_cov_part_kernel<REAL, true>, lds);                               \
+      hipLaunchKernelGGL((kl_cov_part_kernel<REAL, true>), dim3((unsigned)B),     \
+                         dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,         \
+                         L_old_stride, grad_out, out, grad_L, K);                 \
+    } else {                                                                      \
+      TCE_CHECK_ARG(out != nullptr, "kl_cov_part: null output");                  \
+      set_lds(kl_cov_part_kernel<REAL, false>, lds);                              \
+      hipLaunchKernelGGL((kl_cov_part_kernel<REAL, false>), dim3((unsigned)B),    \
+                         dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,         \
+                         L_old_stride, grad_out, out, grad_L, K);                 \
+    }                                                                             \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }                                                                               \
+  int tce_kl_cov_proj_fwd_##SFX(const REAL* L, const REAL* L_old,                 \
+                                int64_t L_old_stride, double eps_cov,             \
+                                const REAL* beta, int entropy_eq, REAL* proj_L,   \
+                                double* ctx, int64_t B, int K, void* stream) {    \
+    TCE_CHECK_ARG(L && L_old && proj_L && ctx && B > 0 && K > 0 && K <= 64,       \
+                  "kl_cov_proj: bad arguments (K <= 64)");                        \
+    const size_t lds = 3 * (size_t)K * (K + 1) * sizeof(double);                  \
+    set_lds(kl_cov_proj_fwd_kernel<REAL>, lds);                                   \
+    hipLaunchKernelGGL(kl_cov_proj_fwd_kernel<REAL>, dim3((unsigned)B),           \
+                       dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,           \
+                       L_old_stride, eps_cov, beta, entropy_eq, proj_L, ctx, K);  \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }                                                                               \
+  int tce_kl_cov_proj_bwd_##SFX(const REAL* L, const REAL* L_old,                 \
+                                int64_t L_old_stride, const REAL* proj_L,         \
+                                const double* ctx, const REAL* grad_proj,         \
+                                REAL* grad_L, int64_t B, int K, void* stream) {   \
+    TCE_CHECK_ARG(L && L_old && proj_L && ctx && grad_proj && grad_L && B > 0 &&  \
+                      K > 0 && K <= 64,                                           \
+                  "kl_cov_proj_bwd: bad arguments (K <= 64)");                    \
+    const size_t lds = 4 * (size_t)K * (K + 1) * sizeof(double);                  \
+    set_lds(kl_cov_proj_bwd_kernel<REAL>, lds);                                   \
+    hipLaunchKernelGGL(kl_cov_proj_bwd_kernel<REAL>, dim3((unsigned)B),           \
+                       dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,           \
+                       L_old_stride, proj_L, ctx, grad_proj, grad_L, K);          \
+    TCE_LAUNCH_CHECK();                                                           \
+    return 0;                                                                     \
+  }
+
+DEFINE_GAUSS(f32, float)
+DEFINE_GAUSS(f64, double)
+
+}  // extern "C"

@@ -276,3 +276,233 @@ def pair_log_prob(mp, traj, mean, L, times_, init_time, init_pos, init_vel,
     return _PairLogProb.apply(_c(mean), Lc, sL, mp, _c(traj), _c(times_),
                               general, _c(init_time), _c(init_pos),
                               _c(init_vel), _c(pred_pairs.to(torch.int64)))
+
+
+# ---------------------------------------------------------------------------
+# Gaussian head, param-space Gaussian, KL trust region (csrc/gauss.hip)
+# ---------------------------------------------------------------------------
+def first_matrix(L):
+    """[K,K] matrix of a shared (non-contextual) factor, or L[0]."""
+    base = getattr(L, "_tce_base", None)
+    if base is not None:
+        return base
+    return L if L.dim() == 2 else L[0]
+
+
+def full_L(L, N):
+    return _c(L if L.dim() == 3 else L.unsqueeze(0).expand(N, -1, -1))
+
+
+def detach_L(L):
+    base = getattr(L, "_tce_base", None)
+    if base is not None:
+        return expand_shared(base.detach(), L.shape[0])
+    return L.detach()
+
+
+class _CholBuild(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec, K, min_std):
+        B, nvec = vec.shape
+        L = torch.empty(B, K, K, dtype=vec.dtype, device=vec.device)
+        call("tce_chol_build_fwd_" + sfx(vec.dtype), ptr(vec), ptr(L), B, K,
+             nvec, float(min_std), stream())
+        ctx.save_for_backward(vec)
+        ctx.K = K
+        return L
+
+    @staticmethod
+    def backward(ctx, gL):
+        vec, = ctx.saved_tensors
+        B, nvec = vec.shape
+        gvec = torch.empty_like(vec)
+        call("tce_chol_build_bwd_" + sfx(vec.dtype), ptr(vec), ptr(_c(gL)),
+             ptr(gvec), B, ctx.K, nvec, stream())
+        return gvec, None, None
+
+
+def chol_build(vec, dim_out, min_std):
+    """_vector_to_cholesky: [..., K | K + K(K-1)/2] -> [..., K, K]."""
+    check_dev(vec)
+    lead = vec.shape[:-1]
+    L = _CholBuild.apply(_c(vec.reshape(-1, vec.shape[-1])), dim_out, min_std)
+    return L.reshape(*lead, dim_out, dim_out)
+
+
+def _vec_env(mode, bwd, x, y, Lc, sL, eps, gout, want_gL=False):
+    N, K = x.shape
+    s = sfx(x.dtype)
+    if not bwd:
+        out = torch.empty((N, K) if mode == 1 else (N,), dtype=x.dtype,
+                          device=x.device)
+        call("tce_vec_env_" + s, mode, 0, ptr(x), ptr(y), ptr(Lc), sL,
+             float(eps), None, ptr(out), None, None, N, K, stream())
+        return out
+    gx = torch.empty_like(x)
+    gL = torch.empty(N, K, K, dtype=x.dtype, device=x.device) if want_gL \
+        else None
+    call("tce_vec_env_" + s, mode, 1, ptr(x), ptr(y), ptr(Lc), sL, float(eps),
+         ptr(_c(gout)), None, ptr(gx), ptr(gL), N, K, stream())
+    return gx, gL
+
+
+class _Maha(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, Lc, sL):
+        ctx.save_for_backward(x, y, Lc)
+        ctx.sL = sL
+        return _vec_env(0, False, x, y, Lc, sL, 0.0, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, Lc = ctx.saved_tensors
+        gx, _ = _vec_env(0, True, x, y, Lc, ctx.sL, 0.0, g)
+        return gx, -gx, None, None
+
+
+def maha(x, y, L):
+    """|L^-1 (x - y)|^2 [N]; differentiable w.r.t. x and y (L is a constant:
+    every call site passes the old / detached factor)."""
+    check_dev(x, y, L)
+    Lc, sL = split_L(L)
+    return _Maha.apply(_c(x), _c(y), Lc.detach(), sL)
+
+
+class _MeanProj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, mean_o, Lc, sL, eps):
+        ctx.save_for_backward(mean, mean_o, Lc)
+        ctx.sL, ctx.eps = sL, eps
+        return _vec_env(1, False, mean, mean_o, Lc, sL, eps, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        mean, mean_o, Lc = ctx.saved_tensors
+        gx, _ = _vec_env(1, True, mean, mean_o, Lc, ctx.sL, ctx.eps, g)
+        return gx, None, None, None, None
+
+
+def kl_mean_projection(mean, mean_old, L_old, eps):
+    check_dev(mean, mean_old, L_old)
+    Lc, sL = split_L(L_old)
+    return _MeanProj.apply(_c(mean), _c(mean_old).detach(), Lc.detach(), sL,
+                           float(eps))
+
+
+class _MvnLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, Lc, sL):
+        ctx.save_for_backward(x, mean, Lc)
+        ctx.sL = sL
+        return _vec_env(2, False, x, mean, Lc, sL, 0.0, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, Lc = ctx.saved_tensors
+        N, K = x.shape
+        need_L = ctx.needs_input_grad[2]
+        gmean, gL = _vec_env(2, True, x, mean, Lc, ctx.sL, 0.0, g,
+                             want_gL=need_L)
+        if need_L and ctx.sL == 0:
+            gLs = torch.empty(K, K, dtype=x.dtype, device=x.device)
+            call("tce_sum_dim0_" + sfx(x.dtype), ptr(gL), ptr(gLs), N, K * K,
+                 stream())
+            gL = gLs
+        return None, gmean, gL, None
+
+
+def mvn_log_prob(x, mean, L):
+    """MultivariateNormal(mean, scale_tril=L).log_prob(x) [N]."""
+    check_dev(x, mean, L)
+    Lc, sL = split_L(L)
+    return _MvnLogProb.apply(_c(x).detach(), _c(mean), Lc, sL)
+
+
+def log_determinant(L):
+    return 2 * L.diagonal(dim1=-2, dim2=-1).log().sum(-1)
+
+
+def mvn_entropy(L, N=None):
+    """MultivariateNormal.entropy(): K/2 (1 + log 2 pi) + sum log diag L."""
+    import math
+    base = getattr(L, "_tce_base", None)
+    M = base if base is not None else L
+    K = M.shape[-1]
+    ent = 0.5 * K * (1.0 + math.log(2 * math.pi)) + \
+        M.diagonal(dim1=-2, dim2=-1).log().sum(-1)
+    if base is not None:
+        return ent.expand(L.shape[0])
+    return ent
+
+
+class _KLCovPart(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, L, Lo, sLo):
+        B, K = L.shape[0], L.shape[-1]
+        out = torch.empty(B, dtype=L.dtype, device=L.device)
+        call("tce_kl_cov_part_" + sfx(L.dtype), 0, ptr(L), ptr(Lo), sLo, None,
+             ptr(out), None, B, K, stream())
+        ctx.save_for_backward(L, Lo)
+        ctx.sLo = sLo
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L, Lo = ctx.saved_tensors
+        B, K = L.shape[0], L.shape[-1]
+        gL = torch.empty_like(L)
+        call("tce_kl_cov_part_" + sfx(L.dtype), 1, ptr(L), ptr(Lo), ctx.sLo,
+             ptr(_c(g)), None, ptr(gL), B, K, stream())
+        return gL, None, None
+
+
+def kl_cov_part(L, L_old, N):
+    """Covariance part of KL(p || q) [N] (constant across envs when both
+    factors are shared); differentiable w.r.t. L."""
+    check_dev(L, L_old)
+    Lc, sL = split_L(L)
+    Loc, sLo = split_L(L_old)
+    K = Lc.shape[-1]
+    if sL == 0:
+        if sLo != 0:
+            Loc, sLo = _c(Loc[0]), 0
+        out = _KLCovPart.apply(Lc.reshape(1, K, K), Loc.detach(), 0)
+        return out.expand(N)
+    return _KLCovPart.apply(Lc, Loc.detach(), sLo)
+
+
+class _KLCovProj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, L, Lo, sLo, eps_cov, beta, entropy_eq):
+        B, K = L.shape[0], L.shape[-1]
+        proj = torch.empty_like(L)
+        n = _lib.load().tce_kl_cov_proj_ctx_len(K)
+        cbuf = torch.empty(B, n, dtype=torch.float64, device=L.device)
+        call("tce_kl_cov_proj_fwd_" + sfx(L.dtype), ptr(L), ptr(Lo), sLo,
+             float(eps_cov), ptr(beta), int(bool(entropy_eq)), ptr(proj),
+             ptr(cbuf), B, K, stream())
+        ctx.save_for_backward(L, Lo, proj, cbuf)
+        ctx.sLo = sLo
+        return proj
+
+    @staticmethod
+    def backward(ctx, g):
+        L, Lo, proj, cbuf = ctx.saved_tensors
+        B, K = L.shape[0], L.shape[-1]
+        gL = torch.empty_like(L)
+        call("tce_kl_cov_proj_bwd_" + sfx(L.dtype), ptr(L), ptr(Lo), ctx.sLo,
+             ptr(proj), ptr(cbuf), ptr(_c(g)), ptr(gL), B, K, stream())
+        return gL, None, None, None, None, None
+
+
+def kl_cov_projection(L, L_old, eps_cov, beta=None, entropy_eq=False):
+    """[B,K,K] -> projected Cholesky factors [B,K,K] (KL bound eps_cov on the
+    covariance part, then entropy control with the device scalar beta);
+    differentiable w.r.t. L."""
+    check_dev(L, L_old, beta)
+    L = _c(L)
+    Lo = _c(L_old).detach()
+    sLo = 0 if Lo.dim() == 2 else Lo.shape[-1] * Lo.shape[-2]
+    if beta is not None:
+        beta = _c(beta.detach().to(L.dtype).reshape(1))
+    return _KLCovProj.apply(L, Lo, sLo, eps_cov, beta, entropy_eq)

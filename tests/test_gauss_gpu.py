@@ -1,0 +1,206 @@
+"""GPU parity of the Gaussian-head / KL trust-region kernels vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kl_oracle as KO
+from oracle import tce_oracle as O
+
+pytestmark = pytest.mark.gpu
+T_ = torch.as_tensor
+F64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tce_rl_amd import ops
+    return ops
+
+
+def rand_chol(K, scale, g, B=1, dtype=F64):
+    vec = torch.cat([scale * torch.randn(B, K, generator=g, dtype=dtype),
+                     0.1 * scale * torch.randn(B, K * (K - 1) // 2, generator=g,
+                                               dtype=dtype)], -1)
+    return O.vector_to_cholesky(vec, K, 1e-3, False)
+
+
+def test_chol_build_golden_and_backward(ops, golden):
+    g = golden("cholesky_head")
+    for K in (20, 24, 28, 36, 63):
+        for std_only in (False, True):
+            tag = f"K{K}_{'diag' if std_only else 'full'}"
+            vec = T_(g[f"vec_{tag}"])
+            L = ops.chol_build(vec.cuda(), K, 1e-5)
+            np.testing.assert_allclose(L.cpu().numpy(), g[f"L_{tag}"],
+                                       rtol=1e-6, atol=1e-7)
+    vec = torch.randn(3, 36 + 36 * 35 // 2, dtype=F64)
+    vec[0, 0] = 25.0                       # softplus threshold branch
+    W = torch.randn(3, 36, 36, dtype=F64)
+    v_c = vec.clone().requires_grad_(True)
+    (O.vector_to_cholesky(v_c, 36, 1e-4, False) * W).sum().backward()
+    v_g = vec.cuda().requires_grad_(True)
+    (ops.chol_build(v_g, 36, 1e-4) * W.cuda()).sum().backward()
+    torch.testing.assert_close(v_g.grad.cpu(), v_c.grad, rtol=1e-12, atol=1e-12)
+
+
+def test_mvn_golden(ops, golden):
+    g = golden("mvn")
+    for K in (20, 36):
+        mean = T_(g[f"mean_K{K}"]).cuda().requires_grad_(True)
+        L = T_(g[f"L_K{K}"]).cuda().requires_grad_(True)
+        x = ops.mvn_rsample(mean.detach(), L.detach(), T_(g[f"eps_K{K}"]).cuda())
+        np.testing.assert_allclose(x.cpu().numpy(), g[f"x_K{K}"], rtol=1e-5,
+                                   atol=1e-5)
+        lp = ops.mvn_log_prob(T_(g[f"x_K{K}"]).cuda(), mean, L)
+        np.testing.assert_allclose(lp.detach().cpu().numpy(), g[f"logp_K{K}"],
+                                   rtol=1e-5, atol=1e-4)
+        (lp * T_(g[f"w_K{K}"]).cuda()).sum().backward()
+        # fp32 triangular solves with small pivots (diag ~ softplus + 1e-5):
+        # gradients agree to fp32 conditioning; exactness is checked in fp64
+        # by test_mvn_logprob_backward_f64
+        np.testing.assert_allclose(mean.grad.cpu().numpy(), g[f"dmean_K{K}"],
+                                   rtol=2e-3, atol=5e-3)
+        np.testing.assert_allclose(np.tril(L.grad.cpu().numpy()),
+                                   g[f"dL_K{K}"], rtol=2e-3, atol=5e-3)
+        np.testing.assert_allclose(
+            ops.mvn_entropy(L.detach()).cpu().numpy(), g[f"ent_K{K}"], rtol=1e-6)
+        np.testing.assert_allclose(
+            ops.log_determinant(L.detach()).cpu().numpy(), g[f"logdet_K{K}"],
+            rtol=1e-6)
+        np.testing.assert_allclose(
+            ops.maha(mean.detach(), T_(g[f"other_K{K}"]).cuda(),
+                     L.detach()).cpu().numpy(), g[f"maha_K{K}"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_mvn_logprob_backward_f64(ops, shared):
+    g = torch.Generator().manual_seed(0)
+    N, K = 9, 20
+    L = rand_chol(K, 1.0, g, 1 if shared else N)
+    mean = torch.randn(N, K, generator=g, dtype=F64)
+    x = mean + torch.randn(N, K, generator=g, dtype=F64)
+    w = torch.randn(N, generator=g, dtype=F64)
+    m_c = mean.clone().requires_grad_(True)
+    L_c = L.clone().requires_grad_(True)
+    (O.mvn_log_prob(x, m_c, L_c.expand(N, -1, -1)) * w).sum().backward()
+    m_g = mean.cuda().requires_grad_(True)
+    Lb = L.cuda().requires_grad_(True)
+    L_g = ops.expand_shared(Lb[0], N) if shared else Lb
+    lp = ops.mvn_log_prob(x.cuda(), m_g, L_g)
+    torch.testing.assert_close(
+        lp.cpu(), O.mvn_log_prob(x, mean, L.expand(N, -1, -1)),
+        rtol=1e-10, atol=1e-10)
+    (lp * w.cuda()).sum().backward()
+    torch.testing.assert_close(m_g.grad.cpu(), m_c.grad, rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(torch.tril(Lb.grad.cpu()), torch.tril(L_c.grad),
+                               rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_mean_projection_and_maha(ops, shared):
+    g = torch.Generator().manual_seed(1)
+    N, K = 33, 36
+    L_o = rand_chol(K, 1.0, g, 1 if shared else N)
+    mu_o = torch.randn(N, K, generator=g, dtype=F64)
+    mu = mu_o + 0.3 * torch.randn(N, K, generator=g, dtype=F64) * \
+        torch.rand(N, 1, generator=g, dtype=F64)
+    mu[0] = mu_o[0] + 1e-4                  # inactive row
+    eps = 0.5
+    w = torch.randn(N, K, generator=g, dtype=F64)
+    Lo_full = L_o.expand(N, -1, -1)
+    mu_c = mu.clone().requires_grad_(True)
+    maha_c, _ = KO.gaussian_kl(mu_c, Lo_full, mu_o, Lo_full)
+    pm_c = KO.mean_projection(mu_c, mu_o, maha_c, eps)
+    (pm_c * w).sum().backward()
+    Lg = ops.expand_shared(L_o[0].cuda(), N) if shared else L_o.cuda()
+    mu_g = mu.cuda().requires_grad_(True)
+    pm = ops.kl_mean_projection(mu_g, mu_o.cuda(), Lg, eps)
+    torch.testing.assert_close(pm.cpu(), pm_c.detach(), rtol=1e-10, atol=1e-10)
+    (pm * w.cuda()).sum().backward()
+    torch.testing.assert_close(mu_g.grad.cpu(), mu_c.grad, rtol=1e-8, atol=1e-9)
+    # tightness: projected mean part == eps where active
+    m2 = 0.5 * ops.maha(pm.detach(), mu_o.cuda(), Lg).cpu()
+    active = maha_c.detach() > eps
+    assert active.any() and (~active).any()
+    torch.testing.assert_close(m2[active], torch.full_like(m2[active], eps),
+                               rtol=1e-9, atol=1e-12)
+    # maha backward
+    x_g = mu.cuda().requires_grad_(True)
+    (ops.maha(x_g, mu_o.cuda(), Lg) * w[:, 0].cuda()).sum().backward()
+    x_c = mu.clone().requires_grad_(True)
+    (O.maha(x_c, mu_o, Lo_full) * w[:, 0]).sum().backward()
+    torch.testing.assert_close(x_g.grad.cpu(), x_c.grad, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("K", [5, 24, 36, 63])
+def test_kl_cov_part_fwd_bwd(ops, K):
+    g = torch.Generator().manual_seed(K)
+    B = 3
+    L = rand_chol(K, 1.0, g, B)
+    L_o = rand_chol(K, 1.0, g, B)
+    w = torch.randn(B, generator=g, dtype=F64)
+    L_c = L.clone().requires_grad_(True)
+    z = torch.zeros(B, K, dtype=F64)
+    _, cp = KO.gaussian_kl(z, L_c, z, L_o)
+    (cp * w).sum().backward()
+    L_g = L.cuda().requires_grad_(True)
+    out = ops.kl_cov_part(L_g, L_o.cuda(), B)
+    torch.testing.assert_close(out.cpu(), cp.detach(), rtol=1e-10, atol=1e-11)
+    (out * w.cuda()).sum().backward()
+    torch.testing.assert_close(torch.tril(L_g.grad.cpu()), torch.tril(L_c.grad),
+                               rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("K", [6, 24, 36, 63])
+@pytest.mark.parametrize("use_beta", [False, True])
+def test_kl_cov_projection_fwd_bwd(ops, K, use_beta):
+    g = torch.Generator().manual_seed(100 + K)
+    B = 3
+    L_o = rand_chol(K, 1.0, g, B)
+    L = rand_chol(K, 1.0, g, B)
+    L[2] = L_o[2] * 1.00001                 # inactive matrix
+    eps = 5e-3
+    W = torch.randn(B, K, K, generator=g, dtype=F64)
+    beta = None
+    if use_beta:
+        beta = torch.tensor(float(KO.entropy(L_o).mean()) + 0.05, dtype=F64)
+
+    def oracle(Lx):
+        cov = Lx @ Lx.transpose(-1, -2)
+        pc, eta = KO.cov_projection(cov, L_o, eps)
+        pl = torch.linalg.cholesky(pc)
+        if beta is not None:
+            _, pl = KO.entropy_projection(None, pl, beta)
+        return pl, eta
+
+    L_c = L.clone().requires_grad_(True)
+    pl_c, eta = oracle(L_c)
+    assert eta[0] > 0 and eta[1] > 0 and eta[2] == 0
+    (pl_c * W).sum().backward()
+    L_g = L.cuda().requires_grad_(True)
+    pl = ops.kl_cov_projection(L_g, L_o.cuda(), eps,
+                               None if beta is None else beta.cuda())
+    torch.testing.assert_close(pl.cpu(), pl_c.detach(), rtol=1e-8, atol=1e-9)
+    (pl * W.cuda()).sum().backward()
+    torch.testing.assert_close(torch.tril(L_g.grad.cpu()), torch.tril(L_c.grad),
+                               rtol=1e-6, atol=1e-7)
+    # KKT: the projected covariance part of the KL sits on the bound
+    if beta is None:
+        kl = ops.kl_cov_part(pl.detach(), L_o.cuda(), B).cpu()
+        torch.testing.assert_close(kl[:2], torch.full_like(kl[:2], eps),
+                                   rtol=1e-7, atol=1e-10)
+        assert kl[2] < eps
+
+
+def test_kl_cov_projection_fp32_close(ops):
+    """fp32 I/O (the Metaworld config): the solve itself is in double like the
+    reference's C++ solver, so the result is within fp32 rounding of the fp64
+    oracle."""
+    g = torch.Generator().manual_seed(7)
+    K = 36
+    L_o = rand_chol(K, 1.0, g)
+    L = rand_chol(K, 1.0, g)
+    pc, _ = KO.cov_projection(L @ L.transpose(-1, -2), L_o, 5e-4)
+    ref = torch.linalg.cholesky(pc)
+    out = ops.kl_cov_projection(L.float().cuda(), L_o.float().cuda(), 5e-4)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-6)
