@@ -220,6 +220,31 @@ int tce_kl_cov_proj_bwd_f64(const double* L, const double* L_old, int64_t L_old_
                             const double* grad_proj, double* grad_L, int64_t B, int K,
                             void* stream);
 
+/* ---- rollout buffer: observation running mean/std, MDP reward ------------
+ * rms_update: RunningMeanStd.update (mprl/util/util_numerical.py:315-337) of
+ *   x [R, D] into the running mean/var [D] (in place; unbiased batch variance,
+ *   parallel-moments merge); `count` is the running count BEFORE the update
+ *   (the caller adds R afterwards, the count lives on the host like in the
+ *   reference).  partials_ws: double [tce_rms_num_partials(), D, 2].
+ * rms_normalize: (x - mean) / sqrt(var + eps)
+ *   (mprl/rl/sampler/temporal_correlated_sampler.py:87-89), D = last dim.
+ * mdp_reward: make_mdp_reward (mprl/util/util_experiment.py:261-328), in place
+ *   on rewards [N,T] with the event flags [N,T] (1 byte each).
+ */
+int64_t tce_rms_num_partials(void);
+int tce_rms_update_f32(const float* x, int64_t R, int D, float* mean, float* var,
+                       double count, double* partials_ws, void* stream);
+int tce_rms_update_f64(const double* x, int64_t R, int D, double* mean, double* var,
+                       double count, double* partials_ws, void* stream);
+int tce_rms_normalize_f32(const float* x, float* y, int64_t total, int D,
+                          const float* mean, const float* var, float eps, void* stream);
+int tce_rms_normalize_f64(const double* x, double* y, int64_t total, int D,
+                          const double* mean, const double* var, double eps, void* stream);
+int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, int T,
+                       void* stream);
+int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

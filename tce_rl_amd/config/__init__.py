@@ -1,0 +1,69 @@
+"""Experiment configurations as Python dicts (same structure as the
+reference's YAML ``params`` documents, mprl/config/*/tcp|bbrl/entire/shared.yaml)
+for the BASELINE.json benchmark points."""
+
+
+def tce_config(env="metaworld", num_env=4096, num_basis=8, dtype="float32",
+               device="cuda", epochs=50, iterations=7600, seed=0,
+               evaluation_interval=0, num_env_test=None):
+    fam = {
+        # (env_id, dof, tau, delay, alpha, bbf, w_scale, g_scale, rel_goal, dt,
+        #  act, policy hidden, critic hidden, mean_bound, cov_bound, min_std)
+        "metaworld": ("metaworld_ProDMP_TCE/reach-v2", 4, 5.0, 0.0, 10, 5, 0.1,
+                      0.1, True, 0.0125, "relu", (128, 2), (128, 2), 0.005,
+                      0.0005, 1e-5),
+        "box_push": ("fancy_ProDMP_TCE/BoxPushingDense-v0", 7, 2.0, 0.0, 10, 3,
+                     0.3, 0.3, False, 0.02, "leaky_relu", (128, 2), (256, 2),
+                     0.05, 0.0005, 1e-4),
+        "table_tennis": ("fancy_ProDMP_TCE/TableTennisRndInit-v0", 7, 0.75, 0.3,
+                         25, 3, 0.7, 0.1, True, 0.008, "tanh", (256, 1),
+                         (256, 2), 0.005, 0.00025, 1e-5),
+    }[env]
+    (env_id, dof, tau, delay, alpha, bbf, ws, gs, rel, dt, act, ph, ch, mb, cb,
+     min_std) = fam
+    mp = {"type": "prodmp", "args": dict(
+        num_dof=dof, tau=tau, delay=delay, alpha_phase=3, num_basis=num_basis,
+        basis_bandwidth_factor=bbf, num_basis_outside=0, alpha=alpha,
+        disable_goal=False, relative_goal=rel, auto_scale_basis=True,
+        weights_scale=ws, goal_scale=gs, dt=dt, dtype=dtype, device=device)}
+    critic_act = "leaky_relu" if env == "table_tennis" else act
+    params = {
+        "agent": {"type": "TemporalCorrelatedAgent", "args": dict(
+            lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0, wd_critic=0.0,
+            schedule_lr_policy=True, schedule_lr_critic=True, clip_critic=0.0,
+            clip_grad_norm=0.0, entropy_penalty_coef=0.0, discount_factor=1,
+            gae_scaling=0.95, epochs_policy=epochs, epochs_critic=epochs,
+            num_minibatchs=1, norm_advantages=True, clip_advantages=0.0,
+            use_gae=True, segment_advantage="value_subtraction",
+            set_variance=False, balance_check=25,
+            evaluation_interval=evaluation_interval, dtype=dtype,
+            device=device)},
+        "mp": mp,
+        "policy": {"type": "TemporalCorrelatedPolicy", "args": dict(
+            mean_net_args=dict(avg_neuron=ph[0], num_hidden=ph[1], shape=0.0),
+            variance_net_args=dict(std_only=False, contextual=False),
+            init_method="orthogonal", out_layer_gain=0.01, min_std=min_std,
+            act_func_hidden=act, act_func_last=None, dtype=dtype,
+            device=device, mp=mp)},
+        "critic": {"type": "ValueFunction", "args": dict(
+            hidden=dict(avg_neuron=ch[0], num_hidden=ch[1], shape=0.0),
+            init_method="orthogonal", out_layer_gain=1,
+            act_func_hidden=critic_act, act_func_last=None, dtype=dtype,
+            device=device)},
+        "projection": {"type": "KLProjectionLayer", "args": dict(
+            proj_type="kl", mean_bound=mb, cov_bound=cb,
+            trust_region_coeff=1.0, scale_prec=True, entropy_schedule="linear",
+            target_entropy=0, temperature=0.7, entropy_eq=False,
+            entropy_first=False, do_regression=False, dtype=dtype,
+            device=device)},
+        "sampler": {"type": "TemporalCorrelatedSampler", "args": dict(
+            env_id=env_id, num_env_train=num_env,
+            num_env_test=num_env_test or min(num_env, 64),
+            episodes_per_train_env=1, episodes_per_test_env=1,
+            norm_step_obs=True,
+            time_pairs_config=dict(num_select=25, fixed_interval=True),
+            dtype=dtype, device=device, seed=seed,
+            task_specified_metrics=["success"])},
+    }
+    return {"name": "tce_" + env, "seed": seed, "iterations": iterations,
+            "verbose_level": 2, "params": params}

@@ -1,0 +1,164 @@
+// Rollout-buffer kernels for gfx950: observation running mean/std (k12) and
+// the non-MDP -> MDP reward re-shaping (k13).
+//
+//   RunningMeanStd.update / update_from_moments   mprl/util/util_numerical.py:315-337
+//   TemporalCorrelatedSampler.apply_normalization mprl/rl/sampler/temporal_correlated_sampler.py:87-89
+//   make_mdp_reward                               mprl/util/util_experiment.py:261-328
+//
+// col_moments: one pass over x [R, D] (R = N*(T+1) rows, HBM-bound: R*D*4 B):
+// thread <-> (row lane, column) so that a workgroup reads whole rows
+// (coalesced), per-thread shifted sums in double, LDS column reduction, one
+// partial per workgroup; rms_finalize merges them into the running statistics
+// with the reference's parallel-moments formula (unbiased batch variance).
+#include "common.h"
+
+namespace {
+
+constexpr int RM_BT = 256;
+
+template <typename real>
+__global__ __launch_bounds__(RM_BT) void col_moments_kernel(
+    const real* __restrict__ x, int64_t R, int D, const real* __restrict__ shift,
+    double* __restrict__ partials /* [gridDim.x][D][2] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s1 = reinterpret_cast<double*>(smem_raw);      // [rows_per_pass][D]
+  const int rpp = RM_BT / D;                              // row lanes per pass
+  double* s2 = s1 + rpp * D;
+  const int tid = threadIdx.x;
+  const int rl = tid / D, c = tid - rl * D;
+  const bool live = rl < rpp;
+  const double k = (live && shift) ? (double)shift[c] : 0.0;
+  double a1 = 0, a2 = 0;
+  if (live) {
+    const int64_t per = (R + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * per, hi = tmin<int64_t>(R, lo + per);
+    for (int64_t r = lo + rl; r < hi; r += rpp) {
+      const double v = (double)x[r * D + c] - k;
+      a1 += v;
+      a2 += v * v;
+    }
+    s1[rl * D + c] = a1;
+    s2[rl * D + c] = a2;
+  }
+  __syncthreads();
+  if (tid < D) {
+    double t1 = 0, t2 = 0;
+    for (int i = 0; i < rpp; ++i) { t1 += s1[i * D + tid]; t2 += s2[i * D + tid]; }
+    partials[((int64_t)blockIdx.x * D + tid) * 2 + 0] = t1;
+    partials[((int64_t)blockIdx.x * D + tid) * 2 + 1] = t2;
+  }
+}
+
+// mean/var [D] (running, updated in place), count/batch_count from the host.
+template <typename real>
+__global__ __launch_bounds__(256) void rms_finalize_kernel(
+    const double* __restrict__ partials, int nparts, int D,
+    const real* shift /* may alias mean */, double batch_count, double count,
+    real* mean, real* var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  double t1 = 0, t2 = 0;
+  for (int i = 0; i < nparts; ++i) {
+    t1 += partials[((int64_t)i * D + c) * 2 + 0];
+    t2 += partials[((int64_t)i * D + c) * 2 + 1];
+  }
+  const double k = shift ? (double)shift[c] : 0.0;
+  const double n = batch_count;
+  const double b_mean = k + t1 / n;
+  const double b_var = n > 1 ? (t2 - t1 * t1 / n) / (n - 1.0) : (double)NAN;  // unbiased
+  // update_from_moments (util_numerical.py:321-337)
+  const double m = (double)mean[c], v = (double)var[c];
+  const double delta = b_mean - m;
+  const double tot = count + n;
+  const double new_mean = m + delta * n / tot;
+  const double m2 = v * count + b_var * n + delta * delta * count * n / tot;
+  mean[c] = (real)new_mean;
+  var[c] = (real)(m2 / tot);
+}
+
+// y = (x - mean) / sqrt(var + eps), column = flat index % D
+template <typename real>
+__global__ __launch_bounds__(256) void rms_normalize_kernel(
+    const real* __restrict__ x, real* __restrict__ y, int64_t total, int D,
+    const real* __restrict__ mean, const real* __restrict__ var, real eps) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % D);
+    y[i] = (x[i] - mean[c]) / sqrt(var[c] + eps);
+  }
+}
+
+// make_mdp_reward: one thread per env row.
+template <typename real>
+__global__ __launch_bounds__(256) void mdp_reward_kernel(real* __restrict__ r,
+                                                         const uint8_t* __restrict__ flags,
+                                                         int64_t N, int T) {
+  const int64_t n = blockIdx.x * 256ll + threadIdx.x;
+  if (n >= N) return;
+  real* row = r + n * (int64_t)T;
+  const uint8_t* f = flags + n * (int64_t)T;
+  int first = 0;                     // argmax of a 0/1 row: first 1, else 0
+  bool found = false;
+  real after = 0;
+  for (int t = 0; t < T; ++t) {
+    if (f[t]) {
+      if (!found) { first = t; found = true; }
+      after += row[t];
+    }
+  }
+  if (first > 0) {                   // reference: event_index_first > 0
+    row[first] = after;
+    for (int t = first + 1; t < T; ++t) row[t] = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+#define TCE_RMS_BLOCKS 1024
+
+int64_t tce_rms_num_partials(void) { return TCE_RMS_BLOCKS; }
+
+#define DEFINE_ROLLOUT(SFX, REAL)                                                  \
+  int tce_rms_update_##SFX(const REAL* x, int64_t R, int D, REAL* mean, REAL* var, \
+                           double count, double* partials_ws, void* stream) {      \
+    TCE_CHECK_ARG(x && mean && var && partials_ws && R > 0 && D > 0 && D <= 256,   \
+                  "rms_update: bad arguments (D <= 256)");                         \
+    const int rpp = RM_BT / D;                                                     \
+    const size_t lds = 2 * (size_t)rpp * D * sizeof(double);                       \
+    const int nb = (int)tmin<int64_t>(TCE_RMS_BLOCKS, ceil_div(R, rpp));           \
+    hipLaunchKernelGGL(col_moments_kernel<REAL>, dim3(nb), dim3(RM_BT), lds,       \
+                       (hipStream_t)stream, x, R, D, mean, partials_ws);           \
+    TCE_LAUNCH_CHECK();                                                            \
+    hipLaunchKernelGGL(rms_finalize_kernel<REAL>, dim3((unsigned)ceil_div(D, 256)), \
+                       dim3(256), 0, (hipStream_t)stream, partials_ws, nb, D,      \
+                       mean, (double)R, count, mean, var);                         \
+    TCE_LAUNCH_CHECK();                                                            \
+    return 0;                                                                      \
+  }                                                                                \
+  int tce_rms_normalize_##SFX(const REAL* x, REAL* y, int64_t total, int D,        \
+                              const REAL* mean, const REAL* var, REAL eps,         \
+                              void* stream) {                                      \
+    TCE_CHECK_ARG(x && y && mean && var && total > 0 && D > 0,                     \
+                  "rms_normalize: bad arguments");                                 \
+    const int64_t nb = tmin<int64_t>(ceil_div(total, 256), 8192);                  \
+    hipLaunchKernelGGL(rms_normalize_kernel<REAL>, dim3((unsigned)nb), dim3(256),  \
+                       0, (hipStream_t)stream, x, y, total, D, mean, var, eps);    \
+    TCE_LAUNCH_CHECK();                                                            \
+    return 0;                                                                      \
+  }                                                                                \
+  int tce_mdp_reward_##SFX(REAL* rewards, const uint8_t* event_flags, int64_t N,   \
+                           int T, void* stream) {                                  \
+    TCE_CHECK_ARG(rewards && event_flags && N > 0 && T > 0,                        \
+                  "mdp_reward: bad arguments");                                    \
+    hipLaunchKernelGGL(mdp_reward_kernel<REAL>, dim3((unsigned)ceil_div(N, 256)),  \
+                       dim3(256), 0, (hipStream_t)stream, rewards, event_flags, N, \
+                       T);                                                         \
+    TCE_LAUNCH_CHECK();                                                            \
+    return 0;                                                                      \
+  }
+
+DEFINE_ROLLOUT(f32, float)
+DEFINE_ROLLOUT(f64, double)
+
+}  // extern "C"

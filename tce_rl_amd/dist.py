@@ -1,0 +1,56 @@
+"""Env-sharded data parallelism over RCCL (torch.distributed, one process per
+GPU).  The reference is single-device (no collectives anywhere under mprl/);
+this is the new exchange step of the sharded path:
+
+* one flat all-reduce (sum) of the gradients per optimizer step, divided by the
+  world size -- policy + critic are replicated, every rank holds N/world envs,
+  local losses are means over the local shard, so the result equals the
+  reference's global-batch mean gradient;
+* merged (count, mean, M2) statistics for advantage normalisation
+  (ops.merge_stats) and a mean of the initial entropy.
+
+Messages are tiny (<= ~300 KB): latency-bound, so exactly one collective per
+step on one flat buffer.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DistContext:
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self._flat = {}
+
+    def allreduce_grads(self, params):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in params]
+        key = id(params)
+        n = sum(g.numel() for g in grads)
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() != n or flat.device != grads[0].device:
+            flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+            self._flat[key] = flat
+        torch.cat([g.reshape(-1) for g in grads], out=flat)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def mean_scalar(self, x):
+        if self.world == 1:
+            return x
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y / self.world
+
+    def broadcast_params(self, params):
+        if self.world == 1:
+            return
+        for p in params:
+            dist.broadcast(p.data, src=0, group=self.group)

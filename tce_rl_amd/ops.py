@@ -506,3 +506,51 @@ def kl_cov_projection(L, L_old, eps_cov, beta=None, entropy_eq=False):
     if beta is not None:
         beta = _c(beta.detach().to(L.dtype).reshape(1))
     return _KLCovProj.apply(L, Lo, sLo, eps_cov, beta, entropy_eq)
+
+
+# ---------------------------------------------------------------------------
+# rollout buffer: running mean/std of observations, MDP reward (rollout.hip)
+# ---------------------------------------------------------------------------
+def rms_update(x, mean, var, count):
+    """RunningMeanStd.update of x [R, D] into mean/var [D] (in place); returns
+    the new count (host float, as in the reference)."""
+    check_dev(x, mean, var)
+    x = _c(x)
+    R, D = x.shape
+    ws = torch.empty(_lib.load().tce_rms_num_partials(), D, 2,
+                     dtype=torch.float64, device=x.device)
+    call("tce_rms_update_" + sfx(x.dtype), ptr(x), R, D, ptr(mean), ptr(var),
+         float(count), ptr(ws), stream())
+    return count + R
+
+
+def rms_normalize(x, mean, var, eps=1e-8):
+    check_dev(x, mean, var)
+    x = _c(x)
+    y = torch.empty_like(x)
+    call("tce_rms_normalize_" + sfx(x.dtype), ptr(x), ptr(y), x.numel(),
+         x.shape[-1], ptr(mean), ptr(var), float(eps), stream())
+    return y
+
+
+def mdp_reward(step_rewards, event_flags):
+    """make_mdp_reward: returns the re-shaped rewards (new tensor)."""
+    check_dev(step_rewards, event_flags)
+    r = _c(step_rewards).clone()
+    N, T = r.shape
+    call("tce_mdp_reward_" + sfx(r.dtype), ptr(r), ptr(_bool_u8(event_flags)),
+         N, T, stream())
+    return r
+
+
+# ---------------------------------------------------------------------------
+# MLP forward (csrc/mlp.hip: fused MFMA kernels; see mlp_forward below)
+# ---------------------------------------------------------------------------
+_ACT = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3, None: -1}
+
+
+def mlp_forward(mlp, x):
+    """MLP.forward (mprl/util/util_nn.py:225-246): hidden layers with the
+    hidden activation, then the output layer (+ optional last activation)."""
+    from . import mlp_ops
+    return mlp_ops.forward(mlp, x)

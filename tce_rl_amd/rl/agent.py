@@ -1,0 +1,589 @@
+"""Agents: mirror of mprl/rl/agent/ (abstract_agent.py:12-255,
+temporal_correlated_agent.py:12-753, black_box_agent.py:12-495).
+
+``step()`` keeps the whole iteration on the device: rollout buffers, GAE /
+segment advantages, critic and policy epochs.  Per-epoch scalars are collected
+in device tensors and copied to the host ONCE at the end of the update (the
+reference synchronises >= 20 times per policy epoch: ``.item()`` x4,
+``to_np`` x12, NaN checks x3, grad-norm ``.item()`` per parameter).
+
+Multi-GPU (env sharding): every rank holds ``num_env_train / world`` envs and a
+replica of policy / critic; gradients are summed with one flat all-reduce per
+optimizer step and divided by the world size (local losses are means over the
+local shard, shards are equal, so this equals the reference's global mean);
+advantage statistics are merged over ranks before normalisation.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import LinearLR
+
+from .. import ops, util
+from ..dist import DistContext
+from .projection import gaussian_kl_details
+
+
+class AbstractAgent(ABC):
+    def __init__(self, policy, critic, sampler, projection,
+                 dtype="torch.float32", device="cpu", **kwargs):
+        self.policy, self.critic = policy, critic
+        self.sampler, self.projection = sampler, projection
+        self.dtype, self.device = util.parse_dtype_device(dtype, device)
+        self.lr_policy = float(kwargs["lr_policy"])
+        self.lr_critic = float(kwargs["lr_critic"])
+        self.wd_policy = float(kwargs["wd_policy"])
+        self.wd_critic = float(kwargs["wd_critic"])
+        self.schedule_lr_policy = kwargs.get("schedule_lr_policy", False)
+        self.schedule_lr_critic = kwargs.get("schedule_lr_critic", False)
+        self.total_iterations = kwargs.get("total_iterations", 10000)
+        self.discount_factor = float(kwargs["discount_factor"])
+        self.epochs_policy = kwargs["epochs_policy"]
+        self.epochs_critic = kwargs["epochs_critic"]
+        self.dist = DistContext(kwargs.get("process_group", None))
+        self.policy_net_params = None
+        self.critic_net_params = None
+        self.policy_optimizer, self.critic_optimizer = \
+            self.get_optimizer(self.policy, self.critic)
+        self.policy_lr_scheduler, self.critic_lr_scheduler = \
+            self.get_lr_scheduler()
+        self.num_iterations = 0
+        self.num_global_steps = 0
+        if self.dist.world > 1:
+            self.dist.broadcast_params(self.policy_net_params +
+                                       self.critic_net_params)
+
+    def get_optimizer(self, policy, critic):
+        """Adam with L2-in-gradient weight decay (abstract_agent.py:62-82)."""
+        self.policy_net_params = policy.parameters
+        self.critic_net_params = critic.parameters
+        mk = lambda params, lr, wd: torch.optim.Adam(
+            params=params, lr=lr, weight_decay=wd, fused=True)
+        return mk(self.policy_net_params, self.lr_policy, self.wd_policy), \
+            mk(self.critic_net_params, self.lr_critic, self.wd_critic)
+
+    def get_lr_scheduler(self):
+        mk = lambda opt: LinearLR(opt, start_factor=1, end_factor=0.01,
+                                  total_iters=self.total_iterations)
+        return (mk(self.policy_optimizer) if self.schedule_lr_policy else None,
+                mk(self.critic_optimizer) if self.schedule_lr_critic else None)
+
+    def save_agent(self, log_dir, epoch):
+        self.policy.save_weights(log_dir, epoch)
+        self.critic.save_weights(log_dir, epoch)
+        for name, opt in (("policy_optimizer", self.policy_optimizer),
+                          ("critic_optimizer", self.critic_optimizer)):
+            path = util.get_training_state_save_path(log_dir, name, epoch)
+            with open(path, "wb") as f:
+                torch.save(opt.state_dict(), f)
+
+    def load_agent(self, log_dir, epoch):
+        self.policy.load_weights(log_dir, epoch)
+        self.critic.load_weights(log_dir, epoch)
+        self.policy_optimizer, self.critic_optimizer = \
+            self.get_optimizer(self.policy, self.critic)
+        for name, opt in (("policy_optimizer", self.policy_optimizer),
+                          ("critic_optimizer", self.critic_optimizer)):
+            path = util.get_training_state_save_path(log_dir, name, epoch)
+            opt.load_state_dict(torch.load(path, map_location=self.device))
+        self.policy_lr_scheduler, self.critic_lr_scheduler = \
+            self.get_lr_scheduler()
+        self.num_iterations = epoch
+
+    @abstractmethod
+    def step(self, *args, **kwargs):
+        pass
+
+    @abstractmethod
+    def update_policy(self, *args, **kwargs):
+        pass
+
+    @abstractmethod
+    def update_critic(self, *args, **kwargs):
+        pass
+
+    @torch.no_grad()
+    def evaluate(self, evaluate_deterministic=True, evaluate_stochastic=False,
+                 render=False):
+        det = self.sampler.run(training=False, policy=self.policy,
+                               critic=self.critic,
+                               deterministic=evaluate_deterministic,
+                               render=render)[0] \
+            if evaluate_deterministic else dict()
+        sto = self.sampler.run(training=False, policy=self.policy,
+                               critic=self.critic, deterministic=False,
+                               render=render)[0] \
+            if evaluate_stochastic else dict()
+        return det, sto
+
+    # ---- shared pieces of the update loops --------------------------------
+    def _grad_norm_clip(self, bound, params):
+        """util_numerical.py:244-275 without host syncs: returns the two norms
+        as 0-dim device tensors."""
+        grads = [p.grad for p in params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        before = flat.norm(2)
+        if bound > 0:
+            coef = torch.clamp(bound / (before + 1e-6), max=1.0)
+            for g in grads:
+                g.mul_(coef)
+            after = before * coef
+        else:
+            after = before
+        return before, after
+
+    def _optimizer_step(self, opt, params, clip):
+        self.dist.allreduce_grads(params)
+        norms = self._grad_norm_clip(clip, params)
+        opt.step()
+        return norms
+
+    @staticmethod
+    def _check_nan(flags):
+        """One host read for all NaN flags of an update."""
+        if flags:
+            bad = torch.stack(flags).any(dim=0).cpu().numpy()
+            for name, b in zip(("surrogate_loss", "entropy_loss",
+                                "trust_region_loss"), bad):
+                if b:
+                    raise Exception("NAN %s detected" % name)
+
+
+class TemporalCorrelatedAgent(AbstractAgent):
+    def __init__(self, policy, critic, sampler, projection,
+                 dtype=torch.float32, device=torch.device("cpu"), **kwargs):
+        super().__init__(policy, critic, sampler, projection, dtype=dtype,
+                         device=device, **kwargs)
+        self.clip_critic = float(kwargs.get("clip_critic", 0.0))
+        self.clip_grad_norm = float(kwargs.get("clip_grad_norm", 0.0))
+        self.num_minibatchs = kwargs.get("num_minibatchs", 10)
+        self.norm_advantages = kwargs.get("norm_advantages", False)
+        self.clip_advantages = kwargs.get("clip_advantages", False)
+        self.entropy_penalty_coef = float(
+            kwargs.get("entropy_penalty_coef", 0.0))
+        self.use_gae = kwargs.get("use_gae", True)
+        self.gae_scaling = float(kwargs.get("gae_scaling", 0.95))
+        self.segment_advantage = kwargs.get("segment_advantage", "accumulate")
+        self.set_variance = kwargs.get("set_variance", False)
+        self.balance_check = kwargs.get("balance_check", 10)
+        self.evaluation_interval = kwargs.get("evaluation_interval", 1)
+        self.check_policy_balance = False
+
+    def step(self):
+        self.num_iterations += 1
+        util.run_time_test(lock=True, key="sampling")
+        dataset, num_env_interaction = self.sampler.run(
+            training=True, policy=self.policy, critic=self.critic)
+        self.num_global_steps += num_env_interaction * self.dist.world
+        sampling_time = util.run_time_test(lock=False, key="sampling")
+
+        util.run_time_test(lock=True, key="process_dataset")
+        dataset = self.process_dataset(dataset)
+        process_dataset_time = util.run_time_test(lock=False,
+                                                  key="process_dataset")
+        dataset_stats = util.device_stats(
+            {k: v for k, v in dataset.items()
+             if k not in ("segment_params_L", "step_states_full",
+                          "step_states", "step_actions")}, "exploration")
+
+        util.run_time_test(lock=True, key="update")
+        util.run_time_test(lock=True, key="update critic")
+        critic_loss_dict = self.update_critic(dataset)
+        if self.schedule_lr_critic:
+            self.critic_lr_scheduler.step()
+        update_critic_time = util.run_time_test(lock=False,
+                                                key="update critic")
+        util.run_time_test(lock=True, key="update policy")
+        policy_loss_dict = self.update_policy(dataset)
+        if self.schedule_lr_policy:
+            self.policy_lr_scheduler.step()
+        update_policy_time = util.run_time_test(lock=False,
+                                                key="update policy")
+        update_time = util.run_time_test(lock=False, key="update")
+
+        result_metrics = {
+            **dataset_stats, **critic_loss_dict, **policy_loss_dict,
+            "sampling_time": sampling_time,
+            "process_dataset_time": process_dataset_time,
+            "update_time": update_time,
+            "update_critic_time": update_critic_time,
+            "update_policy_time": update_policy_time,
+            "num_global_steps": self.num_global_steps,
+            "lr_policy": self.policy_lr_scheduler.get_last_lr()[0]
+            if self.schedule_lr_policy else self.lr_policy,
+            "lr_critic": self.critic_lr_scheduler.get_last_lr()[0]
+            if self.schedule_lr_critic else self.lr_critic}
+
+        # evaluation_interval 0 / None: never (extension; reference default 1)
+        if self.evaluation_interval and (
+                self.evaluation_interval == 1 or
+                self.num_iterations % self.evaluation_interval == 1):
+            util.run_time_test(lock=True, key="evaluation")
+            ev = self.evaluate()[0]
+            result_metrics.update(util.device_stats(
+                {k: v for k, v in ev.items()
+                 if k not in ("segment_params_L", "step_states_full",
+                              "step_states", "step_actions")}, "evaluation"))
+            result_metrics["evaluation_time"] = util.run_time_test(
+                lock=False, key="evaluation")
+        return result_metrics
+
+    # ---- dataset processing (GAE + segment advantage: HIP kernels) -----------
+    def process_dataset(self, dataset):
+        rewards, values = dataset["step_rewards"], dataset["step_values"]
+        pred_pairs = self.sampler.pred_pairs
+        fuse = self.segment_advantage == "value_subtraction"
+        res = ops.gae(rewards, values, dataset["step_dones"],
+                      dataset["step_time_limit_dones"], self.discount_factor,
+                      self.gae_scaling, self.use_gae,
+                      pred_pairs if fuse else None)
+        dataset["step_advantages"], dataset["step_returns"] = res[0], res[1]
+        dataset["segment_advantage"] = self.get_segment_advantage(
+            rewards, values, res[0], pred_pairs,
+            fused=(res[2], res[3]) if fuse else None)
+        return dataset
+
+    def get_advantage_return(self, rewards, values, dones, time_limit_dones):
+        return ops.gae(rewards, values, dones, time_limit_dones,
+                       self.discount_factor, self.gae_scaling, self.use_gae)
+
+    def get_segment_advantage(self, rewards, values, advantages, pred_pairs,
+                              fused=None, **kwargs):
+        return ops.segment_advantage(
+            self.segment_advantage, rewards, values, advantages, pred_pairs,
+            self.discount_factor, self.norm_advantages,
+            float(self.clip_advantages or 0.0), group=self.dist.group,
+            fused=fused)
+
+    # ---- critic ----------------------------------------------------------------
+    def update_critic(self, dataset):
+        D2 = self.policy.num_dof * 2
+        states = dataset["step_states"]                  # [N, T, D] (view)
+        N, T = states.shape[:2]
+        old_values = dataset["step_values"][:, :-1]
+        returns = dataset["step_returns"]
+        losses, norms, norms_c = [], [], []
+        for _ in range(self.epochs_critic):
+            for sel in self._minibatches(N * T):
+                if sel is None:
+                    s_in = states[..., :-D2]
+                    v_old, ret = old_values, returns
+                else:
+                    s_in = states.reshape(N * T, -1)[sel][..., :-D2]
+                    v_old = old_values.reshape(-1)[sel]
+                    ret = returns.reshape(-1)[sel]
+                values_new = self.critic.critic(s_in).squeeze(-1)
+                loss = self.value_loss(values_new, ret, v_old)
+                self.critic_optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                g, gc = self._optimizer_step(self.critic_optimizer,
+                                             self.critic_net_params,
+                                             self.clip_grad_norm)
+                losses.append(loss.detach())
+                norms.append(g)
+                norms_c.append(gc)
+        host = torch.stack([torch.stack(losses), torch.stack(norms),
+                            torch.stack(norms_c)]).cpu().numpy()
+        return {**util.generate_stats(host[0], "critic_loss"),
+                **util.generate_stats(host[1], "critic_grad_norm"),
+                **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+
+    def _minibatches(self, n):
+        """generate_minibatches (util_data_structure.py:378-391).  With ONE
+        minibatch the permutation does not change the full-batch mean loss, so
+        no gather is done (and the numpy generator is not consumed)."""
+        if self.num_minibatchs == 1:
+            return [None]
+        idx = np.arange(n)
+        np.random.shuffle(idx)
+        return [torch.as_tensor(s, device=self.device)
+                for s in np.array_split(idx, self.num_minibatchs)]
+
+    # ---- policy ------------------------------------------------------------------
+    def update_policy(self, dataset):
+        D2 = self.policy.num_dof * 2
+        states = dataset["segment_state"][..., :-D2]
+        actions = dataset["step_actions"]
+        log_probs_old = dataset["segment_log_prob_estimate"]
+        mean_old = dataset["segment_params_mean"]
+        L_old = dataset["segment_params_L"]
+        seg_adv = dataset["segment_advantage"]
+        init_time = dataset["segment_init_time"]
+        init_pos = dataset["segment_init_pos"]
+        init_vel = dataset["segment_init_vel"]
+        times = self.sampler.get_times(init_time, self.sampler.num_times)
+        pred_pairs = self.sampler.pred_pairs
+
+        if self.projection.initial_entropy is None:
+            ent0 = self.policy.entropy([mean_old, L_old]).mean()
+            self.projection.initial_entropy = self.dist.mean_scalar(ent0)
+
+        self.check_policy_balance = isinstance(self.balance_check, int) and \
+            self.num_iterations % self.balance_check == 1
+
+        def forward():
+            mean_new, L_new = self.policy.policy(states)
+            proj = self.projection(self.policy, (mean_new, L_new),
+                                   (mean_old, L_old), self.num_iterations)
+            return mean_new, L_new, proj[0], proj[1]
+
+        def lp(proj_mean, proj_L):
+            return self.policy.log_prob(
+                actions, params_mean=proj_mean, params_L=proj_L, times=times,
+                init_time=init_time, init_pos=init_pos, init_vel=init_vel,
+                pred_pairs=pred_pairs)
+
+        rows, kl_rows, nan_flags = [], [], []
+        surr_gn, tr_gn = [], []
+        util.run_time_test(lock=True, key="projection", sync=False)
+        for _ in range(self.epochs_policy):
+            if self.check_policy_balance:
+                mean_new, L_new, pm, pL = forward()
+                s_loss, _ = self.surrogate_loss(seg_adv, lp(pm, pL),
+                                                log_probs_old)
+                self.policy_optimizer.zero_grad(set_to_none=True)
+                s_loss.backward()
+                surr_gn.append(self._grad_norm_clip(
+                    0.0, self.policy_net_params)[0])
+                mean_new, L_new, pm, pL = forward()
+                t_loss = self.projection.get_trust_region_loss(
+                    self.policy, (mean_new, L_new), (pm, pL),
+                    set_variance=self.set_variance)
+                self.policy_optimizer.zero_grad(set_to_none=True)
+                t_loss.backward()
+                tr_gn.append(self._grad_norm_clip(
+                    0.0, self.policy_net_params)[0])
+
+            mean_new, L_new, proj_mean, proj_L = forward()
+            log_prob_new = lp(proj_mean, proj_L)
+            surrogate_loss, ratio = self.surrogate_loss(
+                seg_adv, log_prob_new, log_probs_old)
+            with torch.no_grad():
+                kl_rows.append(self.kl_old_new_proj(
+                    mean_new, L_new, mean_old, L_old, proj_mean, proj_L))
+            entropy = self.policy.entropy([proj_mean, proj_L]).mean()
+            entropy_loss = -self.entropy_penalty_coef * entropy
+            trust_region_loss = self.projection.get_trust_region_loss(
+                self.policy, (mean_new, L_new), (proj_mean, proj_L),
+                set_variance=self.set_variance)
+            nan_flags.append(torch.isnan(torch.stack(
+                [surrogate_loss.detach(), entropy_loss.detach(),
+                 trust_region_loss.detach()])))
+            policy_loss = surrogate_loss + entropy_loss + trust_region_loss
+            self.policy_optimizer.zero_grad(set_to_none=True)
+            policy_loss.backward()
+            g, gc = self._optimizer_step(self.policy_optimizer,
+                                         self.policy_net_params,
+                                         self.clip_grad_norm)
+            rows.append(torch.stack([
+                surrogate_loss.detach(), entropy_loss.detach(),
+                trust_region_loss.detach(), policy_loss.detach(),
+                entropy.detach(), g, gc]))
+        projection_time = util.run_time_test(lock=False, key="projection",
+                                             sync=False)
+
+        self._check_nan(nan_flags)
+        host = torch.stack(rows).cpu().numpy()            # ONE copy
+        kl_host = torch.stack(kl_rows).cpu().numpy()
+        names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
+                 "policy_loss", "entropy", "policy_grad_norm",
+                 "clipped_policy_grad_norm")
+        out = {}
+        for i, n in enumerate(names):
+            out.update(util.generate_stats(host[:, i], n))
+        kl_names = [a + "_" + b for a in ("new_old", "new_proj", "proj_old")
+                    for b in ("mean_diff", "cov_diff", "shape_diff",
+                              "volume_diff")]
+        for i, n in enumerate(kl_names):
+            out.update(util.generate_stats(kl_host[:, i], "projection_" + n))
+        out["projection_time"] = projection_time
+        if self.check_policy_balance:
+            sg = torch.stack(surr_gn).cpu().numpy()
+            tg = torch.stack(tr_gn).cpu().numpy()
+            out.update(util.generate_stats(sg, "surrogate_grad_norm"))
+            out.update(util.generate_stats(tg, "trust_region_grad_norm"))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                out["balance_ratio"] = float(
+                    np.float64(out["surrogate_grad_norm_mean"]) /
+                    np.float64(out["trust_region_grad_norm_mean"]))
+
+        if self.set_variance and not self.policy.contextual_cov:
+            with torch.no_grad():
+                _, _, _, pL = forward()
+                self.policy.set_cov_variable(pL)
+        return out
+
+    def kl_old_new_proj(self, mean_new, L_new, mean_old, L_old, proj_mean,
+                        proj_L):
+        """12 scalars (means over the batch) as one device vector."""
+        parts = []
+        for p, q in (((mean_new, L_new), (mean_old, L_old)),
+                     ((mean_new, L_new), (proj_mean, proj_L)),
+                     ((proj_mean, proj_L), (mean_old, L_old))):
+            parts.extend(d.mean() for d in
+                         gaussian_kl_details(self.policy, p, q))
+        return torch.stack(parts)
+
+    def value_loss(self, values, returns, old_vs):
+        vf_loss = (returns - values).pow(2)
+        if self.clip_critic > 0:
+            vs_clipped = old_vs + (values - old_vs).clamp(-self.clip_critic,
+                                                          self.clip_critic)
+            vf_loss = torch.max(vf_loss, (vs_clipped - returns).pow(2))
+        return vf_loss.mean()
+
+    @staticmethod
+    def surrogate_loss(advantages, log_prob_new, log_prob_old):
+        ratio = (log_prob_new - log_prob_old).exp()
+        return -(ratio * advantages).mean(), ratio.mean().detach()
+
+    def entropy_loss(self, params_mean, params_L):
+        entropy = self.policy.entropy([params_mean, params_L]).mean()
+        return -self.entropy_penalty_coef * entropy, {"entropy": entropy}
+
+    def save_agent(self, log_dir, epoch):
+        super().save_agent(log_dir, epoch)
+        self.sampler.save_rms(log_dir, epoch)
+
+    def load_agent(self, log_dir, epoch):
+        super().load_agent(log_dir, epoch)
+        self.sampler.load_rms(log_dir, epoch)
+
+
+class BlackBoxAgent(TemporalCorrelatedAgent):
+    """black_box_agent.py: episode-level advantage R - V(s0), critic regresses
+    the episode return, param-space log-prob; otherwise the same update."""
+
+    def step(self):
+        self.num_iterations += 1
+        util.run_time_test(lock=True, key="sampling")
+        dataset, n_steps = self.sampler.run(training=True, policy=self.policy,
+                                            critic=self.critic)
+        self.num_global_steps += n_steps * self.dist.world
+        sampling_time = util.run_time_test(lock=False, key="sampling")
+        dataset = self.process_dataset(dataset)
+        dataset_stats = util.device_stats(
+            {k: v for k, v in dataset.items()
+             if k not in ("segment_params_L", "segment_state")}, "exploration")
+        util.run_time_test(lock=True, key="update")
+        critic_loss_dict = self.update_critic(dataset)
+        policy_loss_dict = self.update_policy(dataset)
+        update_time = util.run_time_test(lock=False, key="update")
+        result = {**dataset_stats, **critic_loss_dict, **policy_loss_dict,
+                  "sampling_time": sampling_time, "update_time": update_time,
+                  "num_global_steps": self.num_global_steps,
+                  "lr_policy": self.lr_policy, "lr_critic": self.lr_critic}
+        if self.evaluation_interval and (
+                self.evaluation_interval == 1 or
+                self.num_iterations % self.evaluation_interval == 1):
+            ev = self.evaluate()[0]
+            result.update(util.device_stats(
+                {k: v for k, v in ev.items()
+                 if k not in ("segment_params_L", "segment_state")},
+                "evaluation"))
+        return result
+
+    def process_dataset(self, dataset):
+        adv = dataset["segment_reward"] - dataset["segment_value"]
+        stats = ops.moments(adv, self.dist.group) \
+            if self.norm_advantages else None
+        if stats is not None or self.clip_advantages > 0:
+            adv = ops.normalize(adv, stats, 1e-8,
+                                float(self.clip_advantages or 0.0),
+                                single_std_one=True)
+        dataset["segment_advantage"] = adv
+        return dataset
+
+    def update_critic(self, dataset):
+        states = dataset["segment_state"]
+        old_values, returns = dataset["segment_value"], \
+            dataset["segment_reward"]
+        losses, norms, norms_c = [], [], []
+        for _ in range(self.epochs_critic):
+            for sel in self._minibatches(states.shape[0]):
+                s_in, v_old, ret = (states, old_values, returns) \
+                    if sel is None else (states[sel], old_values[sel],
+                                         returns[sel])
+                loss = self.value_loss(self.critic.critic(s_in).squeeze(-1),
+                                       ret, v_old)
+                self.critic_optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                g, gc = self._optimizer_step(self.critic_optimizer,
+                                             self.critic_net_params,
+                                             self.clip_grad_norm)
+                losses.append(loss.detach())
+                norms.append(g)
+                norms_c.append(gc)
+        host = torch.stack([torch.stack(losses), torch.stack(norms),
+                            torch.stack(norms_c)]).cpu().numpy()
+        return {**util.generate_stats(host[0], "critic_loss"),
+                **util.generate_stats(host[1], "critic_grad_norm"),
+                **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+
+    def update_policy(self, dataset):
+        states = dataset["segment_state"]
+        actions = dataset["segment_action"]
+        log_probs_old = dataset["segment_log_prob"]
+        mean_old, L_old = dataset["segment_params_mean"], \
+            dataset["segment_params_L"]
+        seg_adv = dataset["segment_advantage"]
+        if self.projection.initial_entropy is None:
+            ent0 = self.policy.entropy([mean_old, L_old]).mean()
+            self.projection.initial_entropy = self.dist.mean_scalar(ent0)
+        rows, nan_flags = [], []
+        mean_new = L_new = proj_mean = proj_L = None
+        for _ in range(self.epochs_policy):
+            mean_new, L_new = self.policy.policy(states)
+            proj_mean, proj_L = self.projection(
+                self.policy, (mean_new, L_new), (mean_old, L_old),
+                self.num_iterations)
+            log_prob_new = self.policy.log_prob(actions, params_mean=proj_mean,
+                                                params_L=proj_L)
+            surrogate_loss, _ = self.surrogate_loss(seg_adv, log_prob_new,
+                                                    log_probs_old)
+            entropy = self.policy.entropy([proj_mean, proj_L]).mean()
+            entropy_loss = -self.entropy_penalty_coef * entropy
+            trust_region_loss = self.projection.get_trust_region_loss(
+                self.policy, (mean_new, L_new), (proj_mean, proj_L),
+                set_variance=self.set_variance)
+            nan_flags.append(torch.isnan(torch.stack(
+                [surrogate_loss.detach(), entropy_loss.detach(),
+                 trust_region_loss.detach()])))
+            policy_loss = surrogate_loss + entropy_loss + trust_region_loss
+            self.policy_optimizer.zero_grad(set_to_none=True)
+            policy_loss.backward()
+            g, gc = self._optimizer_step(self.policy_optimizer,
+                                         self.policy_net_params,
+                                         self.clip_grad_norm)
+            rows.append(torch.stack([
+                surrogate_loss.detach(), entropy_loss.detach(),
+                trust_region_loss.detach(), policy_loss.detach(),
+                entropy.detach(), g, gc]))
+        self._check_nan(nan_flags)
+        host = torch.stack(rows).cpu().numpy()
+        names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
+                 "policy_loss", "entropy", "policy_grad_norm",
+                 "clipped_policy_grad_norm")
+        out = {}
+        for i, n in enumerate(names):
+            out.update(util.generate_stats(host[:, i], n))
+        metrics = self.projection.compute_metrics(
+            self.policy, (mean_new.detach(), ops.detach_L(L_new)),
+            (proj_mean.detach(), ops.detach_L(proj_L)), self.num_iterations)
+        mh = torch.stack([v.to(self.dtype) for v in metrics.values()]) \
+            .cpu().numpy()
+        out.update({"projection_" + k: float(v)
+                    for k, v in zip(metrics.keys(), mh)})
+        if self.set_variance and not self.policy.contextual_cov:
+            with torch.no_grad():
+                m, L = self.policy.policy(states)
+                _, pL = self.projection(self.policy, (m, L),
+                                        (mean_old, L_old),
+                                        self.num_iterations)
+                self.policy.set_cov_variable(pL)
+        return out
+
+
+def agent_factory(typ, **kwargs):
+    return {"TemporalCorrelatedAgent": TemporalCorrelatedAgent,
+            "BlackBoxAgent": BlackBoxAgent}[typ](**kwargs)

@@ -1,0 +1,209 @@
+"""Gaussian policies over movement-primitive parameters.
+
+Mirror of ``mprl/rl/policy/`` (abstract_policy.py:10-328,
+black_box_policy.py:5-224, temporal_correlated_policy.py:6-203): same
+constructor kwargs, method names, argument meaning and tensor shapes; the
+arithmetic runs in the HIP kernels of ``tce_rl_amd.ops``.
+"""
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import ops, util
+from ..mp import get_mp
+from ..nn import MLP, TrainableVariable
+
+
+def reverse_from_softplus_space(data, lower_bound):
+    lb = lower_bound if lower_bound is not None else 1e-2
+    return torch.log(torch.exp(data - lb) - 1)
+
+
+class AbstractGaussianPolicy(ABC):
+    def __init__(self, dim_in, dim_out, mean_net_args, variance_net_args,
+                 init_method, out_layer_gain, act_func_hidden, act_func_last,
+                 dtype="torch.float32", device="cpu", **kwargs):
+        self.dim_in, self.dim_out = dim_in, dim_out
+        variance_net_args = dict(variance_net_args)
+        self.contextual_cov = variance_net_args.pop("contextual")
+        self.std_only = variance_net_args.pop("std_only")
+        self.mean_net_args = mean_net_args
+        self.variance_net_args = variance_net_args
+        self.init_method, self.out_layer_gain = init_method, out_layer_gain
+        self.act_func_hidden, self.act_func_last = act_func_hidden, \
+            act_func_last
+        self.dtype, self.device = util.parse_dtype_device(dtype, device)
+        self.mean_net = None
+        self.variance_net = None
+        self._create_network()
+        self.num_dof = dim_out
+        self.min_std = float(kwargs.get("min_std", 1e-2))
+
+    @property
+    def _policy_net_type(self):
+        return self.__class__.__name__
+
+    def _create_network(self):
+        mk = lambda name, dim_out, args: MLP(
+            name=self._policy_net_type + name, dim_in=self.dim_in,
+            dim_out=dim_out,
+            hidden_layers=util.mlp_arch_3_params(**args),
+            init_method=self.init_method, out_layer_gain=self.out_layer_gain,
+            act_func_hidden=self.act_func_hidden,
+            act_func_last=self.act_func_last, dtype=self.dtype,
+            device=self.device)
+        self.mean_net = mk("_mean", self.dim_out, self.mean_net_args)
+        K = self.dim_out
+        dim_out_var = K if self.std_only else K + (K * (K - 1)) // 2
+        if self.contextual_cov:
+            self.variance_net = mk("_variance", dim_out_var,
+                                   self.variance_net_args)
+        else:
+            v = torch.zeros(dim_out_var, dtype=self.dtype)
+            v[:K] += reverse_from_softplus_space(
+                torch.ones(K, dtype=self.dtype), lower_bound=None)
+            self.variance_net = TrainableVariable(
+                self._policy_net_type + "_variance", v.to(self.device))
+
+    @property
+    def network(self):
+        return self.mean_net, self.variance_net
+
+    @property
+    def parameters(self):
+        return list(self.mean_net.parameters()) + \
+            list(self.variance_net.parameters())
+
+    def save_weights(self, log_dir, epoch):
+        self.mean_net.save(log_dir, epoch)
+        self.variance_net.save(log_dir, epoch)
+
+    def load_weights(self, log_dir, epoch):
+        self.mean_net.load(log_dir, epoch)
+        self.variance_net.load(log_dir, epoch)
+
+    def _vector_to_cholesky(self, cov_val):
+        return ops.chol_build(cov_val, self.dim_out, self.min_std)
+
+    def _cholesky_to_vector(self, params_L):
+        diag = torch.diagonal(params_L, dim1=-2, dim2=-1)
+        diag = reverse_from_softplus_space(diag, lower_bound=self.min_std)
+        if self.std_only:
+            return diag
+        K = params_L.shape[-1]
+        row, col = torch.tril_indices(K, K, -1, device=params_L.device)
+        return torch.cat([diag, params_L[..., row, col]], dim=-1)
+
+    @abstractmethod
+    def policy(self, *args, **kwargs):
+        pass
+
+    @abstractmethod
+    def sample(self, *args, **kwargs):
+        pass
+
+    @abstractmethod
+    def log_prob(self, *args, **kwargs):
+        pass
+
+    @property
+    def contextual_std(self):
+        return self.contextual_cov
+
+    @property
+    def contextual(self):
+        return True
+
+    @property
+    def is_diag(self):
+        return self.std_only
+
+    def set_cov_variable(self, param_L):
+        assert self.contextual_std is False, \
+            "Variance is a net instead of a variable."
+        self.variance_net.variable.data = \
+            self._cholesky_to_vector(ops.first_matrix(param_L)).detach()
+
+
+class BlackBoxPolicy(AbstractGaussianPolicy):
+    def policy(self, obs):
+        """obs [N, dim_obs] -> mean [N, K], L [N, K, K].  With a
+        non-contextual covariance L is a stride-0 view of ONE [K, K] matrix
+        (same values as the reference's materialised expansion)."""
+        params_mean = self.mean_net(obs)
+        if self.contextual_cov:
+            params_L = self._vector_to_cholesky(self.variance_net(obs))
+        else:
+            base = self._vector_to_cholesky(self.variance_net.variable[None])[0]
+            params_L = ops.expand_shared(base, obs.shape[0])
+        return params_mean, params_L
+
+    def sample(self, require_grad, params_mean, params_L, use_mean=False,
+               eps=None):
+        if not use_mean:
+            if eps is None:
+                eps = torch.randn_like(params_mean)
+            smp = ops.mvn_rsample(params_mean.detach(), ops.detach_L(params_L),
+                                  eps)
+        else:
+            smp = params_mean
+        return smp.detach()
+
+    def log_prob(self, smp_params, params_mean, params_L, **kwargs):
+        return ops.mvn_log_prob(smp_params, params_mean, params_L)
+
+    def entropy(self, params):
+        params_mean, params_L = params
+        ent = ops.mvn_entropy(params_L)
+        return ent if ent.dim() else ent.expand(params_mean.shape[0])
+
+    def covariance(self, params_L):
+        return torch.einsum('...ij,...kj->...ik', params_L, params_L)
+
+    def log_determinant(self, params_L):
+        return ops.log_determinant(params_L)
+
+    def precision(self, params_L):
+        eye = torch.eye(params_L.shape[-1], dtype=params_L.dtype,
+                        device=params_L.device)
+        return torch.cholesky_solve(eye, params_L, upper=False)
+
+    def maha(self, params, params_other, params_L):
+        return ops.maha(params, params_other, params_L)
+
+
+class TemporalCorrelatedPolicy(BlackBoxPolicy):
+    def __init__(self, dim_in, dim_out, mean_net_args, variance_net_args,
+                 init_method, out_layer_gain, act_func_hidden, act_func_last,
+                 dtype="torch.float32", device="cpu", **kwargs):
+        super().__init__(dim_in, dim_out, mean_net_args, variance_net_args,
+                         init_method, out_layer_gain, act_func_hidden,
+                         act_func_last, dtype, device, **kwargs)
+        self.mp = get_mp(**kwargs["mp"])
+        self.num_dof = self.mp.num_dof
+
+    def sample(self, require_grad, params_mean, params_L, times, init_time,
+               init_pos, init_vel, use_mean=False, eps=None):
+        """-> smp_traj [N, T, 2*dof] = cat[pos, vel].  ``eps`` [N, K]: the
+        standard-normal noise of the parameter sample (drawn on the device
+        when omitted)."""
+        if not use_mean:
+            if eps is None:
+                eps = torch.randn_like(params_mean)
+            w = ops.mvn_rsample(params_mean.detach(), ops.detach_L(params_L),
+                                eps)
+        else:
+            w = params_mean.detach()
+        return ops.prodmp_traj(self.mp, times, w, init_time, init_pos,
+                               init_vel)
+
+    def log_prob(self, smp_traj, params_mean, params_L, times, init_time,
+                 init_pos, init_vel, **kwargs):
+        return ops.pair_log_prob(self.mp, smp_traj, params_mean, params_L,
+                                 times, init_time, init_pos, init_vel,
+                                 kwargs["pred_pairs"])
+
+
+def policy_factory(typ, **kwargs):
+    return {"BlackBoxPolicy": BlackBoxPolicy,
+            "TemporalCorrelatedPolicy": TemporalCorrelatedPolicy}[typ](**kwargs)

@@ -1,0 +1,313 @@
+"""Rollout samplers: mirror of mprl/rl/sampler/ (abstract_sampler.py:6-43,
+black_box_sampler.py:14-249, temporal_correlated_sampler.py:17-356).
+
+Same constructor kwargs and ``run`` contract: ``run(training, policy, critic,
+deterministic=False, render=False, task_specified_metrics=None) ->
+(dataset dict, num_env_steps)``.  The whole rollout buffer stays on the device:
+no host copies between the policy, the (synthetic) env, the critic and the
+dataset (the reference crosses host <-> device and a process boundary at
+temporal_correlated_sampler.py:229-240).
+"""
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import ops, util
+from ..envs import make_env
+from ..util import assert_shape, select_pred_pairs
+
+
+class RunningMeanStd:
+    """util_numerical.py:278-350 on the device (HIP reduction kernel)."""
+
+    def __init__(self, name="", epsilon=1e-4, shape=(), dtype="torch.float32",
+                 device="cpu"):
+        self.name = "running_mean_std" if name == "" else name
+        self.shape = shape
+        self.dtype, self.device = util.parse_dtype_device(dtype, device)
+        self.mean = torch.zeros(shape, dtype=self.dtype, device=self.device)
+        self.var = torch.ones(shape, dtype=self.dtype, device=self.device)
+        self.count = epsilon
+
+    def update(self, arr, group=None):
+        if group is not None:
+            raise NotImplementedError("use update() per rank + merge_ranks()")
+        self.count = ops.rms_update(arr, self.mean, self.var, self.count)
+
+    def save(self, log_dir, epoch):
+        path = util.get_training_state_save_path(log_dir, self.name, epoch)
+        with open(path, "wb") as f:
+            torch.save({"mean": self.mean, "var": self.var,
+                        "count": self.count}, f)
+
+    def load(self, log_dir, epoch):
+        path = util.get_training_state_save_path(log_dir, self.name, epoch)
+        d = torch.load(path, map_location=self.device)
+        self.mean, self.var, self.count = d["mean"], d["var"], d["count"]
+
+
+class AbstractSampler(ABC):
+    def __init__(self):
+        self.train_envs = None
+        self.test_envs = None
+        self.debug_env = None
+
+    @abstractmethod
+    def run(self, *args, **kwargs):
+        pass
+
+    @property
+    def observation_space(self):
+        return self.debug_env.observation_space
+
+    @property
+    def observation_shape(self):
+        return self.debug_env.observation_space.shape
+
+    @property
+    def action_space(self):
+        return self.debug_env.action_space
+
+    @property
+    def spec(self):
+        return self.debug_env.spec
+
+
+class BlackBoxSampler(AbstractSampler):
+    black_box_env = True
+
+    def __init__(self, env_id, num_env_train=1, num_env_test=1,
+                 episodes_per_train_env=1, episodes_per_test_env=1,
+                 dtype="torch.float32", device="cpu", seed=1, **kwargs):
+        super().__init__()
+        self.env_id = env_id
+        self.num_env_train, self.num_env_test = num_env_train, num_env_test
+        self.episodes_per_train_env = episodes_per_train_env
+        self.episodes_per_test_env = episodes_per_test_env
+        self.mp_args = kwargs["mp"]["args"] if kwargs.get("mp") is not None \
+            else dict()
+        self.dtype, self.device = util.parse_dtype_device(dtype, device)
+        self.seed = seed
+        self.cpu_cores = kwargs.get("cpu_cores", None)
+        self.task_specified_metrics = kwargs.get("task_specified_metrics", None)
+        self.render_test_env = kwargs.get("render_test_env", False)
+        self.env_args = kwargs.get("env_args", {}) or {}
+        self.train_envs = self.get_env("training")
+        self.test_envs = self.get_env("testing")
+        self.debug_env = self.get_env("debugging")
+
+    def get_env(self, env_type="training"):
+        if env_type == "training":
+            num_env, seed = self.num_env_train, self.seed
+        elif env_type == "testing":
+            num_env, seed = self.num_env_test, self.seed + 10000
+        elif env_type == "debugging":
+            num_env, seed = 1, self.seed + 20000
+        else:
+            raise ValueError("Unknown env_type: {}".format(env_type))
+        return make_env(self.env_id, num_env, seed, mp_args=self.mp_args,
+                        black_box=self.black_box_env, dtype=self.dtype,
+                        device=self.device, **self.env_args)
+
+    @torch.no_grad()
+    def run(self, training, policy, critic, deterministic=False, render=False,
+            task_specified_metrics=None):
+        if training:
+            assert deterministic is False
+            envs, num_env = self.train_envs, self.num_env_train
+            ep_per_env = self.episodes_per_train_env
+        else:
+            envs, num_env = self.test_envs, self.num_env_test
+            ep_per_env = self.episodes_per_test_env
+        state = envs.reset()
+        dim_mp_params = policy.dim_out
+        out = {k: [] for k in ("segment_state", "segment_action",
+                               "segment_reward", "segment_value",
+                               "segment_done", "segment_log_prob",
+                               "segment_params_mean", "segment_params_L")}
+        metrics = {m: [] for m in (self.task_specified_metrics or [])}
+        num_steps = 0
+        for _ in range(ep_per_env):
+            mean, L = policy.policy(state)
+            assert_shape(mean, [num_env, dim_mp_params])
+            action = policy.sample(require_grad=False, params_mean=mean,
+                                   params_L=L, use_mean=deterministic)
+            log_prob = policy.log_prob(action, params_mean=mean, params_L=L)
+            values = critic.critic(state).squeeze(-1)
+            out["segment_state"].append(state)
+            out["segment_action"].append(action)
+            out["segment_log_prob"].append(log_prob)
+            out["segment_value"].append(values)
+            out["segment_params_mean"].append(mean)
+            out["segment_params_L"].append(L)
+            state, reward, done, info = envs.step(action)
+            out["segment_reward"].append(reward.to(self.dtype))
+            out["segment_done"].append(done)
+            num_steps += info["trajectory_length"].sum()
+            for m in metrics:
+                metrics[m].append(info[m].to(self.dtype))
+        res = {}
+        for k, v in out.items():
+            res[k] = _cat_L(v) if k == "segment_params_L" else torch.cat(v, 0)
+        res["episode_reward"] = res["segment_reward"]
+        for m, v in metrics.items():
+            res[m] = torch.cat(v, 0)
+        return res, int(num_steps)
+
+
+def _cat_L(Ls):
+    """Concatenate Cholesky factors over episodes, keeping the shared
+    (stride-0) representation when every episode used the same matrix."""
+    if len(Ls) == 1:
+        return Ls[0]
+    bases = [getattr(L, "_tce_base", None) for L in Ls]
+    if all(b is not None for b in bases) and \
+            all(b is bases[0] or torch.equal(b, bases[0]) for b in bases):
+        return ops.expand_shared(bases[0], sum(L.shape[0] for L in Ls))
+    return torch.cat([ops.full_L(L, L.shape[0]) for L in Ls], 0)
+
+
+class TemporalCorrelatedSampler(BlackBoxSampler):
+    black_box_env = False
+
+    def __init__(self, env_id, num_env_train=1, num_env_test=1,
+                 episodes_per_train_env=1, episodes_per_test_env=1,
+                 dtype="torch.float32", device="cpu", seed=1, **kwargs):
+        super().__init__(env_id, num_env_train, num_env_test,
+                         episodes_per_train_env, episodes_per_test_env, dtype,
+                         device, seed, **kwargs)
+        self.dt = self.debug_env.envs[0].dt
+        self.num_times = self.debug_env.envs[0].spec.max_episode_steps
+        self.norm_step_obs = kwargs.get("norm_step_obs", False)
+        self.obs_rms = RunningMeanStd(
+            name="obs_rms", shape=self.observation_space.shape, dtype=dtype,
+            device=device) if self.norm_step_obs else None
+        self.norm_step_rewards = kwargs.get("norm_step_rewards", False)
+        self.rwd_rms = RunningMeanStd(name="rwd_rms", shape=(1,), dtype=dtype,
+                                      device=device) \
+            if self.norm_step_rewards else None
+        self.time_pairs_config = kwargs["time_pairs_config"]
+        self.pred_pairs = None
+
+    def get_times(self, init_time, num_times):
+        return ops.times(init_time, self.dt, num_times)
+
+    def get_time_pairs(self):
+        """Host draw (global torch CPU generator, bit-identical to the
+        reference), float32 -> int64, then one small upload."""
+        pairs = select_pred_pairs(num_all=self.num_times,
+                                  **self.time_pairs_config)
+        self.pred_pairs = pairs.to(torch.long).to(self.device)
+        return self.pred_pairs
+
+    @staticmethod
+    def apply_normalization(raw, rms):
+        return ops.rms_normalize(raw, rms.mean, rms.var, 1e-8)
+
+    @torch.no_grad()
+    def run(self, training, policy, critic, deterministic=False, render=False,
+            task_specified_metrics=None):
+        if training:
+            assert deterministic is False and render is False
+            envs, num_env = self.train_envs, self.num_env_train
+            ep_per_env = self.episodes_per_train_env
+        else:
+            envs, num_env = self.test_envs, self.num_env_test
+            ep_per_env = self.episodes_per_test_env
+        init_state = envs.reset()
+        dim_obs = self.observation_space.shape[-1]
+        num_times, num_dof = self.num_times, policy.num_dof
+        pred_pairs = self.get_time_pairs()
+        keys = ("step_actions", "segment_log_prob_estimate", "step_states",
+                "step_rewards", "segment_state", "episode_reward",
+                "step_dones", "step_values", "segment_init_time",
+                "segment_init_pos", "segment_init_vel", "segment_params_mean",
+                "segment_params_L")
+        out = {k: [] for k in keys}
+        metrics = {m: [] for m in (self.task_specified_metrics or [])}
+        num_steps = 0
+        for _ in range(ep_per_env):
+            init_time = init_state[..., -num_dof * 2 - 1]
+            init_pos = init_state[..., -num_dof * 2: -num_dof]
+            init_vel = init_state[..., -num_dof:]
+            mean, L = policy.policy(init_state[..., :-num_dof * 2])
+            step_times = self.get_times(init_time, num_times)
+            actions = policy.sample(require_grad=False, params_mean=mean,
+                                    params_L=L, times=step_times,
+                                    init_time=init_time, init_pos=init_pos,
+                                    init_vel=init_vel, use_mean=deterministic)
+            log_prob = policy.log_prob(actions, params_mean=mean, params_L=L,
+                                       times=step_times, init_time=init_time,
+                                       init_pos=init_pos, init_vel=init_vel,
+                                       pred_pairs=pred_pairs)
+            assert_shape(actions, [num_env, num_times, num_dof * 2])
+            next_state, ep_reward, _, infos = envs.step(actions)
+            step_states = torch.cat([init_state[:, None],
+                                     infos["step_states"]], dim=-2)
+            # only updated AND applied during training: evaluation feeds the
+            # critic raw states (temporal_correlated_sampler.py:244-249)
+            if self.norm_step_obs and training:
+                self.obs_rms.update(step_states.view(-1, dim_obs))
+                norm_states = self.apply_normalization(step_states,
+                                                       self.obs_rms)
+            else:
+                norm_states = step_states
+            values = critic.critic(
+                norm_states[..., :-num_dof * 2]).squeeze(-1)
+            rewards = infos["step_rewards"].to(self.dtype)
+            if "TableTennis" in self.env_id:
+                rewards = ops.mdp_reward(rewards, infos["hit_ball"])
+            elif "HopperJump" in self.env_id:
+                rewards = ops.mdp_reward(rewards, infos["has_left_floor"])
+            dones = torch.logical_or(infos["step_terminations"],
+                                     infos["step_truncations"])
+            out["step_actions"].append(actions)
+            out["segment_log_prob_estimate"].append(log_prob)
+            out["step_states"].append(norm_states)
+            out["step_values"].append(values)
+            out["segment_state"].append(init_state)
+            out["step_rewards"].append(rewards)
+            out["episode_reward"].append(ep_reward.to(self.dtype))
+            out["step_dones"].append(dones)
+            out["segment_init_time"].append(init_time)
+            out["segment_init_pos"].append(init_pos)
+            out["segment_init_vel"].append(init_vel)
+            out["segment_params_mean"].append(mean)
+            out["segment_params_L"].append(L)
+            num_steps = num_steps + infos["segment_length"].sum()
+            for m in metrics:
+                metrics[m].append(infos[m].to(self.dtype))
+            init_state = next_state
+        res = {}
+        for k, v in out.items():
+            if k == "segment_params_L":
+                res[k] = _cat_L(v)
+            else:
+                res[k] = v[0] if len(v) == 1 else torch.cat(v, dim=0)
+        # the reference stores the normalised states incl. the initial one and
+        # drops the last (temporal_correlated_sampler.py:322); kept as a view
+        res["step_states_full"] = res["step_states"]
+        res["step_states"] = res["step_states"][:, :-1]
+        res["segment_reward"] = res["step_rewards"].sum(dim=-1)
+        res["step_time_limit_dones"] = torch.zeros_like(res["step_dones"])
+        for m, v in metrics.items():
+            res[m] = torch.cat(v, dim=0)
+        return res, int(num_steps)
+
+    def save_rms(self, log_dir, epoch):
+        if self.norm_step_obs:
+            self.obs_rms.save(log_dir, epoch)
+        if self.norm_step_rewards:
+            self.rwd_rms.save(log_dir, epoch)
+
+    def load_rms(self, log_dir, epoch):
+        if self.norm_step_obs:
+            self.obs_rms.load(log_dir, epoch)
+        if self.norm_step_rewards:
+            self.rwd_rms.load(log_dir, epoch)
+
+
+def sampler_factory(typ, **kwargs):
+    return {"BlackBoxSampler": BlackBoxSampler,
+            "TemporalCorrelatedSampler": TemporalCorrelatedSampler}[typ](
+        **kwargs)
