@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the TCE rollout + update hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full ``TemporalCorrelatedAgent.step()`` without evaluation
+(rollout on the synthetic env, obs RMS, critic forward, GAE + segment
+advantage, 50 critic epochs, 50 trust-region-projected policy epochs) on the
+BASELINE.json config 2 shape: 4096 envs per GPU, T = 500, P = 24, dof 4,
+ProDMP with 5 basis functions (K = 24), fp32 (the reference accepts only
+fp32/fp64).  N > 1: one process per GPU (torch.distributed.run), envs sharded
+4096 per rank (weak scaling), one flat RCCL all-reduce of the gradients per
+optimizer step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+NUM_ENV, NUM_BASIS, EPOCHS = 4096, 5, 50
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_agent(num_env, seed):
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    cfg = tce_config("metaworld", num_env=num_env, num_basis=NUM_BASIS,
+                     epochs=EPOCHS, dtype="float32", device="cuda", seed=seed,
+                     evaluation_interval=0)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    return exp.agent, cfg
+
+
+def kernel_time_us(fn, launches=20):
+    """Average device time of `fn`'s kernel(s) with HIP events on the stream
+    they are launched on.  The launches are queued behind a busy-wait kernel so
+    that they run back to back (a Python launch loop on an idle GPU would time
+    the host, not the kernel)."""
+    fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(3):
+        torch.cuda._sleep(4_000_000)
+        e0.record()
+        for _ in range(launches):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / launches)
+    return best
+
+
+def roofline(agent):
+    """HBM roofline of the GAE scan (dominant HBM-bound kernel of the path):
+    algorithmic bytes = 18 B per (env, step) + 4 B per env."""
+    from tce_rl_amd import ops
+    N, T = NUM_ENV, agent.sampler.num_times
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = torch.randn(N, T, device="cuda", generator=g)
+    v = torch.randn(N, T + 1, device="cuda", generator=g)
+    d = torch.zeros(N, T, dtype=torch.bool, device="cuda")
+    d[:, -1] = True
+    tl = torch.zeros_like(d)
+    us = kernel_time_us(lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True))
+    alg = N * T * 18 + N * 4
+    gae = {"kernel": "gae_dpp_kernel<float,true,true,8>", "bound": "hbm",
+           "achieved": round(alg / us / 1e3, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
+           "traffic": None, "us_per_launch": round(us, 2),
+           "algorithmic_bytes": alg}
+    # trajectory generator (write-bound): T*2*dof*4 B written per env
+    mp = agent.policy.mp
+    K = mp.num_dof * mp.num_basis_g
+    t0 = torch.zeros(N, device="cuda")
+    times = ops.times(t0, mp.dt, T)
+    w = 0.1 * torch.randn(N, K, device="cuda", generator=g)
+    y0 = torch.rand(N, mp.num_dof, device="cuda", generator=g)
+    v0 = torch.zeros(N, mp.num_dof, device="cuda")
+    us2 = kernel_time_us(lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0))
+    alg2 = N * (T * 2 * mp.num_dof * 4 + 4 * (K + 2 * mp.num_dof + 1))
+    extra = {"prodmp_traj": {
+        "bound": "hbm", "achieved": round(alg2 / us2 / 1e3, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
+        "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
+        "note": "basis-table kernel + trajectory kernel"}}
+    return gae, extra
+
+
+def cpu_baseline():
+    """The CPU oracle (torch-CPU restatement of the reference path, kind
+    'port') on a bounded sample: 256 envs, full 50 + 50 epochs."""
+    from tce_rl_amd.config import tce_config
+    from oracle.agent_oracle import OracleTCE      # checker / baseline only
+    n = 256
+    # host cores this process may use (the GPU box gives 16 per GPU); torch
+    # with more threads than cores thrashes on the small ops
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
+    torch.set_num_threads(threads)
+    print("[bench] cpu_baseline: %d threads (%d visible cores)" %
+          (threads, avail), file=sys.stderr, flush=True)
+    cfg = tce_config("metaworld", num_env=n, num_basis=NUM_BASIS,
+                     epochs=EPOCHS, device="cpu")
+    o = OracleTCE(cfg["params"], n)
+    t = time.perf_counter()
+    steps = o.step()
+    dt = time.perf_counter() - t
+    return {"value": round(steps / dt, 1), "unit": "env-steps/s",
+            "cores": threads, "kind": "port",
+            "sample": "1 agent.step() of the torch-CPU oracle at %d envs "
+                      "(T 500, 50 critic + 50 policy epochs), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda",
+                                                               local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run for N > 1"
+
+    agent, cfg = build_agent(NUM_ENV, seed=rank)
+    T = agent.sampler.num_times
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.step()
+    barrier()
+    if rank == 0:
+        print("[bench] warmup done", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    pol_time = 0.0
+    for _ in range(args.steps):
+        res = agent.step()
+        pol_time += res["update_policy_time"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed, pol_time], device="cuda",
+                          dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, pol_time = tt.tolist()
+
+    if rank == 0:
+        env_steps = world * NUM_ENV * T * args.steps
+        print("[bench] timed region: %.3f s" % elapsed, file=sys.stderr,
+              flush=True)
+        roof, extra = roofline(agent)
+        print("[bench] roofline done", file=sys.stderr, flush=True)
+        out = {
+            "metric": "env-steps/sec (TCE rollout + update, Metaworld-reach-"
+                      "like, 4096 envs/GPU)",
+            "value": round(env_steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "policy_updates_per_sec": round(EPOCHS * args.steps / pol_time, 2),
+            "iterations_per_sec": round(args.steps / elapsed, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: TCE, Metaworld-"
+                       "reach-like synthetic env, 4096 envs per GPU, T 500, "
+                       "P 24, dof 4, ProDMP 5 basis (K 24), 50 critic + 50 "
+                       "policy epochs, KL projection, fp32",
+                       "num_env_per_gpu": NUM_ENV, "num_times": T,
+                       "num_basis": NUM_BASIS, "epochs": EPOCHS,
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": roof, "roofline_extra": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,7 +83,9 @@ def entropy_schedule(kind, initial_entropy, target_entropy, temperature, step,
 def mean_projection(mean, mean_o, maha, eps):
     mask = maha > eps
     omega = torch.ones_like(maha)
-    omega = torch.where(mask, torch.sqrt(maha / eps) - 1.0, omega)
+    # masked assignment (not torch.where): sqrt'(0) = inf must not reach the
+    # rows that are not projected
+    omega[mask] = torch.sqrt(maha[mask] / eps) - 1.0
     omega = torch.max(-omega, omega)[..., None]
     m = (mean + omega * mean_o) / (1 + omega + 1e-16)
     return torch.where(mask[..., None], m, mean)
