@@ -159,9 +159,13 @@ int tce_pair_logprob_bwd_f64(
     const double* init_vel, double reg, const double* grad_logp, double* grad_mean,
     double* grad_L, double* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,
     void* stream);
-/* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs */
-int tce_sum_dim0_f32(const float* x, float* out, int64_t N, int64_t M, void* stream);
-int tce_sum_dim0_f64(const double* x, double* out, int64_t N, int64_t M, void* stream);
+/* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
+ * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
+int64_t tce_sum_dim0_slices(int64_t N, int64_t M);
+int tce_sum_dim0_f32(const float* x, float* out, float* ws, int64_t N, int64_t M,
+                     void* stream);
+int tce_sum_dim0_f64(const double* x, double* out, double* ws, int64_t N, int64_t M,
+                     void* stream);
 
 /* ---- Gaussian policy head / param-space Gaussian / KL trust region -------
  * chol_build: AbstractGaussianPolicy._vector_to_cholesky

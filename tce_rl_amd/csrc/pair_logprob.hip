@@ -250,21 +250,25 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
   }
 }
 
-// out[j] = sum_n x[n, j]   (x [N, M] row-major): one block per 256 columns
+// out[j] = sum_n x[n, j]   (x [N, M] row-major).  Two stages so that the whole
+// chip streams the N*M elements: stage 1 (grid = column tiles x row slices)
+// writes partial sums, stage 2 adds the slices.
 template <typename real>
 __global__ __launch_bounds__(256) void sum_dim0_kernel(const real* __restrict__ x,
                                                        real* __restrict__ out,
-                                                       int64_t N, int64_t M) {
+                                                       int64_t N, int64_t M, int64_t rows_per) {
   __shared__ real part[4][64];
-  // 64 columns per block, 4 row-groups
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = tmin<int64_t>(N, r0 + rows_per);
   real acc = 0;
   if (col < M)
-    for (int64_t r = g; r < N; r += 4) acc += x[r * M + col];
+    for (int64_t r = r0 + g; r < r1; r += 4) acc += x[r * M + col];
   part[g][c] = acc;
   __syncthreads();
-  if (g == 0 && col < M) out[col] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+  if (g == 0 && col < M)
+    out[(int64_t)blockIdx.y * M + col] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
 template <typename real>
@@ -308,6 +312,13 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
 
 extern "C" {
 
+int64_t tce_sum_dim0_slices(int64_t N, int64_t M) {
+  const int64_t col_blocks = ceil_div(M, 64);
+  int64_t s = ceil_div(2048, col_blocks);
+  s = tmin<int64_t>(s, ceil_div(N, 16));
+  return tmax<int64_t>(s, 1);
+}
+
 #define DEFINE_PL(SFX, REAL)                                                     \
   int tce_pair_logprob_fwd_##SFX(                                                \
       const REAL* traj, const REAL* mean, const REAL* L, int64_t L_stride,       \
@@ -337,12 +348,25 @@ extern "C" {
                            nullptr, grad_logp, grad_mean, grad_L, basis_ws,      \
                            flag_ws, N, T, P, dof, (hipStream_t)stream);          \
   }                                                                              \
-  int tce_sum_dim0_##SFX(const REAL* x, REAL* out, int64_t N, int64_t M,         \
-                         void* stream) {                                         \
+  /* ws: REAL [tce_sum_dim0_slices(N, M), M] workspace (may be NULL when the  \
+     slice count is 1) */                                                        \
+  int tce_sum_dim0_##SFX(const REAL* x, REAL* out, REAL* ws, int64_t N,          \
+                         int64_t M, void* stream) {                              \
     TCE_CHECK_ARG(x && out && N > 0 && M > 0, "sum_dim0: bad arguments");        \
-    hipLaunchKernelGGL(sum_dim0_kernel<REAL>, dim3((unsigned)ceil_div(M, 64)),   \
-                       dim3(256), 0, (hipStream_t)stream, x, out, N, M);         \
+    const int64_t slices = tce_sum_dim0_slices(N, M);                            \
+    TCE_CHECK_ARG(slices == 1 || ws, "sum_dim0: workspace missing");             \
+    const int64_t rows_per = ceil_div(N, slices);                                \
+    dim3 grid((unsigned)ceil_div(M, 64), (unsigned)slices);                      \
+    hipLaunchKernelGGL(sum_dim0_kernel<REAL>, grid, dim3(256), 0,                \
+                       (hipStream_t)stream, x, slices == 1 ? out : ws, N, M,     \
+                       rows_per);                                                \
     TCE_LAUNCH_CHECK();                                                          \
+    if (slices > 1) {                                                            \
+      hipLaunchKernelGGL(sum_dim0_kernel<REAL>, dim3((unsigned)ceil_div(M, 64)), \
+                         dim3(256), 0, (hipStream_t)stream, ws, out, slices, M,  \
+                         slices);                                                \
+      TCE_LAUNCH_CHECK();                                                        \
+    }                                                                            \
     return 0;                                                                    \
   }
 

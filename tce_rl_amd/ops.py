@@ -169,6 +169,20 @@ def split_L(L):
     return L, L.shape[-1] * L.shape[-2]
 
 
+def sum_dim0(x):
+    """[N, M] -> [M] column sums (two-stage, whole-chip)."""
+    check_dev(x)
+    x = _c(x)
+    N, M = x.shape
+    out = torch.empty(M, dtype=x.dtype, device=x.device)
+    slices = _lib.load().tce_sum_dim0_slices(N, M)
+    ws = torch.empty(slices, M, dtype=x.dtype, device=x.device) \
+        if slices > 1 else None
+    call("tce_sum_dim0_" + sfx(x.dtype), ptr(x), ptr(out), ptr(ws), N, M,
+         stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # time grid, parameter sampling, ProDMP trajectories
 # ---------------------------------------------------------------------------
@@ -257,10 +271,7 @@ class _PairLogProb(torch.autograd.Function):
              ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(g), ptr(gmean),
              ptr(gL), ptr(B), ptr(flag), N, T, P, mp.num_dof, stream())
         if sL == 0:
-            gLs = torch.empty(K, K, dtype=mean.dtype, device=mean.device)
-            call("tce_sum_dim0_" + sfx(mean.dtype), ptr(gL), ptr(gLs), N,
-                 K * K, stream())
-            gL = gLs
+            gL = sum_dim0(gL.reshape(N, K * K)).reshape(K, K)
         return (gmean, gL) + (None,) * 9
 
 
@@ -404,10 +415,7 @@ class _MvnLogProb(torch.autograd.Function):
         gmean, gL = _vec_env(2, True, x, mean, Lc, ctx.sL, 0.0, g,
                              want_gL=need_L)
         if need_L and ctx.sL == 0:
-            gLs = torch.empty(K, K, dtype=x.dtype, device=x.device)
-            call("tce_sum_dim0_" + sfx(x.dtype), ptr(gL), ptr(gLs), N, K * K,
-                 stream())
-            gL = gLs
+            gL = sum_dim0(gL.reshape(N, K * K)).reshape(K, K)
         return None, gmean, gL, None
 
 
