@@ -249,6 +249,29 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- fused critic MLP epoch (exact-fp32 MFMA) ----------------------------
+ * Forward (+ value loss + backward when `partials` != NULL) of the value
+ * network D_in -> 128 -> 128 -> 1 (ValueFunction.critic ->
+ * mprl/util/util_nn.py:225-246; value_loss + backward of one critic epoch,
+ * mprl/rl/agent/temporal_correlated_agent.py:343-366,688-716) over R rows.
+ * Row r = (n, t) lives at x + n*env_stride + t*row_stride (t < T, the first
+ * D_in <= 48 features are used), so the critic reads the rollout buffer in
+ * place.  Weights in torch.nn.Linear layout [out][in].  act: 0 tanh, 1 relu,
+ * 2 leaky_relu(0.01), 3 softplus.  clip > 0: PPO-style clipped value loss with
+ * old_values.  values (nullable) [R]; partials float
+ * [tce_mlp_critic_grid(), num_params + 2]; grad float [num_params] in the order
+ * W1, b1, W2, b2, w3, b3; stats float[2] = {mean loss, |grad|^2}.
+ */
+int tce_mlp_critic_hidden(void);
+int tce_mlp_critic_grid(void);
+int64_t tce_mlp_critic_num_params(int din);
+int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                       int64_t R, int din, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3,
+                       int act, const float* returns, const float* old_values, float clip,
+                       float* values, float* partials, float* grad, float* stats,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""Fused critic epochs on the exact-fp32 matrix cores (csrc/mlp.hip).
+
+``supported(mlp)``: the value network D_in -> 128 -> 128 -> 1 in float32 (the
+Metaworld config); anything else stays on the library-GEMM path (mlp_ops).
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_ACT = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
+
+
+def supported(mlp):
+    return (mlp.dtype == torch.float32 and mlp.dim_out == 1
+            and list(mlp.hidden_layers) == [128, 128]
+            and 1 <= mlp.dim_in <= 48 and mlp.act_func_last_type is None
+            and mlp.act_func_hidden_type in _ACT)
+
+
+def _rows(x):
+    """(tensor, env_stride, row_stride, T, R) describing x [..., din] in place
+    when its rows are (env, step)-strided; a copy otherwise."""
+    din = x.shape[-1]
+    if x.dim() == 3 and x.stride(2) == 1:
+        N, T, _ = x.shape
+        return x, x.stride(0), x.stride(1), T, N * T
+    x2 = x.reshape(-1, din)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    return x2, 0, x2.stride(0), x2.shape[0], x2.shape[0]
+
+
+def _weights(mlp):
+    ls = mlp.layers
+    return [ptr(t) for t in (ls[0].weight, ls[0].bias, ls[1].weight,
+                             ls[1].bias, ls[2].weight, ls[2].bias)]
+
+
+def forward(mlp, x):
+    """values [..., 1] without autograd (rollout / evaluation)."""
+    xs, es, rs, T, R = _rows(x)
+    out = torch.empty(R, dtype=torch.float32, device=x.device)
+    call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, mlp.dim_in,
+         *_weights(mlp), _ACT[mlp.act_func_hidden_type], None, None, 0.0,
+         ptr(out), None, None, None, stream())
+    return out.reshape(*x.shape[:-1], 1)
+
+
+class EpochRunner:
+    """Holds the flat gradient buffer (p.grad are views of it) and the
+    per-workgroup partial slabs for repeated critic epochs."""
+
+    def __init__(self, mlp):
+        assert supported(mlp)
+        self.mlp = mlp
+        lib = _lib.load()
+        self.P = lib.tce_mlp_critic_num_params(mlp.dim_in)
+        dev = mlp.layers[0].weight.device
+        self.flat = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(lib.tce_mlp_critic_grid(), self.P + 2,
+                                    dtype=torch.float32, device=dev)
+        off = 0
+        self.params = list(mlp.parameters())
+        self.views = []
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        assert off == self.P
+
+    def epoch(self, states, returns, old_values, clip):
+        """One full-batch forward + loss + backward; leaves the gradient in
+        p.grad (views of the flat buffer) and returns stats = {mean loss,
+        |grad|^2} as a device tensor [2]."""
+        xs, es, rs, T, R = _rows(states)
+        ret = returns.reshape(-1)
+        ret = ret if ret.is_contiguous() else ret.contiguous()
+        old = None
+        if clip > 0:
+            old = old_values.reshape(-1).contiguous()
+        stats = torch.empty(2, dtype=torch.float32, device=self.flat.device)
+        call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, self.mlp.dim_in,
+             *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
+             ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
+             ptr(self.flat), ptr(stats), stream())
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return stats

@@ -42,6 +42,13 @@ class DistContext:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
+    def allreduce_flat(self, flat):
+        """In-place mean over ranks of an already-flat gradient buffer."""
+        if self.world == 1:
+            return
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+
     def mean_scalar(self, x):
         if self.world == 1:
             return x

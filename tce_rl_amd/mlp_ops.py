@@ -15,6 +15,10 @@ _ACT = {"tanh": torch.tanh, "relu": F.relu, "leaky_relu": F.leaky_relu,
 def forward(mlp, x):
     if not x.is_cuda:
         raise RuntimeError("tce_rl_amd MLPs run on a HIP device only")
+    from . import critic_ops
+    if not torch.is_grad_enabled() and critic_ops.supported(mlp) \
+            and x.numel() >= 4096 * mlp.dim_in:
+        return critic_ops.forward(mlp, x)         # fused MFMA forward
     layers = mlp.layers
     act = _ACT[mlp.act_func_hidden_type]
     for i in range(len(mlp.hidden_layers)):

@@ -262,6 +262,12 @@ class TemporalCorrelatedAgent(AbstractAgent):
         N, T = states.shape[:2]
         old_values = dataset["step_values"][:, :-1]
         returns = dataset["step_returns"]
+        from .. import critic_ops
+        fused = critic_ops.supported(self.critic.net) and \
+            self.num_minibatchs == 1
+        if fused:
+            return self._update_critic_fused(states[..., :-D2], returns,
+                                             old_values)
         losses, norms, norms_c = [], [], []
         for _ in range(self.epochs_critic):
             for sel in self._minibatches(N * T):
@@ -287,6 +293,35 @@ class TemporalCorrelatedAgent(AbstractAgent):
         return {**util.generate_stats(host[0], "critic_loss"),
                 **util.generate_stats(host[1], "critic_grad_norm"),
                 **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+
+    def _update_critic_fused(self, x, returns, old_values):
+        """Full-batch critic epochs on the fused fp32-MFMA kernel: one launch
+        does forward + value loss + backward for all N*T rows (read in place
+        from the rollout buffer), a second reduces the per-workgroup gradient
+        slabs; Adam consumes the flat gradient."""
+        from .. import critic_ops
+        run = getattr(self, "_critic_runner", None)
+        if run is None or run.mlp is not self.critic.net:
+            run = self._critic_runner = critic_ops.EpochRunner(self.critic.net)
+        rows = []
+        for _ in range(self.epochs_critic):
+            stats = run.epoch(x, returns, old_values, self.clip_critic)
+            if self.dist.world > 1:
+                self.dist.allreduce_flat(run.flat)
+                g = run.flat.norm(2)
+            else:
+                g = stats[1].sqrt()
+            gc = g
+            if self.clip_grad_norm > 0:
+                coef = torch.clamp(self.clip_grad_norm / (g + 1e-6), max=1.0)
+                run.flat.mul_(coef)
+                gc = g * coef
+            self.critic_optimizer.step()
+            rows.append(torch.stack([stats[0], g, gc]))
+        host = torch.stack(rows).cpu().numpy()
+        return {**util.generate_stats(host[:, 0], "critic_loss"),
+                **util.generate_stats(host[:, 1], "critic_grad_norm"),
+                **util.generate_stats(host[:, 2], "clipped_critic_grad_norm")}
 
     def _minibatches(self, n):
         """generate_minibatches (util_data_structure.py:378-391).  With ONE
