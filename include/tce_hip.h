@@ -126,39 +126,44 @@ int tce_prodmp_traj_f64(const double* tab, int M, int nbg, double tau, double de
  * 2*dof positions at the two times of every pair under N(H theta + c,
  * H L L^T H^T + reg I).  traj [N,T,2*dof], mean [N,K], L [.,K,K] with
  * L_stride (0 = shared), pairs int64 [P,2].  bwd: grad_mean [N,K] and
- * grad_L [N,K,K] (per env, lower triangle) for grad_logp [N,P]; the forward
- * is recomputed, nothing is saved between the two calls.
+ * grad_L ([N,K,K] per env, or [K,K] when L_stride == 0; lower triangle) for
+ * grad_logp [N,P]; the forward is recomputed, nothing is saved between the two
+ * calls.  work: scratch of tce_pair_logprob_work_len(...) elements (NULL when
+ * that is 0, i.e. for a per-env L).  With a shared L and a common init time
+ * the env-independent factorisations are done once per pair.
  */
+int64_t tce_pair_logprob_work_len(int64_t N, int P, int dof, int nbg, int64_t L_stride,
+                                  int bwd);
 int tce_pair_logprob_fwd_f32(
     const float* traj, const float* mean, const float* L, int64_t L_stride,
     const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
     float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
     int times_general, const float* init_time, const float* init_pos,
     const float* init_vel, float reg, float* logp, float* basis_ws, int* flag_ws,
-    int64_t N, int T, int P, int dof, void* stream);
+    float* work, int64_t N, int T, int P, int dof, void* stream);
 int tce_pair_logprob_fwd_f64(
     const double* traj, const double* mean, const double* L, int64_t L_stride,
     const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
     double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
     int times_general, const double* init_time, const double* init_pos,
     const double* init_vel, double reg, double* logp, double* basis_ws, int* flag_ws,
-    int64_t N, int T, int P, int dof, void* stream);
+    double* work, int64_t N, int T, int P, int dof, void* stream);
 int tce_pair_logprob_bwd_f32(
     const float* traj, const float* mean, const float* L, int64_t L_stride,
     const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
     float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
     int times_general, const float* init_time, const float* init_pos,
     const float* init_vel, float reg, const float* grad_logp, float* grad_mean,
-    float* grad_L, float* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,
-    void* stream);
+    float* grad_L, float* basis_ws, int* flag_ws, float* work, int64_t N, int T, int P,
+    int dof, void* stream);
 int tce_pair_logprob_bwd_f64(
     const double* traj, const double* mean, const double* L, int64_t L_stride,
     const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
     double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
     int times_general, const double* init_time, const double* init_pos,
     const double* init_vel, double reg, const double* grad_logp, double* grad_mean,
-    double* grad_L, double* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,
-    void* stream);
+    double* grad_L, double* basis_ws, int* flag_ws, double* work, int64_t N, int T,
+    int P, int dof, void* stream);
 /* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
  * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M);

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
     const real* __restrict__ t0, const real* __restrict__ y0,
     const real* __restrict__ v0, real reg, real* __restrict__ logp,
     const real* __restrict__ gout, real* __restrict__ gmean,
-    real* __restrict__ gL, int T, PLShape s) {
+    real* __restrict__ gL, int T, PLShape s, int skip_if_uniform) {
+  if (skip_if_uniform && !times_general && *nonuniform == 0) return;   // fast path ran
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int K = s.K, R = s.R, P = s.P, PC = s.PC, nbg = s.nbg, dof = s.dof;
@@ -250,13 +251,278 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Shared-L fast path (non-contextual covariance + common init time, i.e. every
+// shipped TCE config): M = H_p L, C, its Cholesky factor and inverse depend on
+// the pair only, not on the env.
+//   pair_prep   (1 block / pair) : M_p, Linv_p, Cinv_p, logdet_p -> workspace
+//   pair_env    (1 thread / env) : d, z = Linv d, logp; bwd: alpha = Linv^T z,
+//                                  dmean, per-block partials of
+//                                  S_p = sum_n g alpha alpha^T and sum_n g
+//   pair_final  (1 block)        : dL = sum_p H_p^T (S_p - sg_p Cinv_p) M_p
+// All three exit immediately when the device flag says the init times differ
+// (then the general kernel above does the work).
+// ---------------------------------------------------------------------------
+inline int64_t tce_sum_dim0_slices_impl(int64_t N, int64_t M) {
+  const int64_t col_blocks = ceil_div(M, 64);
+  int64_t s = ceil_div(2048, col_blocks);
+  s = tmin<int64_t>(s, ceil_div(N, 16));
+  return tmax<int64_t>(s, 1);
+}
+
+struct PFShape { int K, R, P, nbg, dof; };
+__host__ __device__ inline int pf_ws_pair(const PFShape& s) {          // reals per pair
+  return 2 * s.nbg + 4 + s.R * s.K + 2 * s.R * s.R + 1;
+}
+
+template <typename real>
+__global__ __launch_bounds__(256) void pair_prep_kernel(
+    const real* __restrict__ L, const int64_t* __restrict__ pairs, const real* __restrict__ B,
+    const int* __restrict__ nonuniform, real reg, real* __restrict__ ws, PFShape s) {
+  if (*nonuniform != 0) return;
+  __shared__ real C[PL_MAXR][PL_MAXR + 1];
+  __shared__ real X[PL_MAXR][PL_MAXR + 1];
+  const int K = s.K, R = s.R, nbg = s.nbg;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  real* w = ws + (int64_t)p * pf_ws_pair(s);
+  real* Hs = w;                       // [2][nbg]
+  real* cs = Hs + 2 * nbg;            // [2][2]
+  real* M = cs + 4;                   // [R][K]
+  real* Li = M + R * K;               // [R][R]
+  real* Ci = Li + R * R;              // [R][R]
+  real* ld = Ci + R * R;              // logdet
+  if (tid < 2 * nbg) {
+    const int j = tid / nbg, b = tid - j * nbg;
+    Hs[tid] = B[pairs[2 * p + j] * (4 + 2 * nbg) + 4 + b];
+  }
+  if (tid < 4) cs[tid] = B[pairs[2 * p + (tid >> 1)] * (4 + 2 * nbg) + (tid & 1)];
+  __syncthreads();
+  for (int e = tid; e < R * K; e += 256) {
+    const int r = e / K, k = e - r * K;
+    const int d = r >> 1, j = r & 1;
+    real acc = 0;
+    for (int b = 0; b < nbg; ++b) {
+      const int row = d * nbg + b;
+      if (k <= row) acc += Hs[j * nbg + b] * L[row * K + k];
+    }
+    M[e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < R * R; e += 256) {
+    const int r = e / R, c = e - r * R;
+    real acc = 0;
+    for (int k = 0; k < K; ++k) acc += M[r * K + k] * M[c * K + k];
+    C[r][c] = acc + (r == c ? reg : real(0));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    real logdet = 0;
+    for (int j = 0; j < R; ++j) {
+      real sd = C[j][j];
+      for (int k = 0; k < j; ++k) sd -= C[j][k] * C[j][k];
+      const real ljj = sqrt(sd);
+      C[j][j] = ljj;
+      logdet += log(ljj);
+      for (int i = j + 1; i < R; ++i) {
+        real v = C[i][j];
+        for (int k = 0; k < j; ++k) v -= C[i][k] * C[j][k];
+        C[i][j] = v / ljj;
+      }
+    }
+    ld[0] = logdet;
+  }
+  __syncthreads();
+  if (tid < R) {                       // column tid of Lc^-1
+    const int c = tid;
+    for (int r = 0; r < R; ++r) {
+      real v = (r == c) ? real(1) : real(0);
+      for (int k = c; k < r; ++k) v -= C[r][k] * X[k][c];
+      X[r][c] = (r < c) ? real(0) : v / C[r][r];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < R * R; e += 256) {
+    const int r = e / R, c = e - r * R;
+    Li[e] = X[r][c];
+    real acc = 0;
+    for (int m = (r > c ? r : c); m < R; ++m) acc += X[m][r] * X[m][c];
+    Ci[e] = acc;
+  }
+}
+
+template <typename real, bool BWD>
+__global__ __launch_bounds__(256) void pair_env_kernel(
+    const real* __restrict__ traj, const real* __restrict__ mean,
+    const int64_t* __restrict__ pairs, const int* __restrict__ nonuniform,
+    const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
+    real* __restrict__ logp, const real* __restrict__ gout, real* __restrict__ gmean,
+    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, PFShape s) {
+  if (*nonuniform != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  const int K = s.K, R = s.R, P = s.P, nbg = s.nbg, dof = s.dof;
+  const int KP = K + 1, RP = R + 1;
+  const int wsp = pf_ws_pair(s);
+  real* Ws = smem;                               // [P][2 nbg + 4 + R*R + 1] compact
+  const int cw = 2 * nbg + 4 + R * R + 1;
+  const int EB = blockDim.x;                     // envs per block (LDS budget)
+  real* ms = Ws + P * cw;                        // [EB][KP]   mean_n
+  real* gm = ms + EB * KP;                       // [EB][KP]   grad mean (BWD)
+  real* Ab = gm + (BWD ? EB * KP : 0);           // [EB][RP]   alpha of the current pair
+  real* gs = Ab + (BWD ? EB * RP : 0);           // [EB]
+  const int tid = threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * EB + tid;
+  const bool ok = n < N;
+  const int64_t nc = ok ? n : N - 1;
+  for (int e = tid; e < P * cw; e += EB) {
+    const int p = e / cw, i = e - p * cw;
+    const real* w = ws + (int64_t)p * wsp;
+    real v;
+    if (i < 2 * nbg + 4) v = w[i];
+    else if (i < 2 * nbg + 4 + R * R) v = w[2 * nbg + 4 + R * K + (i - 2 * nbg - 4)];       // Linv
+    else v = w[2 * nbg + 4 + R * K + 2 * R * R];                                            // logdet
+    Ws[e] = v;
+  }
+  for (int k = 0; k < K; ++k) {
+    ms[tid * KP + k] = mean[nc * K + k];
+    if (BWD) gm[tid * KP + k] = 0;
+  }
+  __syncthreads();
+  for (int p = 0; p < P; ++p) {
+    const real* Hs = Ws + p * cw;
+    const real* cs = Hs + 2 * nbg;
+    const real* Li = cs + 4;
+    real d[PL_MAXR], z[PL_MAXR];
+    const int64_t ta = pairs[2 * p], tb = pairs[2 * p + 1];
+#pragma unroll
+    for (int r = 0; r < PL_MAXR; ++r) {
+      d[r] = 0;
+      if (r < R) {
+        const int dd = r >> 1, j = r & 1;
+        const real* h = Hs + j * nbg;
+        real mu = cs[2 * j] * y0[nc * dof + dd] + cs[2 * j + 1] * v0[nc * dof + dd];
+        for (int b = 0; b < nbg; ++b) mu += h[b] * ms[tid * KP + dd * nbg + b];
+        const real y = traj[(nc * T + (j ? tb : ta)) * (int64_t)(2 * dof) + dd];
+        d[r] = y - mu;
+      }
+    }
+    real quad = 0;
+#pragma unroll
+    for (int r = 0; r < PL_MAXR; ++r) {
+      z[r] = 0;
+      if (r < R) {
+        real acc = 0;
+#pragma unroll
+        for (int c = 0; c < PL_MAXR; ++c)
+          if (c <= r) acc += Li[r * R + c] * d[c];
+        z[r] = acc;
+        quad += acc * acc;
+      }
+    }
+    if (!BWD) {
+      if (ok) logp[n * P + p] = real(-0.5) * quad - Hs[cw - 1] -
+                                real(0.5) * (real)R * real(1.8378770664093453);
+    } else {
+      const real g = ok ? gout[n * P + p] : real(0);
+#pragma unroll
+      for (int r = 0; r < PL_MAXR; ++r) {
+        if (r < R) {
+          real al = 0;
+#pragma unroll
+          for (int m = 0; m < PL_MAXR; ++m)
+            if (m >= r && m < R) al += Li[m * R + r] * z[m];
+          Ab[tid * RP + r] = al;
+          const int dd = r >> 1, j = r & 1;
+          const real* h = Hs + j * nbg;
+          const real ga = g * al;
+          for (int b = 0; b < nbg; ++b) gm[tid * KP + dd * nbg + b] += h[b] * ga;
+        }
+      }
+      gs[tid] = g;
+      __syncthreads();
+      real* out = spart + ((int64_t)blockIdx.x * P + p) * (R * R + 1);
+      for (int e = tid; e < R * R + 1; e += EB) {
+        real acc = 0;
+        if (e < R * R) {
+          const int r = e / R, c = e - r * R;
+          for (int i = 0; i < EB; ++i) acc += gs[i] * Ab[i * RP + r] * Ab[i * RP + c];
+        } else {
+          for (int i = 0; i < EB; ++i) acc += gs[i];
+        }
+        out[e] = acc;
+      }
+      __syncthreads();
+    }
+  }
+  if (BWD && ok)
+    for (int k = 0; k < K; ++k) gmean[n * K + k] = gm[tid * KP + k];
+}
+
+template <typename real>
+__global__ __launch_bounds__(256) void pair_final_kernel(
+    const real* __restrict__ spart, int nblk, const int* __restrict__ nonuniform,
+    const real* __restrict__ ws, real* __restrict__ gL, PFShape s) {
+  if (*nonuniform != 0) return;
+  __shared__ real G[PL_MAXR][PL_MAXR + 1];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* GM = reinterpret_cast<real*>(smem_raw);      // [R][K]
+  const int K = s.K, R = s.R, P = s.P, nbg = s.nbg;
+  const int tid = threadIdx.x;
+  real acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+  for (int p = 0; p < P; ++p) {
+    const real* w = ws + (int64_t)p * pf_ws_pair(s);
+    const real* Hs = w;
+    const real* M = w + 2 * nbg + 4;
+    const real* Ci = M + R * K + R * R;
+    __syncthreads();
+    if (tid < R * R) {
+      real sv = 0, sg = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const real* o = spart + ((int64_t)b * P + p) * (R * R + 1);
+        sv += o[tid];
+        sg += o[R * R];
+      }
+      G[tid / R][tid % R] = sv - sg * Ci[tid];
+    }
+    __syncthreads();
+    for (int e = tid; e < R * K; e += 256) {
+      const int r = e / K, k = e - r * K;
+      real a = 0;
+      for (int c = 0; c < R; ++c) a += G[r][c] * M[c * K + k];
+      GM[e] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + i * 256;
+      if (e < K * K) {
+        const int row = e / K, k = e - row * K;
+        if (k <= row) {
+          const int d = row / nbg, b = row - d * nbg;
+          acc[i] += Hs[b] * GM[(2 * d) * K + k] + Hs[nbg + b] * GM[(2 * d + 1) * K + k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + i * 256;
+    if (e < K * K) gL[e] = acc[i];
+  }
+}
+
+
 // out[j] = sum_n x[n, j]   (x [N, M] row-major).  Two stages so that the whole
 // chip streams the N*M elements: stage 1 (grid = column tiles x row slices)
 // writes partial sums, stage 2 adds the slices.
 template <typename real>
 __global__ __launch_bounds__(256) void sum_dim0_kernel(const real* __restrict__ x,
                                                        real* __restrict__ out,
-                                                       int64_t N, int64_t M, int64_t rows_per) {
+                                                       int64_t N, int64_t M, int64_t rows_per,
+                                                       const int* __restrict__ run_if_nonzero) {
+  if (run_if_nonzero && *run_if_nonzero == 0) return;
   __shared__ real part[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + c;
@@ -277,7 +543,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
               real scaled_dt, real inv_scale_g, int rel_goal, const real* times,
               int times_general, const real* t0, const real* y0, const real* v0, real reg,
               real* logp, const real* gout, real* gmean, real* gL, real* B, int* flag,
-              int64_t N, int T, int P, int dof, hipStream_t stream) {
+              real* work, int64_t N, int T, int P, int dof, hipStream_t stream) {
   TCE_CHECK_ARG(traj && mean && L && pairs && tab && times && t0 && y0 && v0 && B && flag,
                 "pair_logprob: null buffer");
   TCE_CHECK_ARG(bwd ? (gout && gmean && gL) : (logp != nullptr), "pair_logprob: null output");
@@ -291,6 +557,56 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)),
                      dim3(256), 0, stream, mp, times, t0, N, T, B, flag);
   TCE_LAUNCH_CHECK();
+  // ---- shared-L fast path (kernels self-disable if the init times differ)
+  // workspace carve (shared L only): fast-path scratch | per-env dL | sum scratch
+  PFShape f{K, 2 * dof, P, nbg, dof};
+  // envs per block of the fast path: as many as the LDS budget allows
+  const int cw = 2 * nbg + 4 + f.R * f.R + 1;
+  auto env_lds = [&](int eb) {
+    return ((size_t)P * cw + (size_t)eb * (K + 1) * (bwd ? 2 : 1) +
+            (bwd ? (size_t)eb * (f.R + 1) + eb : 0)) * sizeof(real);
+  };
+  int EB = 256;
+  while (EB > 64 && env_lds(EB) > 140 * 1024) EB >>= 1;
+  const int nblk = (int)ceil_div(N, EB);
+  const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1);
+  TCE_CHECK_ARG(sL != 0 || work != nullptr, "pair_logprob: workspace missing (shared L)");
+  real* gL_env = gL;                                       // per-env L: written in place
+  real* sum_ws = nullptr;
+  if (sL == 0 && bwd) {
+    gL_env = work + fast_len;
+    sum_ws = gL_env + N * (int64_t)K * K;
+  }
+  const bool fast = (sL == 0) && !times_general && N >= 256;
+  if (fast) {
+    real* wsp = work;                                      // [P][pf_ws_pair]
+    real* spart = wsp + (int64_t)P * pf_ws_pair(f);        // [nblk][P][R*R+1]
+    hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256), 0, stream, L, pairs, B,
+                       flag, reg, wsp, f);
+    TCE_LAUNCH_CHECK();
+    const size_t lds = env_lds(EB);
+    TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: fast path LDS");
+    if (bwd) {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(EB), lds, stream,
+                         traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
+                         f);
+      TCE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pair_final_kernel<real>, dim3(1), dim3(256),
+                         (size_t)f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gL,
+                         f);
+    } else {
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(EB), lds, stream,
+                         traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
+                         f);
+    }
+    TCE_LAUNCH_CHECK();
+  }
   PLShape s{K, 2 * dof, P, P, nbg, dof};
   const size_t budget = 60 * 1024;
   while (s.PC > 1 && pl_lds_reals(s, bwd) * sizeof(real) > budget) --s.PC;
@@ -301,22 +617,54 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TCE_CHECK_ARG(N < (1ll << 31), "pair_logprob: too many envs");
+  // with the fast path launched, gL of the general kernel is per env: the fast
+  // path writes the already-reduced [K,K] gradient into gL_shared instead
   hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(PL_BT), lds, stream, traj, mean, L, sL,
                      pairs, B, flag, mp, times, times_general, t0, y0, v0, reg, logp, gout,
-                     gmean, gL, T, s);
+                     gmean, gL_env, T, s, fast ? 1 : 0);
   TCE_LAUNCH_CHECK();
+  if (sL == 0 && bwd) {
+    // dL of the shared matrix = sum over envs of the general kernel's per-env
+    // gradients -- only needed when the general kernel actually ran
+    const int64_t M2 = (int64_t)K * K;
+    const int64_t slices = tce_sum_dim0_slices_impl(N, M2);
+    const int64_t rows_per = ceil_div(N, slices);
+    const int* cond = fast ? flag : nullptr;
+    dim3 grid((unsigned)ceil_div(M2, 64), (unsigned)slices);
+    hipLaunchKernelGGL(sum_dim0_kernel<real>, grid, dim3(256), 0, stream, gL_env,
+                       slices == 1 ? gL : sum_ws, N, M2, rows_per, cond);
+    TCE_LAUNCH_CHECK();
+    if (slices > 1) {
+      hipLaunchKernelGGL(sum_dim0_kernel<real>, dim3((unsigned)ceil_div(M2, 64)), dim3(256), 0,
+                         stream, sum_ws, gL, slices, M2, slices, cond);
+      TCE_LAUNCH_CHECK();
+    }
+  }
   return 0;
+}
+
+template <typename real>
+int64_t pl_work_len(int64_t N, int P, int dof, int nbg, int64_t sL, bool bwd) {
+  if (sL != 0) return 0;
+  const int K = dof * nbg;
+  PFShape f{K, 2 * dof, P, nbg, dof};
+  const int64_t nblk = ceil_div(N, 64);                  // smallest fast-path block
+  int64_t n = (int64_t)P * pf_ws_pair(f) + nblk * P * (f.R * f.R + 1);
+  if (bwd) n += N * (int64_t)K * K + tce_sum_dim0_slices_impl(N, (int64_t)K * K) * K * K;
+  return n;
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t tce_sum_dim0_slices(int64_t N, int64_t M) {
-  const int64_t col_blocks = ceil_div(M, 64);
-  int64_t s = ceil_div(2048, col_blocks);
-  s = tmin<int64_t>(s, ceil_div(N, 16));
-  return tmax<int64_t>(s, 1);
+int64_t tce_sum_dim0_slices(int64_t N, int64_t M) { return tce_sum_dim0_slices_impl(N, M); }
+
+/* workspace (in elements of the dtype) of the pair log-prob calls; 0 for a
+ * per-env L */
+int64_t tce_pair_logprob_work_len(int64_t N, int P, int dof, int nbg, int64_t L_stride,
+                                  int bwd) {
+  return pl_work_len<float>(N, P, dof, nbg, L_stride, bwd != 0);
 }
 
 #define DEFINE_PL(SFX, REAL)                                                     \
@@ -326,13 +674,13 @@ int64_t tce_sum_dim0_slices(int64_t N, int64_t M) {
       REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal,                \
       const REAL* times, int times_general, const REAL* init_time,               \
       const REAL* init_pos, const REAL* init_vel, REAL reg, REAL* logp,          \
-      REAL* basis_ws, int* flag_ws, int64_t N, int T, int P, int dof,            \
-      void* stream) {                                                            \
+      REAL* basis_ws, int* flag_ws, REAL* work, int64_t N, int T, int P,         \
+      int dof, void* stream) {                                                   \
     return pl_launch<REAL>(false, traj, mean, L, L_stride, pairs, tab, M, nbg,   \
                            tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
                            times_general, init_time, init_pos, init_vel, reg,    \
-                           logp, nullptr, nullptr, nullptr, basis_ws, flag_ws, N, \
-                           T, P, dof, (hipStream_t)stream);                      \
+                           logp, nullptr, nullptr, nullptr, basis_ws, flag_ws,   \
+                           work, N, T, P, dof, (hipStream_t)stream);             \
   }                                                                              \
   int tce_pair_logprob_bwd_##SFX(                                                \
       const REAL* traj, const REAL* mean, const REAL* L, int64_t L_stride,       \
@@ -341,12 +689,13 @@ int64_t tce_sum_dim0_slices(int64_t N, int64_t M) {
       const REAL* times, int times_general, const REAL* init_time,               \
       const REAL* init_pos, const REAL* init_vel, REAL reg,                      \
       const REAL* grad_logp, REAL* grad_mean, REAL* grad_L, REAL* basis_ws,      \
-      int* flag_ws, int64_t N, int T, int P, int dof, void* stream) {            \
+      int* flag_ws, REAL* work, int64_t N, int T, int P, int dof,                \
+      void* stream) {                                                            \
     return pl_launch<REAL>(true, traj, mean, L, L_stride, pairs, tab, M, nbg,    \
                            tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
                            times_general, init_time, init_pos, init_vel, reg,    \
                            nullptr, grad_logp, grad_mean, grad_L, basis_ws,      \
-                           flag_ws, N, T, P, dof, (hipStream_t)stream);          \
+                           flag_ws, work, N, T, P, dof, (hipStream_t)stream);    \
   }                                                                              \
   /* ws: REAL [tce_sum_dim0_slices(N, M), M] workspace (may be NULL when the  \
      slice count is 1) */                                                        \
@@ -359,12 +708,12 @@ int64_t tce_sum_dim0_slices(int64_t N, int64_t M) {
     dim3 grid((unsigned)ceil_div(M, 64), (unsigned)slices);                      \
     hipLaunchKernelGGL(sum_dim0_kernel<REAL>, grid, dim3(256), 0,                \
                        (hipStream_t)stream, x, slices == 1 ? out : ws, N, M,     \
-                       rows_per);                                                \
+                       rows_per, (const int*)nullptr);                           \
     TCE_LAUNCH_CHECK();                                                          \
     if (slices > 1) {                                                            \
       hipLaunchKernelGGL(sum_dim0_kernel<REAL>, dim3((unsigned)ceil_div(M, 64)), \
                          dim3(256), 0, (hipStream_t)stream, ws, out, slices, M,  \
-                         slices);                                                \
+                         slices, (const int*)nullptr);                           \
       TCE_LAUNCH_CHECK();                                                        \
     }                                                                            \
     return 0;                                                                    \

@@ -240,6 +240,14 @@ def prodmp_traj(mp, times_, params, init_time, init_pos, init_vel):
     return out
 
 
+def _pl_work(ref, N, P, mp, sL, bwd):
+    n = _lib.load().tce_pair_logprob_work_len(N, P, mp.num_dof,
+                                               mp.num_basis_g, sL, int(bwd))
+    if n == 0:
+        return None
+    return torch.empty(n, dtype=ref.dtype, device=ref.device)
+
+
 class _PairLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, Lc, sL, mp, traj, times_, general, t0, y0, v0,
@@ -248,10 +256,11 @@ class _PairLogProb(torch.autograd.Function):
         P = pairs.shape[0]
         logp = torch.empty(N, P, dtype=mean.dtype, device=mean.device)
         B, flag = _mp_ws(mp, T, mean.device)
+        work = _pl_work(mean, N, P, mp, sL, False)
         call("tce_pair_logprob_fwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
              ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), general,
              ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(logp), ptr(B),
-             ptr(flag), N, T, P, mp.num_dof, stream())
+             ptr(flag), ptr(work), N, T, P, mp.num_dof, stream())
         ctx.save_for_backward(mean, Lc, traj, times_, t0, y0, v0, pairs)
         ctx.mp, ctx.sL, ctx.general = mp, sL, general
         return logp
@@ -264,14 +273,15 @@ class _PairLogProb(torch.autograd.Function):
         P, K = pairs.shape[0], mean.shape[1]
         g = _c(g)
         gmean = torch.empty_like(mean)
-        gL = torch.empty(N, K, K, dtype=mean.dtype, device=mean.device)
+        gL = torch.empty((K, K) if sL == 0 else (N, K, K), dtype=mean.dtype,
+                         device=mean.device)
         B, flag = _mp_ws(mp, T, mean.device)
+        work = _pl_work(mean, N, P, mp, sL, True)
         call("tce_pair_logprob_bwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
              ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), ctx.general,
              ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(g), ptr(gmean),
-             ptr(gL), ptr(B), ptr(flag), N, T, P, mp.num_dof, stream())
-        if sL == 0:
-            gL = sum_dim0(gL.reshape(N, K * K)).reshape(K, K)
+             ptr(gL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof,
+             stream())
         return (gmean, gL) + (None,) * 9
 
 
