@@ -91,7 +91,10 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
     int64_t sL, real eps, const real* __restrict__ gout, real* __restrict__ out,
     real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  real* Ls = reinterpret_cast<real*>(smem_raw);
+  // LDS: d[K][64] | q[K][64] (lane = env: conflict free) | shared L [K][K]
+  real* dS = reinterpret_cast<real*>(smem_raw);
+  real* qS = dS + K * 64;
+  real* Ls = qS + K * 64;
   const bool shared = (sL == 0);
   if (shared) {
     for (int e = threadIdx.x; e < K * K; e += 64) Ls[e] = L[e];
@@ -100,15 +103,15 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
   const int64_t n = blockIdx.x * 64ll + threadIdx.x;
   if (n >= N) return;
   const real* Ln = shared ? Ls : L + n * sL;
-  real d[VE_MAXK];
+  real* d = dS + threadIdx.x;          // d[k] -> d[k * 64]
   real quad = 0, logdet = 0;
 #pragma unroll 1
   for (int r = 0; r < K; ++r) {
     real v = x[n * K + r] - y[n * K + r];
-    for (int k = 0; k < r; ++k) v -= Ln[r * K + k] * d[k];
+    for (int k = 0; k < r; ++k) v -= Ln[r * K + k] * d[k * 64];
     const real lrr = Ln[r * K + r];
     v /= lrr;
-    d[r] = v;
+    d[r * 64] = v;
     quad += v * v;
     if (MODE == 2) logdet += log(lrr);
   }
@@ -128,17 +131,17 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
     }
     return;
   }
-  // backward: q = L^-T d (in place into q[])
-  real q[VE_MAXK];
+  // backward: q = L^-T d
+  real* q = qS + threadIdx.x;
 #pragma unroll 1
   for (int r = K - 1; r >= 0; --r) {
-    real v = d[r];
-    for (int k = r + 1; k < K; ++k) v -= Ln[k * K + r] * q[k];
-    q[r] = v / Ln[r * K + r];
+    real v = d[r * 64];
+    for (int k = r + 1; k < K; ++k) v -= Ln[k * K + r] * q[k * 64];
+    q[r * 64] = v / Ln[r * K + r];
   }
   if (MODE == 0) {
     const real g = gout[n];
-    for (int r = 0; r < K; ++r) gx[n * K + r] = real(2) * g * q[r];
+    for (int r = 0; r < K; ++r) gx[n * K + r] = real(2) * g * q[r * 64];
   } else if (MODE == 1) {
     const real m = real(0.5) * quad;
     if (m > eps) {
@@ -146,19 +149,19 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
       real gd = 0;
       for (int r = 0; r < K; ++r) gd += gout[n * K + r] * (x[n * K + r] - y[n * K + r]);
       const real coef = gd / (real(2) * eps * s * s * s);
-      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r] / s - coef * q[r];
+      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r] / s - coef * q[r * 64];
     } else {
       for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r];
     }
   } else {
     const real g = gout[n];
-    for (int r = 0; r < K; ++r) gx[n * K + r] = g * q[r];      // d logp / d mean
+    for (int r = 0; r < K; ++r) gx[n * K + r] = g * q[r * 64];      // d logp / d mean
     if (gLout) {
       real* gl = gLout + n * (int64_t)K * K;
       for (int r = 0; r < K; ++r)
         for (int c = 0; c < K; ++c) {
           real v = 0;
-          if (c <= r) v = g * (q[r] * d[c] - (r == c ? real(1) / Ln[r * K + r] : real(0)));
+          if (c <= r) v = g * (q[r * 64] * d[c * 64] - (r == c ? real(1) / Ln[r * K + r] : real(0)));
           gl[r * K + c] = v;
         }
     }
@@ -258,13 +261,28 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     if (threadIdx.x < 64) {
       const bool live = threadIdx.x < K;
       const double lm = live ? lam[threadIdx.x] : 1.0;
+      // h is convex and decreasing in eta, h(0) > eps: Newton from the left
+      // converges monotonically; bracket kept for safety, bisection fallback
       double lo = 0.0, hi = 1.0;
       for (int i = 0; i < 200 && klp_h(hi, lm, live) > eps; ++i) { lo = hi; hi *= 2.0; }
-      for (int i = 0; i < 100; ++i) {
-        const double mid = 0.5 * (lo + hi);
-        if (klp_h(mid, lm, live) > eps) lo = mid; else hi = mid;
+      double eta_n = lo;
+      for (int i = 0; i < 60; ++i) {
+        double t = 0, dt = 0;
+        if (live) {
+          const double w = 1.0 / (eta_n * lm + 1.0);
+          const double mu = (eta_n + 1.0) * lm * w;
+          t = mu - 1.0 - log(mu);
+          dt = (1.0 - 1.0 / mu) * lm * (1.0 - lm) * w * w;
+        }
+        const double hv = 0.5 * wave_sum(t) - eps;
+        const double dh = 0.5 * wave_sum(dt);
+        if (hv > 0) lo = eta_n; else hi = eta_n;
+        double nxt = eta_n - hv / dh;
+        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+        if (fabs(nxt - eta_n) <= 1e-15 * fabs(nxt)) { eta_n = nxt; break; }
+        eta_n = nxt;
       }
-      if (threadIdx.x == 0) s_eta = 0.5 * (lo + hi);
+      if (threadIdx.x == 0) s_eta = eta_n;
     }
     __syncthreads();
     eta = s_eta;
@@ -463,32 +481,39 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
     TCE_CHECK_ARG(bwd ? (grad_out && grad_x) : (out != nullptr),                  \
                   "vec_env: null output");                                        \
     const unsigned nb = (unsigned)ceil_div(N, 64);                                \
-    const size_t lds = L_stride == 0 ? (size_t)K * K * sizeof(REAL) : 0;          \
+    const size_t lds = (2 * (size_t)K * 64 + (L_stride == 0 ? (size_t)K * K : 0)) \
+                       * sizeof(REAL);                                            \
     hipStream_t st = (hipStream_t)stream;                                         \
     if (mode == 0 && !bwd)                                                        \
+      { set_lds(vec_env_kernel<REAL, 0, false>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 0, false>), dim3(nb), dim3(64),    \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else if (mode == 0)                                                           \
+      { set_lds(vec_env_kernel<REAL, 0, true>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 0, true>), dim3(nb), dim3(64),     \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else if (mode == 1 && !bwd)                                                   \
+      { set_lds(vec_env_kernel<REAL, 1, false>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 1, false>), dim3(nb), dim3(64),    \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else if (mode == 1)                                                           \
+      { set_lds(vec_env_kernel<REAL, 1, true>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 1, true>), dim3(nb), dim3(64),     \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else if (mode == 2 && !bwd)                                                   \
+      { set_lds(vec_env_kernel<REAL, 2, false>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 2, false>), dim3(nb), dim3(64),    \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else if (mode == 2)                                                           \
+      { set_lds(vec_env_kernel<REAL, 2, true>, lds);                                  \
       hipLaunchKernelGGL((vec_env_kernel<REAL, 2, true>), dim3(nb), dim3(64),     \
                          lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K);                                           \
+                         grad_L, N, K); }                                           \
     else {                                                                        \
       tce_set_error("vec_env: unknown mode");                                     \
       return 1;                                                                   \

@@ -458,61 +458,56 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
     for (int k = 0; k < K; ++k) gmean[n * K + k] = gm[tid * KP + k];
 }
 
+// One block per pair: contribution of pair p to dL, gLp[p] [K,K] (the caller
+// sums over p with sum_dim0).
 template <typename real>
 __global__ __launch_bounds__(256) void pair_final_kernel(
     const real* __restrict__ spart, int nblk, const int* __restrict__ nonuniform,
-    const real* __restrict__ ws, real* __restrict__ gL, PFShape s) {
+    const real* __restrict__ ws, real* __restrict__ gLp, PFShape s) {
   if (*nonuniform != 0) return;
   __shared__ real G[PL_MAXR][PL_MAXR + 1];
+  __shared__ real red[4][PL_MAXR * PL_MAXR + 1];
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* GM = reinterpret_cast<real*>(smem_raw);      // [R][K]
   const int K = s.K, R = s.R, P = s.P, nbg = s.nbg;
-  const int tid = threadIdx.x;
-  real acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0;
-  for (int p = 0; p < P; ++p) {
-    const real* w = ws + (int64_t)p * pf_ws_pair(s);
-    const real* Hs = w;
-    const real* M = w + 2 * nbg + 4;
-    const real* Ci = M + R * K + R * R;
-    __syncthreads();
-    if (tid < R * R) {
-      real sv = 0, sg = 0;
-      for (int b = 0; b < nblk; ++b) {
-        const real* o = spart + ((int64_t)b * P + p) * (R * R + 1);
-        sv += o[tid];
-        sg += o[R * R];
-      }
-      G[tid / R][tid % R] = sv - sg * Ci[tid];
-    }
-    __syncthreads();
-    for (int e = tid; e < R * K; e += 256) {
-      const int r = e / K, k = e - r * K;
-      real a = 0;
-      for (int c = 0; c < R; ++c) a += G[r][c] * M[c * K + k];
-      GM[e] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + i * 256;
-      if (e < K * K) {
-        const int row = e / K, k = e - row * K;
-        if (k <= row) {
-          const int d = row / nbg, b = row - d * nbg;
-          acc[i] += Hs[b] * GM[(2 * d) * K + k] + Hs[nbg + b] * GM[(2 * d + 1) * K + k];
-        }
-      }
-    }
+  const int tid = threadIdx.x, p = blockIdx.x;
+  const real* w = ws + (int64_t)p * pf_ws_pair(s);
+  const real* Hs = w;
+  const real* M = w + 2 * nbg + 4;
+  const real* Ci = M + R * K + R * R;
+  // S_p and sg_p: sum the per-block partials (4 groups of blocks in parallel)
+  const int nv = R * R + 1;
+  for (int e = tid; e < 4 * nv; e += 256) {
+    const int grp = e / nv, i = e - grp * nv;
+    real acc = 0;
+    for (int b = grp; b < nblk; b += 4) acc += spart[((int64_t)b * P + p) * nv + i];
+    red[grp][i] = acc;
   }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + i * 256;
-    if (e < K * K) gL[e] = acc[i];
+  __syncthreads();
+  if (tid < R * R) {
+    const real sv = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const real sg = red[0][R * R] + red[1][R * R] + red[2][R * R] + red[3][R * R];
+    G[tid / R][tid % R] = sv - sg * Ci[tid];
+  }
+  __syncthreads();
+  for (int e = tid; e < R * K; e += 256) {
+    const int r = e / K, k = e - r * K;
+    real a = 0;
+    for (int c = 0; c < R; ++c) a += G[r][c] * M[c * K + k];
+    GM[e] = a;
+  }
+  __syncthreads();
+  real* out = gLp + (int64_t)p * K * K;
+  for (int e = tid; e < K * K; e += 256) {
+    const int row = e / K, k = e - row * K;
+    real v = 0;
+    if (k <= row) {
+      const int d = row / nbg, b = row - d * nbg;
+      v = Hs[b] * GM[(2 * d) * K + k] + Hs[nbg + b] * GM[(2 * d + 1) * K + k];
+    }
+    out[e] = v;
   }
 }
-
 
 // out[j] = sum_n x[n, j]   (x [N, M] row-major).  Two stages so that the whole
 // chip streams the N*M elements: stage 1 (grid = column tiles x row slices)
@@ -521,8 +516,10 @@ template <typename real>
 __global__ __launch_bounds__(256) void sum_dim0_kernel(const real* __restrict__ x,
                                                        real* __restrict__ out,
                                                        int64_t N, int64_t M, int64_t rows_per,
-                                                       const int* __restrict__ run_if_nonzero) {
+                                                       const int* __restrict__ run_if_nonzero,
+                                                       const int* __restrict__ run_if_zero = nullptr) {
   if (run_if_nonzero && *run_if_nonzero == 0) return;
+  if (run_if_zero && *run_if_zero != 0) return;
   __shared__ real part[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + c;
@@ -566,10 +563,12 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     return ((size_t)P * cw + (size_t)eb * (K + 1) * (bwd ? 2 : 1) +
             (bwd ? (size_t)eb * (f.R + 1) + eb : 0)) * sizeof(real);
   };
-  int EB = 256;
-  while (EB > 64 && env_lds(EB) > 140 * 1024) EB >>= 1;
+  // 64 envs per block: N/64 blocks keep more CUs busy than N/256 and the
+  // per-pair S reduction loops over 64 entries
+  int EB = 64;
   const int nblk = (int)ceil_div(N, EB);
-  const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1);
+  const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1) +
+                           (bwd ? (int64_t)P * K * K : 0);
   TCE_CHECK_ARG(sL != 0 || work != nullptr, "pair_logprob: workspace missing (shared L)");
   real* gL_env = gL;                                       // per-env L: written in place
   real* sum_ws = nullptr;
@@ -594,9 +593,15 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f);
       TCE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(pair_final_kernel<real>, dim3(1), dim3(256),
-                         (size_t)f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gL,
+      real* gLp = spart + (int64_t)nblk * P * (f.R * f.R + 1);   // [P][K][K]
+      hipLaunchKernelGGL(pair_final_kernel<real>, dim3(P), dim3(256),
+                         (size_t)f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gLp,
                          f);
+      TCE_LAUNCH_CHECK();
+      // dL = sum_p gLp[p]  (runs only when the fast path did: flag == 0)
+      hipLaunchKernelGGL(sum_dim0_kernel<real>, dim3((unsigned)ceil_div((int64_t)K * K, 64)),
+                         dim3(256), 0, stream, gLp, gL, (int64_t)P, (int64_t)K * K,
+                         (int64_t)P, (const int*)nullptr, flag);
     } else {
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, false>),
@@ -650,7 +655,8 @@ int64_t pl_work_len(int64_t N, int P, int dof, int nbg, int64_t sL, bool bwd) {
   PFShape f{K, 2 * dof, P, nbg, dof};
   const int64_t nblk = ceil_div(N, 64);                  // smallest fast-path block
   int64_t n = (int64_t)P * pf_ws_pair(f) + nblk * P * (f.R * f.R + 1);
-  if (bwd) n += N * (int64_t)K * K + tce_sum_dim0_slices_impl(N, (int64_t)K * K) * K * K;
+  if (bwd) n += (int64_t)P * K * K + N * (int64_t)K * K +
+                tce_sum_dim0_slices_impl(N, (int64_t)K * K) * K * K;
   return n;
 }
 
