@@ -266,6 +266,9 @@ int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, i
  * old_values.  values (nullable) [R]; partials float
  * [tce_mlp_critic_grid(), num_params + 2]; grad float [num_params] in the order
  * W1, b1, W2, b2, w3, b3; stats float[2] = {mean loss, |grad|^2}.
+ * max_workgroups (0 = one per CU): persistent workgroups to launch; fewer than
+ * the CU count leaves CUs free for kernels of another stream (the policy
+ * update runs beside the critic epochs).
  */
 int tce_mlp_critic_hidden(void);
 int tce_mlp_critic_grid(void);
@@ -275,7 +278,7 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        const float* w2, const float* b2, const float* w3, const float* b3,
                        int act, const float* returns, const float* old_values, float clip,
                        float* values, float* partials, float* grad, float* stats,
-                       void* stream);
+                       int max_workgroups, void* stream);
 
 #ifdef __cplusplus
 }

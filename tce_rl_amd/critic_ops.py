@@ -43,7 +43,7 @@ def forward(mlp, x):
     out = torch.empty(R, dtype=torch.float32, device=x.device)
     call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, mlp.dim_in,
          *_weights(mlp), _ACT[mlp.act_func_hidden_type], None, None, 0.0,
-         ptr(out), None, None, None, stream())
+         ptr(out), None, None, None, 0, stream())
     return out.reshape(*x.shape[:-1], 1)
 
 
@@ -68,7 +68,7 @@ class EpochRunner:
             off += p.numel()
         assert off == self.P
 
-    def epoch(self, states, returns, old_values, clip):
+    def epoch(self, states, returns, old_values, clip, max_workgroups=0):
         """One full-batch forward + loss + backward; leaves the gradient in
         p.grad (views of the flat buffer) and returns stats = {mean loss,
         |grad|^2} as a device tensor [2]."""
@@ -82,7 +82,7 @@ class EpochRunner:
         call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, self.mlp.dim_in,
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
-             ptr(self.flat), ptr(stats), stream())
+             ptr(self.flat), ptr(stats), int(max_workgroups), stream())
         for p, v in zip(self.params, self.views):
             p.grad = v
         return stats

@@ -414,7 +414,7 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        const float* w2, const float* b2, const float* w3, const float* b3,
                        int act, const float* returns, const float* old_values, float clip,
                        float* values, float* partials, float* grad, float* stats,
-                       void* stream) {
+                       int max_workgroups, void* stream) {
   TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && R > 0 && T > 0,
                 "mlp_critic: null buffer / bad sizes");
   TCE_CHECK_ARG(din >= 1 && din <= 48, "mlp_critic: 1 <= D_in <= 48");
@@ -427,7 +427,9 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
             returns, old_values, clip, values, partials};
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = ceil_div(R, ROWS_PER_TILE);
-  const int grid = (int)tmin<int64_t>(tce_mlp_critic_grid(), ntiles);
+  int cap = tce_mlp_critic_grid();
+  if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
+  const int grid = (int)tmin<int64_t>(cap, ntiles);
   switch (act) {
     case 0: mlp_go<ACT_TANH>(bwd, a, grid, st); break;
     case 1: mlp_go<ACT_RELU>(bwd, a, grid, st); break;

@@ -168,6 +168,10 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.balance_check = kwargs.get("balance_check", 10)
         self.evaluation_interval = kwargs.get("evaluation_interval", 1)
         self.check_policy_balance = False
+        # extension: run the critic and policy updates on two HIP streams
+        self.overlap_updates = kwargs.get("overlap_updates", True)
+        self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
+        self._policy_stream = None
 
     def step(self):
         self.num_iterations += 1
@@ -187,18 +191,22 @@ class TemporalCorrelatedAgent(AbstractAgent):
                           "step_states", "step_actions")}, "exploration")
 
         util.run_time_test(lock=True, key="update")
-        util.run_time_test(lock=True, key="update critic")
-        critic_loss_dict = self.update_critic(dataset)
+        if self._can_overlap():
+            critic_loss_dict, policy_loss_dict, update_critic_time, \
+                update_policy_time = self._update_overlapped(dataset)
+        else:
+            util.run_time_test(lock=True, key="update critic")
+            critic_loss_dict = self.update_critic(dataset)
+            update_critic_time = util.run_time_test(lock=False,
+                                                    key="update critic")
+            util.run_time_test(lock=True, key="update policy")
+            policy_loss_dict = self.update_policy(dataset)
+            update_policy_time = util.run_time_test(lock=False,
+                                                    key="update policy")
         if self.schedule_lr_critic:
             self.critic_lr_scheduler.step()
-        update_critic_time = util.run_time_test(lock=False,
-                                                key="update critic")
-        util.run_time_test(lock=True, key="update policy")
-        policy_loss_dict = self.update_policy(dataset)
         if self.schedule_lr_policy:
             self.policy_lr_scheduler.step()
-        update_policy_time = util.run_time_test(lock=False,
-                                                key="update policy")
         update_time = util.run_time_test(lock=False, key="update")
 
         result_metrics = {
@@ -228,6 +236,41 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 lock=False, key="evaluation")
         return result_metrics
 
+    # ---- critic and policy updates side by side ------------------------------
+    def _can_overlap(self):
+        from .. import critic_ops
+        return self.overlap_updates and self.num_minibatchs == 1 and \
+            critic_ops.supported(self.critic.net)
+
+    def _update_overlapped(self, dataset):
+        """The critic and policy updates of one iteration touch disjoint
+        networks and only read the dataset, so they are independent.  The
+        critic epochs (one persistent MFMA kernel each, 1 workgroup per CU) are
+        enqueued first on the main stream with a few CUs left free; the policy
+        epochs (many small latency-bound kernels) are then enqueued on a second
+        HIP stream and run beside them.  Results are identical to the
+        sequential order; the per-phase times reported are the device times of
+        each stream (HIP events)."""
+        main = torch.cuda.current_stream()
+        if self._policy_stream is None:
+            self._policy_stream = torch.cuda.Stream()
+        side = self._policy_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(main)
+        finish_critic = self.update_critic(dataset, defer=True,
+                                           max_workgroups=self.critic_workgroups)
+        ev[1].record(main)
+        side.wait_event(ev[0])
+        with torch.cuda.stream(side):
+            ev[2].record(side)
+            policy_loss_dict = self.update_policy(dataset)
+            ev[3].record(side)
+        main.wait_stream(side)
+        critic_loss_dict = finish_critic()
+        torch.cuda.synchronize()
+        return critic_loss_dict, policy_loss_dict, \
+            ev[0].elapsed_time(ev[1]) * 1e-3, ev[2].elapsed_time(ev[3]) * 1e-3
+
     # ---- dataset processing (GAE + segment advantage: HIP kernels) -----------
     def process_dataset(self, dataset):
         rewards, values = dataset["step_rewards"], dataset["step_values"]
@@ -256,7 +299,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
             fused=fused)
 
     # ---- critic ----------------------------------------------------------------
-    def update_critic(self, dataset):
+    def update_critic(self, dataset, defer=False, max_workgroups=0):
         D2 = self.policy.num_dof * 2
         states = dataset["step_states"]                  # [N, T, D] (view)
         N, T = states.shape[:2]
@@ -266,8 +309,10 @@ class TemporalCorrelatedAgent(AbstractAgent):
         fused = critic_ops.supported(self.critic.net) and \
             self.num_minibatchs == 1
         if fused:
-            return self._update_critic_fused(states[..., :-D2], returns,
-                                             old_values)
+            finish = self._update_critic_fused(states[..., :-D2], returns,
+                                               old_values, max_workgroups)
+            return finish if defer else finish()
+        assert not defer
         losses, norms, norms_c = [], [], []
         for _ in range(self.epochs_critic):
             for sel in self._minibatches(N * T):
@@ -294,7 +339,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 **util.generate_stats(host[1], "critic_grad_norm"),
                 **util.generate_stats(host[2], "clipped_critic_grad_norm")}
 
-    def _update_critic_fused(self, x, returns, old_values):
+    def _update_critic_fused(self, x, returns, old_values, max_workgroups=0):
         """Full-batch critic epochs on the fused fp32-MFMA kernel: one launch
         does forward + value loss + backward for all N*T rows (read in place
         from the rollout buffer), a second reduces the per-workgroup gradient
@@ -305,7 +350,8 @@ class TemporalCorrelatedAgent(AbstractAgent):
             run = self._critic_runner = critic_ops.EpochRunner(self.critic.net)
         rows = []
         for _ in range(self.epochs_critic):
-            stats = run.epoch(x, returns, old_values, self.clip_critic)
+            stats = run.epoch(x, returns, old_values, self.clip_critic,
+                              max_workgroups)
             if self.dist.world > 1:
                 self.dist.allreduce_flat(run.flat)
                 g = run.flat.norm(2)
@@ -318,10 +364,15 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 gc = g * coef
             self.critic_optimizer.step()
             rows.append(torch.stack([stats[0], g, gc]))
-        host = torch.stack(rows).cpu().numpy()
-        return {**util.generate_stats(host[:, 0], "critic_loss"),
-                **util.generate_stats(host[:, 1], "critic_grad_norm"),
-                **util.generate_stats(host[:, 2], "clipped_critic_grad_norm")}
+        stacked = torch.stack(rows)
+
+        def finish():
+            host = stacked.cpu().numpy()                     # the only sync
+            return {**util.generate_stats(host[:, 0], "critic_loss"),
+                    **util.generate_stats(host[:, 1], "critic_grad_norm"),
+                    **util.generate_stats(host[:, 2],
+                                          "clipped_critic_grad_norm")}
+        return finish
 
     def _minibatches(self, n):
         """generate_minibatches (util_data_structure.py:378-391).  With ONE
