@@ -26,6 +26,7 @@ import torch.distributed as dist  # noqa: E402
 
 NUM_ENV, NUM_BASIS, EPOCHS = 4096, 5, 50
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix (dense, = vector peak)
 
 
 def build_agent(num_env, seed):
@@ -61,11 +62,34 @@ def kernel_time_us(fn, launches=20):
 
 
 def roofline(agent):
-    """HBM roofline of the GAE scan (dominant HBM-bound kernel of the path):
-    algorithmic bytes = 18 B per (env, step) + 4 B per env."""
-    from tce_rl_amd import ops
+    """Rooflines measured live with HIP events on the launch stream.
+
+    dominant kernel = mlp_critic_kernel (the 50 critic epochs are ~85 % of the
+    device time of a step): MFMA-bound, algorithmic flops per launch =
+    6 * (D_in*H + H*H + H) per row (forward 2x, backward 4x) * N*T rows
+    against the dense FP32 matrix peak.  GAE scan and trajectory generator:
+    HBM-bound, algorithmic bytes per SURVEY 8(d)."""
+    from tce_rl_amd import ops, critic_ops
     N, T = NUM_ENV, agent.sampler.num_times
     g = torch.Generator(device="cuda").manual_seed(0)
+    net = agent.critic.net
+    din = net.dim_in
+    full = torch.randn(N, T + 1, din + 8, device="cuda", generator=g)
+    xs = full[:, :-1, :din]
+    rets = torch.randn(N, T, device="cuda", generator=g)
+    saved = [p.grad for p in net.parameters()]
+    run = critic_ops.EpochRunner(net)
+    us_c = kernel_time_us(lambda: run.epoch(xs, rets, rets, 0.0), launches=5)
+    for p, gr in zip(net.parameters(), saved):
+        p.grad = gr
+    flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
+    critic = {"kernel": "mlp_critic_kernel<relu,bwd> (+ mlp_reduce_kernel)",
+              "bound": "mfma", "achieved": round(flops / us_c / 1e6, 2),
+              "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+              "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4),
+              "traffic": None, "us_per_launch": round(us_c, 1),
+              "algorithmic_flops": flops, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+    del full, xs
     r = torch.randn(N, T, device="cuda", generator=g)
     v = torch.randn(N, T + 1, device="cuda", generator=g)
     d = torch.zeros(N, T, dtype=torch.bool, device="cuda")
@@ -94,7 +118,8 @@ def roofline(agent):
         "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
         "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
         "note": "basis-table kernel + trajectory kernel"}}
-    return gae, extra
+    extra["gae_scan"] = gae
+    return critic, extra
 
 
 def cpu_baseline():

@@ -1,0 +1,17 @@
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tce_rl_amd.config import tce_config
+from tce_rl_amd.mp_exp import MPExperiment
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for wg in (0, 208, 224, 240, 248):
+    cfg = tce_config("metaworld", num_env=4096, epochs=50, num_basis=nb)
+    a = cfg["params"]["agent"]["args"]
+    a["overlap_updates"] = wg != 0
+    a["critic_workgroups"] = wg or 256
+    exp = MPExperiment(); exp.initialize(cfg, 0, None)
+    for i in range(4):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        res = exp.iterate(cfg, 0, i)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print(f"critic_workgroups={wg or 'sequential'}: {dt*1e3:.1f} ms/step  critic {res['update_critic_time']*1e3:.0f} ms policy {res['update_policy_time']*1e3:.0f} ms", flush=True)
+    del exp

@@ -34,6 +34,7 @@ constexpr int HID = 128;
 constexpr int NB = HID / 16;          // 8 row blocks of 16 hidden units
 constexpr int W2P = HID + 1;          // LDS pitch of W2 (bank-conflict free rows)
 constexpr int TP = 17;                // pitch of the [hidden][16 batch] transposes
+constexpr int XSP = 49;               // pitch of the X tile stashed for dW1 (>= 4 * MAXKPG, odd)
 constexpr int MAXKPG = 12;            // D_in <= 48 (LDS budget)
 constexpr int MLP_BT = 256;
 constexpr int ROWS_PER_TILE = 64;
@@ -135,49 +136,82 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
   float* th1 = Th1 + wave * HID * TP;
   float* tdy = Tdy + wave * HID * TP;
 
+  // X fragment of a tile: lane (c, g) holds X[r][kpg*g + s], s < kpg.  Loaded
+  // one tile ahead (clamped addresses, no branches around the loads) so that
+  // the HBM latency hides behind the previous tile's MFMAs.
+  auto load_x = [&](int64_t tile, float* dst) {
+    const int64_t rr = tile * ROWS_PER_TILE + wave * 16 + c;
+    const int64_t rcl = rr < a.R ? rr : a.R - 1;
+    const int64_t ne = rcl / a.T;
+    const float* xr = a.x + ne * a.env_stride + (rcl - ne * a.T) * a.row_stride;
+#pragma unroll
+    for (int s = 0; s < MAXKPG; ++s) {
+      const int k = kpg * g + s;
+      dst[s] = xr[k < din ? k : din - 1];
+    }
+  };
+  float xn[MAXKPG];
+  if ((int64_t)blockIdx.x < ntiles) load_x(blockIdx.x, xn);
+
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * ROWS_PER_TILE;
     const int64_t r = row0 + wave * 16 + c;                   // this lane's batch row
     const bool rok = r < a.R;
     const int64_t rc = rok ? r : a.R - 1;
-    const int64_t n_env = rc / a.T;
-    const float* xrow = a.x + n_env * a.env_stride + (rc - n_env * a.T) * a.row_stride;
 
-    // ---- F1: X fragment, lane (c, g) holds X[r][kpg*g + s], s < kpg
+    // ---- F1: take the prefetched fragment, start the next tile's loads
     float xb[MAXKPG];
 #pragma unroll
     for (int s = 0; s < MAXKPG; ++s) {
       const int k = kpg * g + s;
-      xb[s] = (s < kpg && k < din && rok) ? xrow[k] : 0.f;
+      xb[s] = (s < kpg && k < din && rok) ? xn[s] : 0.f;
     }
-    // ---- F2: Y1^T = W1 X^T + b1  (A = W1 from LDS, B = X fragment)
+    {
+      const int64_t nt = tile + gridDim.x;
+      load_x(nt < ntiles ? nt : tile, xn);
+    }
+    // ---- F2: Y1^T = W1 X^T + b1  (A = W1 from LDS, B = X fragment).  Two row
+    // blocks at a time: v_mfma_f32_16x16x4_f32 issues every 32 cycles but a
+    // dependent accumulate needs 40, so every chain is paired with a second one.
     f32x4 h1[NB];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) {
+    for (int m = 0; m < NB; m += 2) {
       const float* bb1 = Bs + 16 * m + 4 * g;
-      f32x4 acc = {bb1[0], bb1[1], bb1[2], bb1[3]};
-      const float* wrow = W1s + (16 * m + c) * w1p + kpg * g;
+      f32x4 acc0 = {bb1[0], bb1[1], bb1[2], bb1[3]};
+      f32x4 acc1 = {bb1[16], bb1[17], bb1[18], bb1[19]};
+      const float* wr0 = W1s + (16 * m + c) * w1p + kpg * g;
+      const float* wr1 = wr0 + 16 * w1p;
 #pragma unroll
       for (int s = 0; s < MAXKPG; ++s)
-        if (s < kpg) acc = mfma(wrow[s], xb[s], acc);
+        if (s < kpg) {
+          acc0 = mfma(wr0[s], xb[s], acc0);
+          acc1 = mfma(wr1[s], xb[s], acc1);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = act_f<ACT>(acc[i]);
-      h1[m] = acc;
+      for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
+      h1[m] = acc0;
+      h1[m + 1] = acc1;
     }
     // ---- F4: Y2^T = W2 H1^T + b2  (B = H1 accumulators, k = 16 kb + 4 g + j)
     f32x4 h2[NB];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) {
+    for (int m = 0; m < NB; m += 2) {
       const float* bb2 = Bs + HID + 16 * m + 4 * g;
-      f32x4 acc = {bb2[0], bb2[1], bb2[2], bb2[3]};
-      const float* wrow = W2s + (16 * m + c) * W2P + 4 * g;
+      f32x4 acc0 = {bb2[0], bb2[1], bb2[2], bb2[3]};
+      f32x4 acc1 = {bb2[16], bb2[17], bb2[18], bb2[19]};
+      const float* wr0 = W2s + (16 * m + c) * W2P + 4 * g;
+      const float* wr1 = wr0 + 16 * W2P;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = mfma(wrow[16 * kb + j], h1[kb][j], acc);
+        for (int j = 0; j < 4; ++j) {
+          acc0 = mfma(wr0[16 * kb + j], h1[kb][j], acc0);
+          acc1 = mfma(wr1[16 * kb + j], h1[kb][j], acc1);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = act_f<ACT>(acc[i]);
-      h2[m] = acc;
+      for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
+      h2[m] = acc0;
+      h2[m + 1] = acc1;
     }
     // ---- F5: v = w3 . H2 + b3 (sum over the 4 lane groups of a column)
     float v = 0.f;
@@ -241,29 +275,43 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
         gW2[1][n] = mfma(a1, b, gW2[1][n]);
       }
     }
-    // ---- B2: dH1^T = W2^T dY2^T, dY1 = dH1 act'(H1)
+    // ---- B2: dH1^T = W2^T dY2^T, dY1 = dH1 act'(H1)   (two chains at a time)
     f32x4 d1[NB];
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      f32x4 acc = {0, 0, 0, 0};
+    for (int kb = 0; kb < NB; kb += 2) {
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
       for (int m = 0; m < NB; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc = mfma(W2s[(16 * m + 4 * g + j) * W2P + 16 * kb + c], h2[m][j], acc);
+        for (int j = 0; j < 4; ++j) {
+          const float* wr = W2s + (16 * m + 4 * g + j) * W2P + 16 * kb + c;
+          acc0 = mfma(wr[0], h2[m][j], acc0);
+          acc1 = mfma(wr[16], h2[m][j], acc1);
+        }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float d = acc[i] * act_d<ACT>(h1[kb][i]);
-        acc[i] = d;
-        gb1[kb][i] += d;
+        const float da = acc0[i] * act_d<ACT>(h1[kb][i]);
+        const float db = acc1[i] * act_d<ACT>(h1[kb + 1][i]);
+        acc0[i] = da;
+        acc1[i] = db;
+        gb1[kb][i] += da;
+        gb1[kb + 1][i] += db;
       }
-      d1[kb] = acc;
+      d1[kb] = acc0;
+      d1[kb + 1] = acc1;
     }
     __syncthreads();                       // all waves finished reading Tdy / Th1
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) tdy[(16 * m + 4 * g + i) * TP + c] = d1[m][i];
+    // X tile [64 rows][din] into the (now free) Th1 region for dW1's B operand
+    {
+      float* xs = Th1 + (wave * 16 + c) * XSP + kpg * g;
+#pragma unroll
+      for (int s = 0; s < MAXKPG; ++s)
+        if (s < kpg) xs[s] = xb[s];
+    }
     __syncthreads();
     // ---- dW1[h1][in] += sum_b dY1^T[h1][b] X[b][in]   (B straight from global / L1)
 #pragma unroll 2
@@ -273,16 +321,12 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
       const float* sd = Tdy + ws * HID * TP + cb;
       const float a0 = sd[(32 * wave + c) * TP];
       const float a1 = sd[(32 * wave + 16 + c) * TP];
-      const int64_t rb = row0 + 4 * t + g;                    // batch row of this k
-      const bool bok = rb < a.R;
-      const int64_t rbc = bok ? rb : a.R - 1;
-      const int64_t ne = rbc / a.T;
-      const float* xr = a.x + ne * a.env_stride + (rbc - ne * a.T) * a.row_stride;
+      const float* xr = Th1 + (4 * t + g) * XSP;              // X row of this k (zeros past R / din)
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
         if (16 * n < din) {                                   // uniform
           const int k = 16 * n + c;
-          const float b = (k < din && bok) ? xr[k] : 0.f;
+          const float b = k < 4 * kpg ? xr[k] : 0.f;
           gW1[0][n] = mfma(a0, b, gW1[0][n]);
           gW1[1][n] = mfma(a1, b, gW1[1][n]);
         }
