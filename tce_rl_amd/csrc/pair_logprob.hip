@@ -550,7 +550,6 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   const int K = dof * nbg;
   TCE_CHECK_ARG(K <= 64, "pair_logprob: dof * (num_basis + 1) must be <= 64");
   MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
-  (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
   hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)),
                      dim3(256), 0, stream, mp, times, t0, N, T, B, flag);
   TCE_LAUNCH_CHECK();

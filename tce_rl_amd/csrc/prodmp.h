@@ -147,7 +147,8 @@ __device__ inline real sampler_time_at(real t0, real off_first, real off_last, i
 }
 
 // Basis rows for the time grid of env 0 + "init times are not all equal" flag.
-// times_row: explicit [T] row (row 0 of the caller's times tensor).
+// times_row: explicit [T] row (row 0 of the caller's times tensor).  The flag
+// is written (not accumulated) by workgroup 0, so no memset is needed.
 template <typename real>
 __global__ __launch_bounds__(256) void prodmp_basis_kernel(
     MPParams<real> mp, const real* __restrict__ times_row,
@@ -160,9 +161,14 @@ __global__ __launch_bounds__(256) void prodmp_basis_kernel(
     prodmp_row(mp, times_row[i], t0, row);
     mp_row_store(row, mp.nbg, B + (int64_t)i * (4 + 2 * mp.nbg));
   }
-  bool bad = false;
-  for (int64_t n = blockIdx.x * 256ll + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256)
-    bad |= (init_time[n] != t0);
-  if (bad) atomicOr(nonuniform, 1);
+  if (blockIdx.x == 0) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int64_t n = threadIdx.x; n < N; n += 256) bad |= (init_time[n] != t0);
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) *nonuniform = s_bad;
+  }
 }
-

@@ -51,53 +51,86 @@ __device__ inline void store_vec(real* dst, const real* src) {
   *reinterpret_cast<vec*>(dst) = v;
 }
 
-template <typename real, int DOF>
+// NBG > 0: num_basis + 1 known at compile time (the loops over the basis
+// become straight-line FMAs with SGPR parameter operands); NBG == 0: runtime.
+// HALF (DOF == 4 only): a lane owns (t, pos | vel) and writes ONE 16-byte
+// chunk, so a wave store covers 1 KiB without gaps; otherwise a lane owns a
+// whole step and writes its 2*DOF values.
+template <typename real, int DOF, int NBG, bool HALF>
 __global__ __launch_bounds__(256) void prodmp_traj_kernel(
     const real* __restrict__ B, const int* __restrict__ nonuniform,
     MPParams<real> mp, const real* __restrict__ times, int times_general,
     const real* __restrict__ w, const real* __restrict__ t0,
     const real* __restrict__ y0, const real* __restrict__ v0,
     real* __restrict__ out, int64_t N, int T, int epb) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nbg = NBG > 0 ? NBG : mp.nbg;
+  constexpr int MAXB = NBG > 0 ? NBG : TCE_MAXB;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int t = HALF ? (i >> 1) : i;
+  const int h = HALF ? (i & 1) : 0;
   const int64_t n_begin = (int64_t)blockIdx.y * epb;
   const int64_t n_end = tmin<int64_t>(N, n_begin + epb);
-  const int nbg = mp.nbg;
   const bool general = times_general || (*nonuniform != 0);
   const int tc = t < T ? t : T - 1;
   real row[TCE_ROWLEN];
   if (!general) mp_row_load(B + (int64_t)tc * (4 + 2 * nbg), nbg, row);
+  // HALF: this lane's coefficients (c_y0, c_v0, H[b]) of pos (h=0) or vel (h=1)
+  real hr[2 + MAXB];
+  auto pick_half = [&]() {
+    hr[0] = h ? row[2] : row[0];
+    hr[1] = h ? row[3] : row[1];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) hr[2 + b] = h ? row[4 + TCE_MAXB + b] : row[4 + b];
+  };
+  if (HALF) pick_half();
   for (int64_t n = n_begin; n < n_end; ++n) {
-    if (general) prodmp_row(mp, times[n * T + tc], t0[n], row);
-    real o[2 * DOF];
-    const real* wn = w + n * (int64_t)(DOF * nbg);
-#pragma unroll
-    for (int d = 0; d < DOF; ++d) {
-      const real yd = y0[n * DOF + d], vd = v0[n * DOF + d];
-      real pos = row[0] * yd + row[1] * vd;
-      real vel = row[2] * yd + row[3] * vd;
-#pragma unroll
-      for (int b = 0; b < TCE_MAXB; ++b) {
-        if (b < nbg) {
-          const real th = wn[d * nbg + b];
-          pos += row[4 + b] * th;
-          vel += row[4 + TCE_MAXB + b] * th;
-        }
-      }
-      o[d] = pos;
-      o[DOF + d] = vel;
+    if (general) {
+      prodmp_row(mp, times[n * T + tc], t0[n], row);
+      if (HALF) pick_half();
     }
-    if (t < T) {
-      real* dst = out + (n * T + t) * (int64_t)(2 * DOF);
-      constexpr int C = 2 * DOF;
-      if (C % 4 == 0) {
+    const real* wn = w + n * (int64_t)(DOF * nbg);
+    if (HALF) {
+      real o[DOF];
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i) store_vec<real, 4>(dst + 4 * i, o + 4 * i);
-      } else if (C % 2 == 0) {
+      for (int d = 0; d < DOF; ++d) {
+        real acc = hr[0] * y0[n * DOF + d] + hr[1] * v0[n * DOF + d];
 #pragma unroll
-        for (int i = 0; i < C / 2; ++i) store_vec<real, 2>(dst + 2 * i, o + 2 * i);
-      } else {
+        for (int b = 0; b < MAXB; ++b)
+          if (b < nbg) acc += hr[2 + b] * wn[d * nbg + b];
+        o[d] = acc;
+      }
+      if (t < T) store_vec<real, DOF>(out + (n * T + t) * (int64_t)(2 * DOF) + DOF * h, o);
+    } else {
+      real o[2 * DOF];
 #pragma unroll
-        for (int i = 0; i < C; ++i) dst[i] = o[i];
+      for (int d = 0; d < DOF; ++d) {
+        const real yd = y0[n * DOF + d], vd = v0[n * DOF + d];
+        real pos = row[0] * yd + row[1] * vd;
+        real vel = row[2] * yd + row[3] * vd;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+          if (b < nbg) {
+            const real th = wn[d * nbg + b];
+            pos += row[4 + b] * th;
+            vel += row[4 + TCE_MAXB + b] * th;
+          }
+        }
+        o[d] = pos;
+        o[DOF + d] = vel;
+      }
+      if (t < T) {
+        real* dst = out + (n * T + t) * (int64_t)(2 * DOF);
+        constexpr int C = 2 * DOF;
+        if (C % 4 == 0) {
+#pragma unroll
+          for (int k = 0; k < C / 4; ++k) store_vec<real, 4>(dst + 4 * k, o + 4 * k);
+        } else if (C % 2 == 0) {
+#pragma unroll
+          for (int k = 0; k < C / 2; ++k) store_vec<real, 2>(dst + 2 * k, o + 2 * k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < C; ++k) dst[k] = o[k];
+        }
       }
     }
   }
@@ -115,29 +148,40 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
   TCE_CHECK_ARG(nbg >= 1 && nbg <= TCE_MAXB, "prodmp_traj: num_basis + 1 must be <= 16");
   TCE_CHECK_ARG(dof >= 1 && dof <= 8, "prodmp_traj: num_dof must be <= 8");
   MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
-  (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
   const int tb = (int)ceil_div(T, 256);
-  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3(tb), dim3(256), 0, stream, mp,
-                     times, t0, N, T, B, flag);
+  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0,
+                     stream, mp, times, t0, N, T, B, flag);
   TCE_LAUNCH_CHECK();
   // ~2048 workgroups: each keeps its basis rows for `epb` envs
-  int epb = (int)tmax<int64_t>(1, (N * tb) / 2048);
+  const bool half = (dof == 4);
+  const int txb = (int)ceil_div((int64_t)T * (half ? 2 : 1), 256);
+  int epb = (int)tmax<int64_t>(1, (N * txb) / 2048);
   const int64_t gy = ceil_div(N, epb);
   TCE_CHECK_ARG(gy <= 65535, "prodmp_traj: too many envs");
-  dim3 grid(tb, (unsigned)gy);
-#define TRAJ_GO(D)                                                              \
-  hipLaunchKernelGGL((prodmp_traj_kernel<real, D>), grid, dim3(256), 0, stream, \
-                     B, flag, mp, times, times_general, w, t0, y0, v0, out, N, T, epb)
-  switch (dof) {
-    case 1: TRAJ_GO(1); break;
-    case 2: TRAJ_GO(2); break;
-    case 3: TRAJ_GO(3); break;
-    case 4: TRAJ_GO(4); break;
-    case 5: TRAJ_GO(5); break;
-    case 6: TRAJ_GO(6); break;
-    case 7: TRAJ_GO(7); break;
-    default: TRAJ_GO(8); break;
+  dim3 grid(txb, (unsigned)gy);
+#define TRAJ_GO(D, NB, H)                                                         \
+  hipLaunchKernelGGL((prodmp_traj_kernel<real, D, NB, H>), grid, dim3(256), 0,    \
+                     stream, B, flag, mp, times, times_general, w, t0, y0, v0,    \
+                     out, N, T, epb)
+#define TRAJ_NB(D, H)                                                             \
+  switch (nbg) {                                                                  \
+    case 4: TRAJ_GO(D, 4, H); break;                                              \
+    case 5: TRAJ_GO(D, 5, H); break;                                              \
+    case 6: TRAJ_GO(D, 6, H); break;                                              \
+    case 9: TRAJ_GO(D, 9, H); break;                                              \
+    default: TRAJ_GO(D, 0, H); break;                                             \
   }
+  switch (dof) {
+    case 1: TRAJ_GO(1, 0, false); break;
+    case 2: TRAJ_GO(2, 0, false); break;
+    case 3: TRAJ_GO(3, 0, false); break;
+    case 4: TRAJ_NB(4, true); break;
+    case 5: TRAJ_GO(5, 0, false); break;
+    case 6: TRAJ_GO(6, 0, false); break;
+    case 7: TRAJ_NB(7, false); break;
+    default: TRAJ_GO(8, 0, false); break;
+  }
+#undef TRAJ_NB
 #undef TRAJ_GO
   TCE_LAUNCH_CHECK();
   return 0;

@@ -16,29 +16,56 @@ namespace {
 
 constexpr int RM_BT = 256;
 
-template <typename real>
+// V = elements per thread (4 when D % 4 == 0: 16-byte loads, else 1).
+template <typename real, int V>
 __global__ __launch_bounds__(RM_BT) void col_moments_kernel(
     const real* __restrict__ x, int64_t R, int D, const real* __restrict__ shift,
     double* __restrict__ partials /* [gridDim.x][D][2] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* s1 = reinterpret_cast<double*>(smem_raw);      // [rows_per_pass][D]
-  const int rpp = RM_BT / D;                              // row lanes per pass
+  typedef real vec __attribute__((ext_vector_type(V), aligned(V * sizeof(real))));
+  const int DV = D / V;                                   // column groups per row
+  const int rpp = RM_BT / DV;                             // row lanes per pass
+  double* s1 = reinterpret_cast<double*>(smem_raw);       // [rpp][D]
   double* s2 = s1 + rpp * D;
   const int tid = threadIdx.x;
-  const int rl = tid / D, c = tid - rl * D;
+  const int rl = tid / DV, cg = tid - rl * DV;
   const bool live = rl < rpp;
-  const double k = (live && shift) ? (double)shift[c] : 0.0;
-  double a1 = 0, a2 = 0;
+  double k[V], a1[V], a2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    k[i] = (live && shift) ? (double)shift[cg * V + i] : 0.0;
+    a1[i] = 0;
+    a2[i] = 0;
+  }
   if (live) {
     const int64_t per = (R + gridDim.x - 1) / gridDim.x;
     const int64_t lo = blockIdx.x * per, hi = tmin<int64_t>(R, lo + per);
-    for (int64_t r = lo + rl; r < hi; r += rpp) {
-      const double v = (double)x[r * D + c] - k;
-      a1 += v;
-      a2 += v * v;
+    int64_t r = lo + rl;
+    // 4 rows in flight per thread (independent loads, clamped addresses)
+    for (; r < hi; r += 4 * rpp) {
+      vec v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t rr = tmin<int64_t>(r + u * rpp, hi - 1);
+        v[u] = *reinterpret_cast<const vec*>(x + rr * D + cg * V);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * rpp < hi) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const double d = (double)v[u][i] - k[i];
+            a1[i] += d;
+            a2[i] += d * d;
+          }
+        }
+      }
     }
-    s1[rl * D + c] = a1;
-    s2[rl * D + c] = a2;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      s1[rl * D + cg * V + i] = a1[i];
+      s2[rl * D + cg * V + i] = a2[i];
+    }
   }
   __syncthreads();
   if (tid < D) {
@@ -48,25 +75,30 @@ __global__ __launch_bounds__(RM_BT) void col_moments_kernel(
     partials[((int64_t)blockIdx.x * D + tid) * 2 + 1] = t2;
   }
 }
+template <typename real>
+__device__ inline real vec_get(real v, int) { return v; }
 
-// mean/var [D] (running, updated in place), count/batch_count from the host.
+// One workgroup per column: sum the partials, then merge into the running
+// statistics (update_from_moments, util_numerical.py:321-337).
 template <typename real>
 __global__ __launch_bounds__(256) void rms_finalize_kernel(
     const double* __restrict__ partials, int nparts, int D,
     const real* shift /* may alias mean */, double batch_count, double count,
     real* mean, real* var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= D) return;
+  __shared__ double red[4];
+  const int c = blockIdx.x;
   double t1 = 0, t2 = 0;
-  for (int i = 0; i < nparts; ++i) {
+  for (int i = threadIdx.x; i < nparts; i += 256) {
     t1 += partials[((int64_t)i * D + c) * 2 + 0];
     t2 += partials[((int64_t)i * D + c) * 2 + 1];
   }
+  t1 = block_sum(t1, red);
+  t2 = block_sum(t2, red);
+  if (threadIdx.x != 0) return;
   const double k = shift ? (double)shift[c] : 0.0;
   const double n = batch_count;
   const double b_mean = k + t1 / n;
   const double b_var = n > 1 ? (t2 - t1 * t1 / n) / (n - 1.0) : (double)NAN;  // unbiased
-  // update_from_moments (util_numerical.py:321-337)
   const double m = (double)mean[c], v = (double)var[c];
   const double delta = b_mean - m;
   const double tot = count + n;
@@ -124,15 +156,22 @@ int64_t tce_rms_num_partials(void) { return TCE_RMS_BLOCKS; }
                            double count, double* partials_ws, void* stream) {      \
     TCE_CHECK_ARG(x && mean && var && partials_ws && R > 0 && D > 0 && D <= 256,   \
                   "rms_update: bad arguments (D <= 256)");                         \
-    const int rpp = RM_BT / D;                                                     \
+    /* the running mean is the shift of the one-pass sums; it must not change   \
+       while the partial kernel reads it: finalize runs after it on the stream */ \
+    const bool v4 = (D % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);    \
+    const int rpp = RM_BT / (v4 ? D / 4 : D);                                      \
     const size_t lds = 2 * (size_t)rpp * D * sizeof(double);                       \
     const int nb = (int)tmin<int64_t>(TCE_RMS_BLOCKS, ceil_div(R, rpp));           \
-    hipLaunchKernelGGL(col_moments_kernel<REAL>, dim3(nb), dim3(RM_BT), lds,       \
-                       (hipStream_t)stream, x, R, D, mean, partials_ws);           \
+    if (v4)                                                                        \
+      hipLaunchKernelGGL((col_moments_kernel<REAL, 4>), dim3(nb), dim3(RM_BT),     \
+                         lds, (hipStream_t)stream, x, R, D, mean, partials_ws);    \
+    else                                                                           \
+      hipLaunchKernelGGL((col_moments_kernel<REAL, 1>), dim3(nb), dim3(RM_BT),     \
+                         lds, (hipStream_t)stream, x, R, D, mean, partials_ws);    \
     TCE_LAUNCH_CHECK();                                                            \
-    hipLaunchKernelGGL(rms_finalize_kernel<REAL>, dim3((unsigned)ceil_div(D, 256)), \
-                       dim3(256), 0, (hipStream_t)stream, partials_ws, nb, D,      \
-                       mean, (double)R, count, mean, var);                         \
+    hipLaunchKernelGGL(rms_finalize_kernel<REAL>, dim3(D), dim3(256), 0,           \
+                       (hipStream_t)stream, partials_ws, nb, D, mean, (double)R,   \
+                       count, mean, var);                                          \
     TCE_LAUNCH_CHECK();                                                            \
     return 0;                                                                      \
   }                                                                                \
