@@ -61,6 +61,17 @@ def kernel_time_us(fn, launches=20):
     return best
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes
+    (profiles/r01_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2
+    correction); None if the file is absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline(agent):
     """Rooflines measured live with HIP events on the launch stream.
 
@@ -87,7 +98,8 @@ def roofline(agent):
               "bound": "mfma", "achieved": round(flops / us_c / 1e6, 2),
               "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
               "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4),
-              "traffic": None, "us_per_launch": round(us_c, 1),
+              "traffic": pmc_traffic("mlp_critic_kernel"),
+              "us_per_launch": round(us_c, 1),
               "algorithmic_flops": flops, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     del full, xs
     r = torch.randn(N, T, device="cuda", generator=g)
@@ -100,8 +112,8 @@ def roofline(agent):
     gae = {"kernel": "gae_dpp_kernel<float,true,true,8>", "bound": "hbm",
            "achieved": round(alg / us / 1e3, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
-           "traffic": None, "us_per_launch": round(us, 2),
-           "algorithmic_bytes": alg}
+           "traffic": pmc_traffic("gae_dpp_kernel"),
+           "us_per_launch": round(us, 2), "algorithmic_bytes": alg}
     # trajectory generator (write-bound): T*2*dof*4 B written per env
     mp = agent.policy.mp
     K = mp.num_dof * mp.num_basis_g
@@ -116,6 +128,7 @@ def roofline(agent):
         "bound": "hbm", "achieved": round(alg2 / us2 / 1e3, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
+        "traffic": pmc_traffic("prodmp_traj_kernel"),
         "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
         "note": "basis-table kernel + trajectory kernel"}}
     extra["gae_scan"] = gae
