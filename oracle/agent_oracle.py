@@ -55,6 +55,9 @@ class OracleTCE:
         self.initial_entropy = None
         self.it = 0
         self.gen = torch.Generator().manual_seed(seed)
+        self.forced_reset = None      # (goal, init_pos) injected by tests
+        self.forced_eps = None        # parameter noise injected by tests
+        self.last = {}                # rollout tensors of the last step
 
     def _mlp(self, net, x, act):
         ps = list(net)
@@ -69,8 +72,11 @@ class OracleTCE:
 
     def _reset(self):
         r = lambda *s: torch.rand(*s, generator=self.gen, dtype=self.dtype)
-        self.goal = r(self.N, self.dof) * 2 - 1
-        pos = 0.1 * (r(self.N, self.dof) * 2 - 1)
+        if self.forced_reset is not None:           # tests: same env state
+            self.goal, pos = self.forced_reset
+        else:
+            self.goal = r(self.N, self.dof) * 2 - 1
+            pos = 0.1 * (r(self.N, self.dof) * 2 - 1)
         task = torch.zeros(self.N, self.d_task, dtype=self.dtype)
         task[:, :self.dof] = self.goal
         task[:, self.dof:2 * self.dof] = pos
@@ -90,7 +96,8 @@ class OracleTCE:
             y0, v0 = s0[:, -D2:-self.dof], s0[:, -self.dof:]
             mean_old, L_old = self._policy(s0[:, :-D2])
             times = O.get_times(t0, self.dt, T)
-            eps = torch.randn(N, self.K, generator=self.gen, dtype=self.dtype)
+            eps = torch.randn(N, self.K, generator=self.gen, dtype=self.dtype) \
+                if self.forced_eps is None else self.forced_eps
             pos, vel = self.mp.sample_trajectories(times, mean_old, L_old, t0,
                                                    y0, v0, eps)
             actions = torch.cat([pos, vel], -1)
@@ -118,6 +125,11 @@ class OracleTCE:
                 a["segment_advantage"], rewards, values, adv, pairs,
                 a["discount_factor"], a["norm_advantages"],
                 a["clip_advantages"])
+        self.last = dict(step_actions=actions, segment_log_prob_estimate=lp_old,
+                         step_values=values, step_rewards=rewards,
+                         step_advantages=adv, step_returns=ret,
+                         segment_advantage=seg_adv, pred_pairs=pairs,
+                         segment_params_mean=mean_old, step_states=nstates)
         # ---- critic epochs (full batch, num_minibatchs = 1)
         cs = nstates[:, :-1, :-D2].reshape(N * T, -1)
         cr, cv = ret.reshape(-1), values[:, :-1].reshape(-1)

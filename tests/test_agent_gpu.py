@@ -1,0 +1,182 @@
+"""End-to-end parity of one agent.step(): the MI355X engine against the CPU
+oracle of the reference path, on identical weights, env state, pair indices and
+parameter noise (BASELINE configs[0]-like shape: few envs, T = 500)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(num_env, epochs, overlap):
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    cfg = tce_config("metaworld", num_env=num_env, num_basis=5, epochs=epochs,
+                     evaluation_interval=0)
+    cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    return exp.agent, cfg
+
+
+def to_cpu_params(net):
+    return [p.detach().cpu().clone() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_agent_step_matches_cpu_oracle(overlap):
+    from oracle.agent_oracle import OracleTCE
+    N, EPOCHS = 16, 3
+    agent, cfg = build(N, EPOCHS, overlap)
+    oracle = OracleTCE(cfg["params"], N)
+    # identical weights
+    with torch.no_grad():
+        for po, pg in zip(oracle.pnet, agent.policy.mean_net.parameters()):
+            po.copy_(pg.cpu())
+        for po, pg in zip(oracle.cnet, agent.critic.net.parameters()):
+            po.copy_(pg.cpu())
+        oracle.var.copy_(agent.policy.variance_net.variable.cpu())
+    # identical env state and noise
+    g = torch.Generator().manual_seed(7)
+    goal = torch.rand(N, 4, generator=g) * 2 - 1
+    pos0 = 0.1 * (torch.rand(N, 4, generator=g) * 2 - 1)
+    eps = torch.randn(N, 24, generator=g)
+    env = agent.sampler.train_envs
+
+    def reset():
+        env.goal = goal.cuda()
+        z = torch.zeros(N, 4, device="cuda")
+        return env._obs(torch.zeros(N, device="cuda"), pos0.cuda(), z)
+    env.reset = reset
+    orig_sample = agent.policy.sample
+    agent.policy.sample = lambda **kw: orig_sample(**kw, eps=eps.cuda())
+    oracle.forced_reset = (goal, pos0)
+    oracle.forced_eps = eps
+
+    captured = {}
+    orig_pd = agent.process_dataset
+
+    def pd(ds):
+        out = orig_pd(ds)
+        captured.update({k: v.detach().cpu() for k, v in out.items()
+                         if torch.is_tensor(v) and k != "segment_params_L"})
+        return out
+    agent.process_dataset = pd
+
+    torch.manual_seed(11)           # pair offset: same host draw on both sides
+    res = agent.step()
+    torch.manual_seed(11)
+    oracle.step()
+    ref = oracle.last
+    assert np.array_equal(agent.sampler.pred_pairs.cpu().numpy(),
+                          ref["pred_pairs"].numpy())           # bit-exact indexing
+    tol = dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(captured["step_actions"], ref["step_actions"],
+                               rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(captured["step_rewards"], ref["step_rewards"],
+                               rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(captured["step_values"], ref["step_values"],
+                               **tol)
+    torch.testing.assert_close(captured["step_returns"], ref["step_returns"],
+                               rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(captured["step_advantages"],
+                               ref["step_advantages"], rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(captured["segment_advantage"],
+                               ref["segment_advantage"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(captured["segment_log_prob_estimate"],
+                               ref["segment_log_prob_estimate"], rtol=5e-4,
+                               atol=5e-3)
+    # parameters after EPOCHS critic + policy updates
+    for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
+        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=2e-3,
+                                   atol=2e-5)
+    for pg, po in zip(agent.policy.mean_net.parameters(), oracle.pnet):
+        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=5e-3,
+                                   atol=5e-5)
+    torch.testing.assert_close(agent.policy.variance_net.variable.detach().cpu(),
+                               oracle.var.detach(), rtol=5e-3, atol=5e-5)
+    assert np.isfinite(res["critic_loss_mean"])
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """save_agent / load_agent (reference file naming and formats)."""
+    agent, _ = build(8, 1, False)
+    agent.step()
+    agent.save_agent(str(tmp_path), 1)
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert "ValueFunction_mlp_parameters.pkl" in names
+    assert "ValueFunction_mlp_weights_1" in names
+    assert "TemporalCorrelatedPolicy_mean_mlp_weights_1" in names
+    assert "TemporalCorrelatedPolicy_variance_variable_weights_1" in names
+    assert "policy_optimizer_state_1" in names and "obs_rms_state_1" in names
+    before = [p.detach().clone() for p in agent.policy.parameters]
+    agent2, _ = build(8, 1, False)
+    agent2.load_agent(str(tmp_path), 1)
+    for a, b in zip(before, agent2.policy.parameters):
+        assert torch.equal(a, b.detach())
+    assert agent2.num_iterations == 1
+    torch.testing.assert_close(agent2.sampler.obs_rms.mean,
+                               agent.sampler.obs_rms.mean)
+
+
+@pytest.mark.parametrize("env", ["box_push", "table_tennis"])
+def test_other_tce_configs_step(env):
+    """BASELINE configs[2] / [4] shapes at reduced env count: dof 7, K 63 / 28,
+    leaky_relu / tanh nets (library-GEMM critic path), MDP reward re-shaping."""
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    nb = 8 if env == "box_push" else 3
+    cfg = tce_config(env, num_env=96, num_basis=nb, epochs=2,
+                     evaluation_interval=1, num_env_test=16)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    for i in range(2):
+        res = exp.iterate(cfg, 0, i)
+    for k in ("critic_loss_mean", "surrogate_loss_mean", "entropy_mean",
+              "projection_proj_old_cov_diff_mean",
+              "evaluation_episode_reward_mean"):
+        assert np.isfinite(res[k]), k
+    assert res["projection_proj_old_cov_diff_mean"] <= \
+        cfg["params"]["projection"]["args"]["cov_bound"] * 1.01
+
+
+def test_bbrl_agent_step():
+    """BASELINE configs[3]-like: black-box agent, diagonal covariance, K 20."""
+    from tce_rl_amd.rl import (agent_factory, critic_factory, policy_factory,
+                               projection_factory, sampler_factory)
+    mp = {"type": "prodmp", "args": dict(
+        num_dof=4, num_basis=4, tau=5.0, alpha_phase=3, alpha=10, dt=0.0125,
+        basis_bandwidth_factor=5, weights_scale=0.1, goal_scale=0.1,
+        relative_goal=True, dtype="float32", device="cuda")}
+    sampler = sampler_factory("BlackBoxSampler",
+                              env_id="metaworld_ProDMP/push-v2",
+                              num_env_train=256, num_env_test=16,
+                              dtype="float32", device="cuda", seed=0, mp=mp,
+                              task_specified_metrics=["success"])
+    d_in = sampler.observation_shape[-1]
+    common = dict(init_method="orthogonal", act_func_hidden="relu",
+                  act_func_last=None, dtype="float32", device="cuda")
+    policy = policy_factory(
+        "BlackBoxPolicy", dim_in=d_in, dim_out=20,
+        mean_net_args=dict(avg_neuron=32, num_hidden=2, shape=0.0),
+        variance_net_args=dict(std_only=True, contextual=False),
+        out_layer_gain=0.01, min_std=1e-5, **common)
+    critic = critic_factory("ValueFunction", dim_in=d_in, dim_out=1,
+                            hidden=dict(avg_neuron=32, num_hidden=2, shape=0.0),
+                            out_layer_gain=1, **common)
+    proj = projection_factory(
+        "KLProjectionLayer", proj_type="kl", mean_bound=0.005,
+        cov_bound=0.0005, trust_region_coeff=1.0, entropy_schedule=False,
+        action_dim=20, total_train_steps=100, dtype="float32", device="cuda")
+    agent = agent_factory(
+        "BlackBoxAgent", policy=policy, critic=critic, sampler=sampler,
+        projection=proj, lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0,
+        wd_critic=0.0, discount_factor=1, epochs_policy=3, epochs_critic=3,
+        num_minibatchs=1, norm_advantages=True, clip_advantages=0.0,
+        set_variance=True, balance_check=25, evaluation_interval=1,
+        dtype="float32", device="cuda")
+    for _ in range(2):
+        res = agent.step()
+    assert np.isfinite(res["critic_loss_mean"])
+    assert np.isfinite(res["projection_kl"])
+    assert res["num_global_steps"] == 2 * 256 * 500
