@@ -260,7 +260,7 @@ int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, i
  * mprl/util/util_nn.py:225-246; value_loss + backward of one critic epoch,
  * mprl/rl/agent/temporal_correlated_agent.py:343-366,688-716) over R rows.
  * Row r = (n, t) lives at x + n*env_stride + t*row_stride (t < T, the first
- * D_in <= 48 features are used), so the critic reads the rollout buffer in
+ * D_in <= 40 features are used), so the critic reads the rollout buffer in
  * place.  Weights in torch.nn.Linear layout [out][in].  act: 0 tanh, 1 relu,
  * 2 leaky_relu(0.01), 3 softplus.  clip > 0: PPO-style clipped value loss with
  * old_values.  values (nullable) [R]; partials float

@@ -14,7 +14,7 @@ _ACT = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
 def supported(mlp):
     return (mlp.dtype == torch.float32 and mlp.dim_out == 1
             and list(mlp.hidden_layers) == [128, 128]
-            and 1 <= mlp.dim_in <= 48 and mlp.act_func_last_type is None
+            and 1 <= mlp.dim_in <= 40 and mlp.act_func_last_type is None
             and mlp.act_func_hidden_type in _ACT)
 
 

@@ -35,8 +35,9 @@ def torch_ref(mlp, x, ret, old, clip, dtype):
 
 
 @pytest.mark.parametrize("act", ["relu", "tanh", "leaky_relu", "softplus"])
-@pytest.mark.parametrize("din,N,T", [(40, 7, 33), (21, 5, 64), (48, 3, 1),
-                                     (17, 130, 10)])
+@pytest.mark.parametrize("din,N,T", [(40, 7, 33), (21, 5, 64), (32, 3, 1),
+                                     (17, 130, 10), (24, 9, 21), (25, 4, 70),
+                                     (16, 3, 40), (1, 6, 11)])
 def test_fused_critic_epoch_vs_torch(act, din, N, T):
     from tce_rl_amd import critic_ops
     mlp = make(din, act, 0)
