@@ -254,6 +254,25 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- optimizer: flat Adam with global-norm clipping -----------------------
+ * One optimizer step over a flat parameter buffer of n elements:
+ *   grad_norm_clip(clip, params)   mprl/util/util_numerical.py:244-275
+ *     (coef = min(1, clip / (|g| + 1e-6)) as torch.nn.utils.clip_grad_norm_;
+ *      clip <= 0: norms only)
+ *   torch.optim.Adam(lr, betas, eps, weight_decay).step()   -- L2-in-gradient
+ *     weight decay, mprl/rl/agent/abstract_agent.py:62-82; used at
+ *     temporal_correlated_agent.py:361-366,597-612, black_box_agent.py:160-166,330-339.
+ * state: 4 elements on the device = {step count (incremented by the call),
+ *   |g| before clipping, |g| after, clip factor}.  sumsq_in (nullable): |g|^2
+ *   already reduced by the producer (tce_mlp_critic_f32 stats[1]).
+ */
+int tce_adam_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                      float* state, const float* sumsq_in, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float clip, void* stream);
+int tce_adam_flat_f64(double* param, const double* grad, double* m, double* v, int64_t n,
+                      double* state, const double* sumsq_in, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, double clip, void* stream);
+
 /* ---- fused critic MLP epoch (exact-fp32 MFMA) ----------------------------
  * Forward (+ value loss + backward when `partials` != NULL) of the value
  * network D_in -> 128 -> 128 -> 1 (ValueFunction.critic ->
@@ -265,7 +284,12 @@ int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, i
  * 2 leaky_relu(0.01), 3 softplus.  clip > 0: PPO-style clipped value loss with
  * old_values.  values (nullable) [R]; partials float
  * [tce_mlp_critic_grid(), num_params + 2]; grad float [num_params] in the order
- * W1, b1, W2, b2, w3, b3; stats float[2] = {mean loss, |grad|^2}.
+ * W1, b1, W2, b2, w3, b3; stats float[2] = {mean loss, |grad|^2}, zeroed by the
+ * caller ([1] accumulates).  adam_param != NULL: the Adam step of the critic
+ * optimizer (torch.optim.Adam with L2 weight decay, abstract_agent.py:62-82;
+ * temporal_correlated_agent.py:361-366) on the flat buffers adam_param / adam_m /
+ * adam_v [num_params] is fused into the gradient reduction (no clipping;
+ * adam_step = step count including this update, stored to adam_state[0]).
  * max_workgroups (0 = one per CU): persistent workgroups to launch; fewer than
  * the CU count leaves CUs free for kernels of another stream (the policy
  * update runs beside the critic epochs).
@@ -278,7 +302,9 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        const float* w2, const float* b2, const float* w3, const float* b3,
                        int act, const float* returns, const float* old_values, float clip,
                        float* values, float* partials, float* grad, float* stats,
-                       int max_workgroups, void* stream);
+                       int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                       float* adam_state, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float adam_step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tce_rl_amd.config import tce_config
 from tce_rl_amd.mp_exp import MPExperiment
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-for wg in (0, 208, 224, 240, 248):
+for wg in [int(a) for a in sys.argv[2:]] or (0, 208, 224, 240, 248):
     cfg = tce_config("metaworld", num_env=4096, epochs=50, num_basis=nb)
     a = cfg["params"]["agent"]["args"]
     a["overlap_updates"] = wg != 0

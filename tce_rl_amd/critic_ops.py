@@ -43,7 +43,8 @@ def forward(mlp, x):
     out = torch.empty(R, dtype=torch.float32, device=x.device)
     call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, mlp.dim_in,
          *_weights(mlp), _ACT[mlp.act_func_hidden_type], None, None, 0.0,
-         ptr(out), None, None, None, 0, stream())
+         ptr(out), None, None, None, 0, None, None, None, None, 0.0, 0.0, 0.0,
+         0.0, 0.0, 0.0, stream())
     return out.reshape(*x.shape[:-1], 1)
 
 
@@ -51,13 +52,18 @@ class EpochRunner:
     """Holds the flat gradient buffer (p.grad are views of it) and the
     per-workgroup partial slabs for repeated critic epochs."""
 
-    def __init__(self, mlp):
+    def __init__(self, mlp, flat=None):
+        """flat: gradient buffer to fill (the optimizer's flat gradient, in
+        parameter order W1, b1, W2, b2, w3, b3); allocated if omitted."""
         assert supported(mlp)
         self.mlp = mlp
         lib = _lib.load()
         self.P = lib.tce_mlp_critic_num_params(mlp.dim_in)
         dev = mlp.layers[0].weight.device
-        self.flat = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        if flat is None:
+            flat = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        assert flat.numel() == self.P and flat.dtype == torch.float32
+        self.flat = flat
         self.partials = torch.empty(lib.tce_mlp_critic_grid(), self.P + 2,
                                     dtype=torch.float32, device=dev)
         off = 0
@@ -68,21 +74,34 @@ class EpochRunner:
             off += p.numel()
         assert off == self.P
 
-    def epoch(self, states, returns, old_values, clip, max_workgroups=0):
+    def epoch(self, states, returns, old_values, clip, max_workgroups=0,
+              stats=None, adam=None):
         """One full-batch forward + loss + backward; leaves the gradient in
         p.grad (views of the flat buffer) and returns stats = {mean loss,
-        |grad|^2} as a device tensor [2]."""
+        |grad|^2} as a device tensor [2] (``stats``: a ZEROED float32[2] to
+        fill instead of a fresh one).  adam: a FlatAdam over the same
+        parameters whose step (without clipping) is fused into the launch."""
         xs, es, rs, T, R = _rows(states)
         ret = returns.reshape(-1)
         ret = ret if ret.is_contiguous() else ret.contiguous()
         old = None
         if clip > 0:
             old = old_values.reshape(-1).contiguous()
-        stats = torch.empty(2, dtype=torch.float32, device=self.flat.device)
+        if stats is None:
+            stats = torch.zeros(2, dtype=torch.float32, device=self.flat.device)
+        if adam is not None:
+            g = adam.param_groups[0]
+            adam.host_step += 1
+            ad = (ptr(adam.flat_param), ptr(adam.m), ptr(adam.v),
+                  ptr(adam.dev_state), float(g["lr"]), float(g["betas"][0]),
+                  float(g["betas"][1]), float(g["eps"]),
+                  float(g["weight_decay"]), float(adam.host_step))
+        else:
+            ad = (None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
         call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, self.mlp.dim_in,
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
-             ptr(self.flat), ptr(stats), int(max_workgroups), stream())
+             ptr(self.flat), ptr(stats), int(max_workgroups), *ad, stream())
         for p, v in zip(self.params, self.views):
             p.grad = v
         return stats

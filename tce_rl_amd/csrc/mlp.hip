@@ -469,21 +469,59 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
   }
 }
 
-// grad[p] = sum over workgroups; out_stats[0] = mean loss, [1] = |grad|^2
-__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials,
+// Optional Adam step fused into the slab reduction (no clipping: the clip factor
+// needs the global norm first; then the caller runs tce_adam_flat instead).
+struct AdamArgs {
+  float *param, *m, *v, *state;          // param == nullptr: gradient only
+  float lr, b1, b2, eps, wd, step;       // step = count INCLUDING this update
+};
+
+// grad[p] = sum over the workgroup slabs (fixed order: 4 interleaved groups of
+// slabs, then the groups); stats[0] = mean loss, stats[1] += |grad|^2 (the caller
+// zeroes stats); with ad.param the Adam update of torch.optim.Adam (L2 weight
+// decay in the gradient, mprl/rl/agent/abstract_agent.py:62-82) is applied in
+// the same pass.
+__global__ __launch_bounds__(256) void mlp_finish_kernel(const float* __restrict__ partials,
                                                          int nparts, int P, int64_t R,
                                                          float* __restrict__ grad,
-                                                         float* __restrict__ stats) {
+                                                         float* __restrict__ stats, AdamArgs ad) {
+  __shared__ float part[4][64];
   __shared__ float red[4];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (p < P + 1) {
+    const float* src = partials + p;
+#pragma unroll 8
+    for (int i = grp; i < nparts; i += 4) s += src[(int64_t)i * (P + 2)];
+  }
+  part[grp][col] = s;
+  __syncthreads();
   float sq = 0.f;
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < P + 1; p += gridDim.x * 256) {
-    float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += partials[(int64_t)i * (P + 2) + p];
-    if (p < P) { grad[p] = s; sq += s * s; }
-    else stats[0] = s / (float)R;                              // mean loss
+  if (grp == 0 && p < P + 1) {
+    const float g0 = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    if (p < P) {
+      grad[p] = g0;
+      sq = g0 * g0;
+      if (ad.param) {
+        const float w = ad.param[p];
+        const float g = ad.wd != 0.f ? g0 + ad.wd * w : g0;
+        const float mi = ad.b1 * ad.m[p] + (1.f - ad.b1) * g;
+        const float vi = ad.b2 * ad.v[p] + (1.f - ad.b2) * g * g;
+        ad.m[p] = mi;
+        ad.v[p] = vi;
+        const float bc1 = 1.f - powf(ad.b1, ad.step), bc2s = sqrtf(1.f - powf(ad.b2, ad.step));
+        ad.param[p] = w - (ad.lr / bc1) * mi / (sqrtf(vi) / bc2s + ad.eps);
+      }
+    } else {
+      stats[0] = g0 / (float)R;                                // mean loss
+    }
   }
   const float tot = block_sum(sq, red);
-  if (threadIdx.x == 0) atomicAdd(&stats[1], tot);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[1], tot);
+    if (ad.param && blockIdx.x == 0) ad.state[0] = ad.step;
+  }
 }
 
 template <int KPGE>
@@ -522,13 +560,18 @@ int64_t tce_mlp_critic_num_params(int din) { return mlp_num_params(din); }
 // value network over R rows.  act: 0 tanh, 1 relu, 2 leaky_relu, 3 softplus.
 // partials: float [tce_mlp_critic_grid()][num_params + 2]; grad: float
 // [num_params] in the order W1, b1, W2, b2, w3, b3 (torch Linear layouts);
-// stats: float[2] = {mean loss, |grad|^2} (zeroed by the call).
+// stats: float[2] = {mean loss, |grad|^2}, ZEROED BY THE CALLER ([1] accumulates).
+// adam_param != NULL: Adam step on (adam_param, adam_m, adam_v) [num_params]
+// fused into the gradient reduction (no clipping), adam_step = step count
+// including this update, written to adam_state[0].
 int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
                        int64_t R, int din, const float* w1, const float* b1,
                        const float* w2, const float* b2, const float* w3, const float* b3,
                        int act, const float* returns, const float* old_values, float clip,
                        float* values, float* partials, float* grad, float* stats,
-                       int max_workgroups, void* stream) {
+                       int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                       float* adam_state, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float adam_step, void* stream) {
   TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && R > 0 && T > 0,
                 "mlp_critic: null buffer / bad sizes");
   TCE_CHECK_ARG(din >= 1 && din <= MAX_DIN, "mlp_critic: 1 <= D_in <= 40");
@@ -537,6 +580,8 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_CHECK_ARG(!bwd || (returns && grad && stats), "mlp_critic: backward buffers missing");
   TCE_CHECK_ARG(bwd || values, "mlp_critic: nothing to compute");
   TCE_CHECK_ARG(!(bwd && clip > 0.f && !old_values), "mlp_critic: old values missing");
+  TCE_CHECK_ARG(!adam_param || (bwd && adam_m && adam_v && adam_state && adam_step >= 1.f),
+                "mlp_critic: fused Adam needs the backward pass and its state buffers");
   MlpArgs a{x, env_stride, row_stride, T, R, din, w1, b1, w2, b2, w3, b3,
             returns, old_values, clip, values, partials};
   hipStream_t st = (hipStream_t)stream;
@@ -553,9 +598,10 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_LAUNCH_CHECK();
   if (bwd) {
     const int P = mlp_num_params(din);
-    (void)hipMemsetAsync(stats, 0, 2 * sizeof(float), st);
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)ceil_div(P + 1, 256)), dim3(256), 0,
-                       st, partials, grid, P, R, grad, stats);
+    AdamArgs ad{adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps, weight_decay,
+                adam_step};
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)), dim3(256), 0,
+                       st, partials, grid, P, R, grad, stats, ad);
     TCE_LAUNCH_CHECK();
   }
   return 0;

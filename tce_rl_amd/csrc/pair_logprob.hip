@@ -256,7 +256,7 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
 // shipped TCE config): M = H_p L, C, its Cholesky factor and inverse depend on
 // the pair only, not on the env.
 //   pair_prep   (1 block / pair) : M_p, Linv_p, Cinv_p, logdet_p -> workspace
-//   pair_env    (1 thread / env) : d, z = Linv d, logp; bwd: alpha = Linv^T z,
+//   pair_env    (lane = env, wave = pair subset): d, z = Linv d, logp; bwd: alpha = Linv^T z,
 //                                  dmean, per-block partials of
 //                                  S_p = sum_n g alpha alpha^T and sum_n g
 //   pair_final  (1 block)        : dL = sum_p H_p^T (S_p - sg_p Cinv_p) M_p
@@ -350,13 +350,18 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
   }
 }
 
+// Block = EB (<= 64) envs x 4 waves; wave q takes the pairs q, q + 4, ...; lane
+// = env.  The per-pair reduction S_p over the block's envs runs inside the
+// wave (alpha goes through a wave-private LDS slab, no block barrier), the
+// pair-sum of dmean over the 4 waves through LDS at the end.
 template <typename real, bool BWD>
 __global__ __launch_bounds__(256) void pair_env_kernel(
     const real* __restrict__ traj, const real* __restrict__ mean,
     const int64_t* __restrict__ pairs, const int* __restrict__ nonuniform,
     const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
     real* __restrict__ logp, const real* __restrict__ gout, real* __restrict__ gmean,
-    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, PFShape s) {
+    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, PFShape s,
+    int EB) {
   if (*nonuniform != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
@@ -365,97 +370,121 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
   const int wsp = pf_ws_pair(s);
   real* Ws = smem;                               // [P][2 nbg + 4 + R*R + 1] compact
   const int cw = 2 * nbg + 4 + R * R + 1;
-  const int EB = blockDim.x;                     // envs per block (LDS budget)
-  real* ms = Ws + P * cw;                        // [EB][KP]   mean_n
-  real* gm = ms + EB * KP;                       // [EB][KP]   grad mean (BWD)
-  real* Ab = gm + (BWD ? EB * KP : 0);           // [EB][RP]   alpha of the current pair
-  real* gs = Ab + (BWD ? EB * RP : 0);           // [EB]
-  const int tid = threadIdx.x;
-  const int64_t n = (int64_t)blockIdx.x * EB + tid;
-  const bool ok = n < N;
-  const int64_t nc = ok ? n : N - 1;
-  for (int e = tid; e < P * cw; e += EB) {
-    const int p = e / cw, i = e - p * cw;
+  real* ms = Ws + P * cw;                        // [EB][KP]      mean_n
+  real* gmp = ms + EB * KP;                      // [4][EB][KP]   grad mean per wave (BWD)
+  real* Ab = gmp + (BWD ? 4 * EB * KP : 0);      // [4][EB][RP]   alpha of the wave's current pair
+  real* gs = Ab + (BWD ? 4 * EB * RP : 0);       // [4][EB]
+  const int tid = threadIdx.x, q = tid >> 6, e = tid & 63;
+  const int64_t n0 = (int64_t)blockIdx.x * EB;
+  const int64_t n = n0 + e;
+  const bool act = e < EB;
+  const bool ok = act && n < N;
+  const int64_t nc = n < N ? n : N - 1;
+  for (int i = tid; i < P * cw; i += 256) {
+    const int p = i / cw, j = i - p * cw;
     const real* w = ws + (int64_t)p * wsp;
     real v;
-    if (i < 2 * nbg + 4) v = w[i];
-    else if (i < 2 * nbg + 4 + R * R) v = w[2 * nbg + 4 + R * K + (i - 2 * nbg - 4)];       // Linv
+    if (j < 2 * nbg + 4) v = w[j];
+    else if (j < 2 * nbg + 4 + R * R) v = w[2 * nbg + 4 + R * K + (j - 2 * nbg - 4)];       // Linv
     else v = w[2 * nbg + 4 + R * K + 2 * R * R];                                            // logdet
-    Ws[e] = v;
+    Ws[i] = v;
   }
-  for (int k = 0; k < K; ++k) {
-    ms[tid * KP + k] = mean[nc * K + k];
-    if (BWD) gm[tid * KP + k] = 0;
+  for (int i = tid; i < EB * K; i += 256) {
+    const int en = i / K, k = i - en * K;
+    const int64_t nn = n0 + en < N ? n0 + en : N - 1;
+    ms[en * KP + k] = mean[nn * K + k];
   }
+  if (BWD)
+    for (int i = tid; i < 4 * EB * KP; i += 256) gmp[i] = 0;
   __syncthreads();
-  for (int p = 0; p < P; ++p) {
+  real* gmq = gmp + q * EB * KP + e * KP;
+  real* Abq = Ab + q * EB * RP;
+  real* gsq = gs + q * EB;
+  for (int p = q; p < P; p += 4) {
     const real* Hs = Ws + p * cw;
     const real* cs = Hs + 2 * nbg;
     const real* Li = cs + 4;
-    real d[PL_MAXR], z[PL_MAXR];
-    const int64_t ta = pairs[2 * p], tb = pairs[2 * p + 1];
-#pragma unroll
-    for (int r = 0; r < PL_MAXR; ++r) {
-      d[r] = 0;
-      if (r < R) {
-        const int dd = r >> 1, j = r & 1;
-        const real* h = Hs + j * nbg;
-        real mu = cs[2 * j] * y0[nc * dof + dd] + cs[2 * j + 1] * v0[nc * dof + dd];
-        for (int b = 0; b < nbg; ++b) mu += h[b] * ms[tid * KP + dd * nbg + b];
-        const real y = traj[(nc * T + (j ? tb : ta)) * (int64_t)(2 * dof) + dd];
-        d[r] = y - mu;
-      }
-    }
-    real quad = 0;
-#pragma unroll
-    for (int r = 0; r < PL_MAXR; ++r) {
-      z[r] = 0;
-      if (r < R) {
-        real acc = 0;
-#pragma unroll
-        for (int c = 0; c < PL_MAXR; ++c)
-          if (c <= r) acc += Li[r * R + c] * d[c];
-        z[r] = acc;
-        quad += acc * acc;
-      }
-    }
-    if (!BWD) {
-      if (ok) logp[n * P + p] = real(-0.5) * quad - Hs[cw - 1] -
-                                real(0.5) * (real)R * real(1.8378770664093453);
-    } else {
-      const real g = ok ? gout[n * P + p] : real(0);
+    if (act) {
+      real d[PL_MAXR], z[PL_MAXR];
+      const int64_t ta = pairs[2 * p], tb = pairs[2 * p + 1];
 #pragma unroll
       for (int r = 0; r < PL_MAXR; ++r) {
+        d[r] = 0;
         if (r < R) {
-          real al = 0;
-#pragma unroll
-          for (int m = 0; m < PL_MAXR; ++m)
-            if (m >= r && m < R) al += Li[m * R + r] * z[m];
-          Ab[tid * RP + r] = al;
           const int dd = r >> 1, j = r & 1;
           const real* h = Hs + j * nbg;
-          const real ga = g * al;
-          for (int b = 0; b < nbg; ++b) gm[tid * KP + dd * nbg + b] += h[b] * ga;
+          real mu = cs[2 * j] * y0[nc * dof + dd] + cs[2 * j + 1] * v0[nc * dof + dd];
+          for (int b = 0; b < nbg; ++b) mu += h[b] * ms[e * KP + dd * nbg + b];
+          const real y = traj[(nc * T + (j ? tb : ta)) * (int64_t)(2 * dof) + dd];
+          d[r] = y - mu;
         }
       }
-      gs[tid] = g;
-      __syncthreads();
+      real quad = 0;
+#pragma unroll
+      for (int r = 0; r < PL_MAXR; ++r) {
+        z[r] = 0;
+        if (r < R) {
+          real acc = 0;
+#pragma unroll
+          for (int c = 0; c < PL_MAXR; ++c)
+            if (c <= r) acc += Li[r * R + c] * d[c];
+          z[r] = acc;
+          quad += acc * acc;
+        }
+      }
+      if (!BWD) {
+        if (ok) logp[n * P + p] = real(-0.5) * quad - Hs[cw - 1] -
+                                  real(0.5) * (real)R * real(1.8378770664093453);
+      } else {
+        const real g = ok ? gout[n * P + p] : real(0);
+#pragma unroll
+        for (int r = 0; r < PL_MAXR; ++r) {
+          if (r < R) {
+            real al = 0;
+#pragma unroll
+            for (int m = 0; m < PL_MAXR; ++m)
+              if (m >= r && m < R) al += Li[m * R + r] * z[m];
+            Abq[e * RP + r] = al;
+            const int dd = r >> 1, j = r & 1;
+            const real* h = Hs + j * nbg;
+            const real ga = g * al;
+            for (int b = 0; b < nbg; ++b) gmq[dd * nbg + b] += h[b] * ga;
+          }
+        }
+        gsq[e] = g;
+      }
+    }
+    if (BWD) {
+      // wave-private slab: LDS operations of one wave complete in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       real* out = spart + ((int64_t)blockIdx.x * P + p) * (R * R + 1);
-      for (int e = tid; e < R * R + 1; e += EB) {
+      for (int i = e; i < R * R + 1; i += 64) {
         real acc = 0;
-        if (e < R * R) {
-          const int r = e / R, c = e - r * R;
-          for (int i = 0; i < EB; ++i) acc += gs[i] * Ab[i * RP + r] * Ab[i * RP + c];
+        if (i < R * R) {
+          const int r = i / R, c = i - r * R;
+          for (int m = 0; m < EB; ++m) acc += gsq[m] * Abq[m * RP + r] * Abq[m * RP + c];
         } else {
-          for (int i = 0; i < EB; ++i) acc += gs[i];
+          for (int m = 0; m < EB; ++m) acc += gsq[m];
         }
-        out[e] = acc;
+        out[i] = acc;
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
-  if (BWD && ok)
-    for (int k = 0; k < K; ++k) gmean[n * K + k] = gm[tid * KP + k];
+  if (BWD) {
+    __syncthreads();
+    for (int i = tid; i < EB * K; i += 256) {
+      const int en = i / K, k = i - en * K;
+      if (n0 + en < N) {
+        const real* g0 = gmp + en * KP + k;
+        gmean[(n0 + en) * K + k] = (g0[0] + g0[EB * KP]) + (g0[2 * EB * KP] + g0[3 * EB * KP]);
+      }
+    }
+  }
 }
 
 // One block per pair: contribution of pair p to dL, gLp[p] [K,K] (the caller
@@ -559,12 +588,13 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   // envs per block of the fast path: as many as the LDS budget allows
   const int cw = 2 * nbg + 4 + f.R * f.R + 1;
   auto env_lds = [&](int eb) {
-    return ((size_t)P * cw + (size_t)eb * (K + 1) * (bwd ? 2 : 1) +
-            (bwd ? (size_t)eb * (f.R + 1) + eb : 0)) * sizeof(real);
+    return ((size_t)P * cw + (size_t)eb * (K + 1) * (bwd ? 5 : 1) +
+            (bwd ? 4 * ((size_t)eb * (f.R + 1) + eb) : 0)) * sizeof(real);
   };
-  // 64 envs per block: N/64 blocks keep more CUs busy than N/256 and the
-  // per-pair S reduction loops over 64 entries
+  // up to 64 envs (one lane each) per block of 4 waves; fewer when the four
+  // per-wave gradient slabs would not fit the LDS (fp64, K = 63)
   int EB = 64;
+  while (EB > 8 && env_lds(EB) > 150 * 1024) EB >>= 1;
   const int nblk = (int)ceil_div(N, EB);
   const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1) +
                            (bwd ? (int64_t)P * K * K : 0);
@@ -588,9 +618,9 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(EB), lds, stream,
+      hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(256), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
-                         f);
+                         f, EB);
       TCE_LAUNCH_CHECK();
       real* gLp = spart + (int64_t)nblk * P * (f.R * f.R + 1);   // [P][K][K]
       hipLaunchKernelGGL(pair_final_kernel<real>, dim3(P), dim3(256),
@@ -605,9 +635,9 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(EB), lds, stream,
+      hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(256), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
-                         f);
+                         f, EB);
     }
     TCE_LAUNCH_CHECK();
   }
@@ -652,7 +682,7 @@ int64_t pl_work_len(int64_t N, int P, int dof, int nbg, int64_t sL, bool bwd) {
   if (sL != 0) return 0;
   const int K = dof * nbg;
   PFShape f{K, 2 * dof, P, nbg, dof};
-  const int64_t nblk = ceil_div(N, 64);                  // smallest fast-path block
+  const int64_t nblk = ceil_div(N, 8);                   // smallest fast-path block
   int64_t n = (int64_t)P * pf_ws_pair(f) + nblk * P * (f.R * f.R + 1);
   if (bwd) n += (int64_t)P * K * K + N * (int64_t)K * K +
                 tce_sum_dim0_slices_impl(N, (int64_t)K * K) * K * K;

@@ -85,7 +85,8 @@ class MLP(nn.Module):
                       "act_func_last_type": self.act_func_last_type,
                       "dtype": self.dtype, "device": self.device}, f)
         with open(w_path, "wb") as f:
-            torch.save(self.state_dict(), f)
+            torch.save({k: v.detach().clone()           # not the flat buffer
+                        for k, v in self.state_dict().items()}, f)
 
     def load(self, log_dir, epoch):
         s_path, w_path = util.get_nn_save_paths(log_dir, self.mlp_name, epoch)
@@ -124,7 +125,7 @@ class TrainableVariable:
                       "variable_shape": self.shape, "dtype": self.dtype,
                       "device": self.device}, f)
         with open(w_path, "wb") as f:
-            torch.save(self.variable, f)
+            torch.save(nn.Parameter(self.variable.detach().clone()), f)
 
     def load(self, log_dir, epoch):
         s_path, w_path = util.get_nn_save_paths(log_dir, self.variable_name,
@@ -134,5 +135,7 @@ class TrainableVariable:
             assert self.variable_name == p["variable_name"] \
                 and self.shape == p["variable_shape"], \
                 "Variable %s's parameters do not match" % self.variable_name
-        self.variable = torch.load(w_path, map_location=self.device,
-                                   weights_only=False)
+        loaded = torch.load(w_path, map_location=self.device,
+                            weights_only=False)
+        with torch.no_grad():                     # keep the optimizer's view
+            self.variable.data.copy_(loaded.data)

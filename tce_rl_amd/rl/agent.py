@@ -21,6 +21,7 @@ from torch.optim.lr_scheduler import LinearLR
 
 from .. import ops, util
 from ..dist import DistContext
+from ..optim import FlatAdam
 from .projection import gaussian_kl_details
 
 
@@ -57,8 +58,7 @@ class AbstractAgent(ABC):
         """Adam with L2-in-gradient weight decay (abstract_agent.py:62-82)."""
         self.policy_net_params = policy.parameters
         self.critic_net_params = critic.parameters
-        mk = lambda params, lr, wd: torch.optim.Adam(
-            params=params, lr=lr, weight_decay=wd, fused=True)
+        mk = lambda params, lr, wd: FlatAdam(params, lr=lr, weight_decay=wd)
         return mk(self.policy_net_params, self.lr_policy, self.wd_policy), \
             mk(self.critic_net_params, self.lr_critic, self.wd_critic)
 
@@ -133,10 +133,33 @@ class AbstractAgent(ABC):
         return before, after
 
     def _optimizer_step(self, opt, params, clip):
-        self.dist.allreduce_grads(params)
-        norms = self._grad_norm_clip(clip, params)
-        opt.step()
-        return norms
+        """grad_norm_clip + Adam step (one flat buffer; one collective when
+        the envs are sharded over ranks)."""
+        if self.dist.world > 1:
+            opt.sync_grads()
+            self.dist.allreduce_flat(opt.flat_grad)
+        opt.step(clip)
+        norms = opt.dev_state[1:3].clone()      # the state is reused next step
+        return norms[0], norms[1]
+
+    def _capture(self, fn):
+        """Record fn() (kernel launches only, fixed buffers) into a HIP graph
+        on a side stream, without the device-wide synchronisation of
+        torch.cuda.graph() -- the critic epochs keep running meanwhile."""
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        graph = torch.cuda.CUDAGraph()
+        cur = torch.cuda.current_stream()
+        self._graph_stream.wait_stream(cur)
+        with torch.cuda.stream(self._graph_stream):
+            graph.capture_begin(pool=self._graph_pool)
+            try:
+                fn()
+            finally:
+                graph.capture_end()
+        cur.wait_stream(self._graph_stream)
+        return graph
 
     @staticmethod
     def _check_nan(flags):
@@ -170,6 +193,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.check_policy_balance = False
         # extension: run the critic and policy updates on two HIP streams
         self.overlap_updates = kwargs.get("overlap_updates", True)
+        self.graph_policy_update = kwargs.get("graph_policy_update", True)
         self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
         self._policy_stream = None
 
@@ -185,16 +209,20 @@ class TemporalCorrelatedAgent(AbstractAgent):
         dataset = self.process_dataset(dataset)
         process_dataset_time = util.run_time_test(lock=False,
                                                   key="process_dataset")
-        dataset_stats = util.device_stats(
-            {k: v for k, v in dataset.items()
-             if k not in ("segment_params_L", "step_states_full",
-                          "step_states", "step_actions")}, "exploration")
+        # exploration statistics: reductions are enqueued behind the policy
+        # update (second stream), the host reads them after the updates
+        stat_items = {k: v for k, v in dataset.items()
+                      if k not in ("segment_params_L", "step_states_full",
+                                   "step_states", "step_actions")}
 
         util.run_time_test(lock=True, key="update")
         if self._can_overlap():
             critic_loss_dict, policy_loss_dict, update_critic_time, \
-                update_policy_time = self._update_overlapped(dataset)
+                update_policy_time, dataset_stats = self._update_overlapped(
+                    dataset, lambda: util.device_stats_async(
+                        stat_items, "exploration"))
         else:
+            dataset_stats = util.device_stats(stat_items, "exploration")
             util.run_time_test(lock=True, key="update critic")
             critic_loss_dict = self.update_critic(dataset)
             update_critic_time = util.run_time_test(lock=False,
@@ -242,7 +270,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         return self.overlap_updates and self.num_minibatchs == 1 and \
             critic_ops.supported(self.critic.net)
 
-    def _update_overlapped(self, dataset):
+    def _update_overlapped(self, dataset, side_work=None):
         """The critic and policy updates of one iteration touch disjoint
         networks and only read the dataset, so they are independent.  The
         critic epochs (one persistent MFMA kernel each, 1 workgroup per CU) are
@@ -265,11 +293,14 @@ class TemporalCorrelatedAgent(AbstractAgent):
             ev[2].record(side)
             policy_loss_dict = self.update_policy(dataset)
             ev[3].record(side)
+            finish_side = side_work() if side_work is not None else dict
         main.wait_stream(side)
         critic_loss_dict = finish_critic()
+        side_result = finish_side()
         torch.cuda.synchronize()
         return critic_loss_dict, policy_loss_dict, \
-            ev[0].elapsed_time(ev[1]) * 1e-3, ev[2].elapsed_time(ev[3]) * 1e-3
+            ev[0].elapsed_time(ev[1]) * 1e-3, \
+            ev[2].elapsed_time(ev[3]) * 1e-3, side_result
 
     # ---- dataset processing (GAE + segment advantage: HIP kernels) -----------
     def process_dataset(self, dataset):
@@ -345,32 +376,35 @@ class TemporalCorrelatedAgent(AbstractAgent):
         from the rollout buffer), a second reduces the per-workgroup gradient
         slabs; Adam consumes the flat gradient."""
         from .. import critic_ops
+        opt = self.critic_optimizer
         run = getattr(self, "_critic_runner", None)
-        if run is None or run.mlp is not self.critic.net:
-            run = self._critic_runner = critic_ops.EpochRunner(self.critic.net)
-        rows = []
-        for _ in range(self.epochs_critic):
-            stats = run.epoch(x, returns, old_values, self.clip_critic,
-                              max_workgroups)
-            if self.dist.world > 1:
-                self.dist.allreduce_flat(run.flat)
-                g = run.flat.norm(2)
-            else:
-                g = stats[1].sqrt()
-            gc = g
-            if self.clip_grad_norm > 0:
-                coef = torch.clamp(self.clip_grad_norm / (g + 1e-6), max=1.0)
-                run.flat.mul_(coef)
-                gc = g * coef
-            self.critic_optimizer.step()
-            rows.append(torch.stack([stats[0], g, gc]))
-        stacked = torch.stack(rows)
+        if run is None or run.mlp is not self.critic.net or \
+                run.flat is not opt.flat_grad:
+            run = self._critic_runner = critic_ops.EpochRunner(
+                self.critic.net, opt.flat_grad)
+        opt.bind_grads()
+        E = self.epochs_critic
+        # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
+        rows = torch.zeros(E, 4, dtype=torch.float32, device=self.device)
+        fuse_adam = self.dist.world == 1 and not self.clip_grad_norm > 0
+        for e in range(E):
+            run.epoch(x, returns, old_values, self.clip_critic, max_workgroups,
+                      stats=rows[e], adam=opt if fuse_adam else None)
+            if not fuse_adam:
+                if self.dist.world > 1:
+                    self.dist.allreduce_flat(opt.flat_grad)
+                    opt.step(self.clip_grad_norm)
+                else:                   # |g|^2 comes with the reduction
+                    opt.step(self.clip_grad_norm, sumsq=rows[e, 1:2])
+                rows[e, 2:4].copy_(opt.dev_state[1:3])
 
         def finish():
-            host = stacked.cpu().numpy()                     # the only sync
+            host = rows.cpu().numpy()                        # the only sync
+            if fuse_adam:                                    # no clipping
+                host[:, 2] = host[:, 3] = np.sqrt(host[:, 1])
             return {**util.generate_stats(host[:, 0], "critic_loss"),
-                    **util.generate_stats(host[:, 1], "critic_grad_norm"),
-                    **util.generate_stats(host[:, 2],
+                    **util.generate_stats(host[:, 2], "critic_grad_norm"),
+                    **util.generate_stats(host[:, 3],
                                           "clipped_critic_grad_norm")}
         return finish
 
@@ -419,10 +453,13 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 init_time=init_time, init_pos=init_pos, init_vel=init_vel,
                 pred_pairs=pred_pairs)
 
-        rows, kl_rows, nan_flags = [], [], []
+        # per-epoch record: 7 loss/norm scalars, 12 KL terms, 3 NaN flags
+        E = self.epochs_policy
+        rec_all = torch.zeros(E, 22, dtype=self.dtype, device=self.device)
+        rec_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
         surr_gn, tr_gn = [], []
-        util.run_time_test(lock=True, key="projection", sync=False)
-        for _ in range(self.epochs_policy):
+
+        def epoch():
             if self.check_policy_balance:
                 mean_new, L_new, pm, pL = forward()
                 s_loss, _ = self.surrogate_loss(seg_adv, lp(pm, pL),
@@ -445,32 +482,54 @@ class TemporalCorrelatedAgent(AbstractAgent):
             surrogate_loss, ratio = self.surrogate_loss(
                 seg_adv, log_prob_new, log_probs_old)
             with torch.no_grad():
-                kl_rows.append(self.kl_old_new_proj(
-                    mean_new, L_new, mean_old, L_old, proj_mean, proj_L))
+                kl_row = self.kl_old_new_proj(
+                    mean_new, L_new, mean_old, L_old, proj_mean, proj_L)
             entropy = self.policy.entropy([proj_mean, proj_L]).mean()
             entropy_loss = -self.entropy_penalty_coef * entropy
             trust_region_loss = self.projection.get_trust_region_loss(
                 self.policy, (mean_new, L_new), (proj_mean, proj_L),
                 set_variance=self.set_variance)
-            nan_flags.append(torch.isnan(torch.stack(
-                [surrogate_loss.detach(), entropy_loss.detach(),
-                 trust_region_loss.detach()])))
             policy_loss = surrogate_loss + entropy_loss + trust_region_loss
             self.policy_optimizer.zero_grad(set_to_none=True)
             policy_loss.backward()
             g, gc = self._optimizer_step(self.policy_optimizer,
                                          self.policy_net_params,
                                          self.clip_grad_norm)
-            rows.append(torch.stack([
-                surrogate_loss.detach(), entropy_loss.detach(),
-                trust_region_loss.detach(), policy_loss.detach(),
-                entropy.detach(), g, gc]))
+            losses = torch.stack([surrogate_loss.detach(),
+                                  entropy_loss.detach(),
+                                  trust_region_loss.detach()])
+            rec = torch.cat([losses, torch.stack([policy_loss.detach(),
+                                                  entropy.detach(), g, gc]),
+                             kl_row.to(losses.dtype),
+                             torch.isnan(losses).to(losses.dtype)])
+            rec_all.index_copy_(0, rec_idx, rec[None])
+            rec_idx.add_(1)
+
+        util.run_time_test(lock=True, key="projection", sync=False)
+        if self.graph_policy_update and self.dist.world == 1 and E > 2 \
+                and not self.check_policy_balance:
+            # The epochs are identical launch sequences on fixed buffers: run
+            # the first one eagerly, record the second into a HIP graph and
+            # replay it -- ~150 launches per epoch leave the host.
+            epoch()
+            graph = self._capture(epoch)
+            for _ in range(E - 1):
+                graph.replay()
+            self.policy_optimizer.host_step += E - 2   # capture counted one
+            self._last_policy_graph = graph       # alive until the replays ran
+        else:
+            for _ in range(E):
+                epoch()
         projection_time = util.run_time_test(lock=False, key="projection",
                                              sync=False)
 
-        self._check_nan(nan_flags)
-        host = torch.stack(rows).cpu().numpy()            # ONE copy
-        kl_host = torch.stack(kl_rows).cpu().numpy()
+        rec_host = rec_all.cpu().numpy()                  # ONE copy
+        for name, bad in zip(("surrogate_loss", "entropy_loss",
+                              "trust_region_loss"),
+                             rec_host[:, 19:22].any(axis=0)):
+            if bad:
+                raise Exception("NAN %s detected" % name)
+        host, kl_host = rec_host[:, :7], rec_host[:, 7:19]
         names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
                  "policy_loss", "entropy", "policy_grad_norm",
                  "clipped_policy_grad_norm")

@@ -121,8 +121,8 @@ class AbstractGaussianPolicy(ABC):
     def set_cov_variable(self, param_L):
         assert self.contextual_std is False, \
             "Variance is a net instead of a variable."
-        self.variance_net.variable.data = \
-            self._cholesky_to_vector(ops.first_matrix(param_L)).detach()
+        self.variance_net.variable.data.copy_(
+            self._cholesky_to_vector(ops.first_matrix(param_L)).detach())
 
 
 class BlackBoxPolicy(AbstractGaussianPolicy):

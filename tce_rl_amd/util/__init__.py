@@ -132,6 +132,13 @@ def generate_many_stats(data_dict, name=None, to_np_=False):
 def device_stats(tensors, name):
     """Same five statistics for a dict of device tensors with ONE host copy:
     the reductions run on the device, the scalars are gathered in one tensor."""
+    return device_stats_async(tensors, name)()
+
+
+def device_stats_async(tensors, name):
+    """Enqueue the reductions now (current stream); the returned callable does
+    the single host copy and builds the dict -- call it when the host would
+    wait anyway."""
     keys, rows = [], []
     for k, v in tensors.items():
         if not torch.is_tensor(v) or v.numel() == 0:
@@ -141,14 +148,18 @@ def device_stats(tensors, name):
         rows.append(torch.stack([x.mean(), x.max(), x.min(), x.median(), std]))
         keys.append(k)
     if not rows:
-        return {}
-    host = torch.stack(rows).cpu().numpy()
-    out = {}
-    prefix = name + "_" if name else ""
-    for k, r in zip(keys, host):
-        for s, val in zip(("mean", "max", "min", "median", "std"), r):
-            out[prefix + k + "_" + s] = float(val)
-    return out
+        return dict
+    stacked = torch.stack(rows)
+
+    def finish():
+        host = stacked.cpu().numpy()
+        out = {}
+        prefix = name + "_" if name else ""
+        for k, r in zip(keys, host):
+            for s, val in zip(("mean", "max", "min", "median", "std"), r):
+                out[prefix + k + "_" + s] = float(val)
+        return out
+    return finish
 
 
 def rewrite_dict(d, prefix):
