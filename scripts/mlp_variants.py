@@ -8,9 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "tce_rl_amd", "csrc")
 OUT = os.path.join(HERE, "variants")
 VARIANTS = {
-    "base": [], "nof2": ["-DMLPX_NOF2"], "nof4": ["-DMLPX_NOF4"],
-    "nodw2": ["-DMLPX_NODW2"], "nob2": ["-DMLPX_NOB2"], "nodw1": ["-DMLPX_NODW1"],
-    "nomfma": ["-DMLPX_NOF2", "-DMLPX_NOF4", "-DMLPX_NODW2", "-DMLPX_NOB2", "-DMLPX_NODW1"],
+    "base": [], "stamp": ["-DMLPX_STAMP"],
 }
 VARIANTS.update({k: v.split() for k, v in
                  (a.split("=", 1) for a in os.environ.get("MLPX_EXTRA", "").split(";") if a)})
@@ -68,6 +66,14 @@ def run():
             e.record(); torch.cuda.synchronize()
             res.append(s.elapsed_time(e) / 5)
         print(f"{name:10s} fwd+bwd {res[0]:.3f} ms   fwd {res[1]:.3f} ms", flush=True)
+        if name == "stamp":
+            go(True); torch.cuda.synchronize()
+            st = partials[0, :14].cpu().tolist()
+            names = ["forward", "P1a bar+loss+dY2", "barrier P1b", "P2 writes+bar", "B2 loop", "epilogue", "barrier P3", "P4 writes+bar", "-", "loop top",
+                     "G: dW1", "G: dW1+barrier", "G: dW2", "G: dW2+barrier"]
+            tiles = (N * T // 64) // G
+            for n_, v_ in zip(names, st):
+                print(f"    {n_:16s} {v_ / tiles:9.0f} cycles/tile (counter units)")
 
 
 if __name__ == "__main__":

@@ -92,6 +92,7 @@ class EpochRunner:
         if adam is not None:
             g = adam.param_groups[0]
             adam.host_step += 1
+            adam._opt_called = True           # for LinearLR's order check
             ad = (ptr(adam.flat_param), ptr(adam.m), ptr(adam.v),
                   ptr(adam.dev_state), float(g["lr"]), float(g["betas"][0]),
                   float(g["betas"][1]), float(g["eps"]),

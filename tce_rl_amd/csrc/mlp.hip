@@ -74,6 +74,20 @@ __device__ inline float act_d(float h) {
 __device__ inline f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// v summed over the lanes l, l ^ 16, l ^ 32, l ^ 48 (all four get the total):
+// two VALU swaps (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two
+// LDS-routed shuffles.
+__device__ inline float sum_lane_groups(float v) {
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
 // nothing moves across: keeps the next step's LDS reads ahead of this step's MFMAs
 __device__ inline void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
 
@@ -101,286 +115,422 @@ __host__ __device__ inline int mlp_num_params(int din) {
   return HID * din + HID + HID * HID + HID + HID + 1;
 }
 
-// KPGE: input features per lane group (even); D_in <= 4 KPGE.
-template <int ACT, bool BWD, int KPGE>
-__global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
-  constexpr int W1P = 4 * KPGE + 2;                           // even pitch: float2 reads
-  constexpr int NCB = (4 * KPGE + 1 + 15) / 16;               // dW1 column blocks incl. the ones column
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* W2s = reinterpret_cast<float*>(smem_raw);            // [HID][W2P]   rows h2, columns h1 unit
-  float* W1s = W2s + HID * W2P;                               // [HID pos][W1P]
-  float* Bs = W1s + HID * W1P;                                // b1 (by position) | b2 | w3
-  float* Th1 = Bs + 3 * HID;                                  // [64][TPT] H1 by position; later X stash [64][XP]
-  float* Tdy = Th1 + ROWS_PER_TILE * TPT;                     // [64][TPT] dY2 (by h2), later dY1 (by position)
-  const int din = a.din;
+// LDS carve shared by both kernels.  KPGE: input features per lane group
+// (even); D_in <= 4 KPGE.
+template <int KPGE>
+struct Lds {
+  static constexpr int W1P = 4 * KPGE + 2;                    // even pitch: float2 reads
+  float *W2s, *W1s, *Bs, *Th1, *Tdy;
+  __device__ explicit Lds(char* raw) {
+    W2s = reinterpret_cast<float*>(raw);                      // [HID][W2P]   rows h2, columns h1 unit
+    W1s = W2s + HID * W2P;                                    // [HID pos][W1P]
+    Bs = W1s + HID * W1P;                                     // b1 (by position) | b2 | w3
+    Th1 = Bs + 3 * HID;                                       // [64][TPT] H1 by position; later X stash [64][XP]
+    Tdy = Th1 + ROWS_PER_TILE * TPT;                          // [64][TPT] dY2 (by h2), later dY1 (by position)
+  }
+};
 
+template <int KPGE>
+__device__ inline void stage_weights(const MlpArgs& a, const Lds<KPGE>& L, int tid, int nthreads) {
+  constexpr int W1P = Lds<KPGE>::W1P;
+  const int din = a.din;
+  for (int e = tid; e < HID * HID; e += nthreads) L.W2s[(e >> 7) * W2P + (e & 127)] = a.w2[e];
+  for (int e = tid; e < HID * 4 * KPGE; e += nthreads) {
+    const int q = e / (4 * KPGE), f = e - q * 4 * KPGE;
+    L.W1s[q * W1P + f] = f < din ? a.w1[u1_of(q) * din + f] : 0.f;
+  }
+  for (int e = tid; e < HID; e += nthreads) {
+    L.Bs[e] = a.b1[u1_of(e)];
+    L.Bs[HID + e] = a.b2[e];
+    L.Bs[2 * HID + e] = a.w3[e];
+  }
+}
+
+// This lane's batch row r = tile * 64 + 16 w + c as (env, step), advanced by
+// gridDim.x tiles at a time without a division in the tile loop.
+struct RowCursor {
+  int64_t r, ne;        // row index (unclamped), env
+  int t;                // step inside the env
+  int64_t dn;           // per advance: envs
+  int dt;               //              steps
+  int64_t dr;           //              rows
+  int64_t last_ne;      // (R - 1) as (env, step): rows past the end read this one
+  int last_t;
+  __device__ RowCursor(const MlpArgs& a, int64_t tile, int w, int c) {
+    r = tile * ROWS_PER_TILE + w * 16 + c;
+    ne = r / a.T;
+    t = (int)(r - ne * a.T);
+    dr = (int64_t)gridDim.x * ROWS_PER_TILE;
+    dn = dr / a.T;
+    dt = (int)(dr - dn * a.T);
+    last_ne = (a.R - 1) / a.T;
+    last_t = (int)((a.R - 1) - last_ne * a.T);
+  }
+  __device__ void advance(int T) {
+    r += dr; ne += dn; t += dt;
+    if (t >= T) { t -= T; ++ne; }
+  }
+};
+
+// X fragment of the cursor's row: lane group g holds X[r][KPGE g + s], s < KPGE
+// (clamped addresses, no branches around the loads); returns the clamped row.
+template <int KPGE>
+__device__ inline int64_t load_x(const MlpArgs& a, const RowCursor& cur, int g, float* dst) {
+  const bool in = cur.r < a.R;
+  const int64_t ne = in ? cur.ne : cur.last_ne;
+  const int t = in ? cur.t : cur.last_t;
+  const float* xr = a.x + ne * a.env_stride + t * a.row_stride;
+#pragma unroll
+  for (int s = 0; s < KPGE; ++s) {
+    const int k = KPGE * g + s;
+    dst[s] = xr[k < a.din ? k : a.din - 1];
+  }
+  return in ? cur.r : a.R - 1;
+}
+
+// Forward chain of one 16-row slice: h1 = act(W1 x + b1) (by position), h2 =
+// act(W2 h1 + b2).
+template <int ACT, int KPGE>
+__device__ inline void forward_chain(const Lds<KPGE>& L, const float* xb, int c, int g,
+                                     f32x4* h1, f32x4* h2) {
+  constexpr int W1P = Lds<KPGE>::W1P;
+  // ---- F2: Y1^T = W1 X^T + b1  (A = W1 rows by position, B = X fragment).
+  // Two row blocks at a time: a dependent accumulate needs 40 cycles but the
+  // MFMA issues every 32, so every chain is paired with a second one.
+  {
+    float A[2][2 * KPGE];
+    auto ld = [&](int mp, float* d) {
+      const float* p = L.W1s + (32 * mp + c) * W1P + KPGE * g;
+#pragma unroll
+      for (int s = 0; s < KPGE; s += 2) {
+        const f32x2 v0 = *reinterpret_cast<const f32x2*>(p + s);
+        const f32x2 v1 = *reinterpret_cast<const f32x2*>(p + 16 * W1P + s);
+        d[s] = v0.x; d[s + 1] = v0.y;
+        d[KPGE + s] = v1.x; d[KPGE + s + 1] = v1.y;
+      }
+    };
+    ld(0, A[0]);
+#pragma unroll
+    for (int mp = 0; mp < NB / 2; ++mp) {
+      if (mp + 1 < NB / 2) ld(mp + 1, A[(mp + 1) & 1]);
+      f32x4 acc0 = *reinterpret_cast<const f32x4*>(L.Bs + 32 * mp + 4 * g);
+      f32x4 acc1 = *reinterpret_cast<const f32x4*>(L.Bs + 32 * mp + 16 + 4 * g);
+      fence_sched();
+#pragma unroll
+      for (int s = 0; s < KPGE; ++s) {
+        acc0 = mfma(A[mp & 1][s], xb[s], acc0);
+        acc1 = mfma(A[mp & 1][KPGE + s], xb[s], acc1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
+      h1[2 * mp] = acc0;
+      h1[2 * mp + 1] = acc1;
+    }
+  }
+  // ---- F4: Y2^T = W2 H1^T + b2.  Step (mp, j): rows 32 mp + c and + 16, the
+  // 8 k-steps kb with B = h1[kb][j] (unit 64 (kb>>2) + 16 j + 4 g + (kb&3)).
+  {
+    f32x4 A[2][4];
+    const float* wb = L.W2s + c * W2P + 4 * g;
+    auto ld = [&](int st, f32x4* d) {
+      const float* p = wb + (32 * (st >> 2)) * W2P + 16 * (st & 3);
+      d[0] = *reinterpret_cast<const f32x4*>(p);
+      d[1] = *reinterpret_cast<const f32x4*>(p + 64);
+      d[2] = *reinterpret_cast<const f32x4*>(p + 16 * W2P);
+      d[3] = *reinterpret_cast<const f32x4*>(p + 16 * W2P + 64);
+    };
+    ld(0, A[0]);
+    f32x4 acc0, acc1;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int mp = st >> 2, j = st & 3;
+      if (st + 1 < 16) ld(st + 1, A[(st + 1) & 1]);
+      if (j == 0) {
+        acc0 = *reinterpret_cast<const f32x4*>(L.Bs + HID + 32 * mp + 4 * g);
+        acc1 = *reinterpret_cast<const f32x4*>(L.Bs + HID + 32 * mp + 16 + 4 * g);
+      }
+      fence_sched();
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        acc0 = mfma(A[st & 1][kb >> 2][kb & 3], h1[kb][j], acc0);
+        acc1 = mfma(A[st & 1][2 + (kb >> 2)][kb & 3], h1[kb][j], acc1);
+      }
+      if (j == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
+        h2[2 * mp] = acc0;
+        h2[2 * mp + 1] = acc1;
+      }
+    }
+  }
+}
+
+// v = w3 . H2 (without b3; summed over the 4 lane groups of a column)
+template <int KPGE>
+__device__ inline float value_head(const Lds<KPGE>& L, int g, const f32x4* h2) {
+  float v = 0.f;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    const f32x4 w3v = *reinterpret_cast<const f32x4*>(L.Bs + 2 * HID + 16 * m + 4 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += w3v[i] * h2[m][i];
+  }
+  return sum_lane_groups(v);
+}
+
+// ---- forward only (rollout values): 4 waves, 64 rows per tile -------------
+template <int ACT, int KPGE>
+__global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_fwd_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const Lds<KPGE> L(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-
-  // ---- stage the weights once per workgroup
-  for (int e = tid; e < HID * HID; e += MLP_BT) W2s[(e >> 7) * W2P + (e & 127)] = a.w2[e];
-  for (int e = tid; e < HID * 4 * KPGE; e += MLP_BT) {
-    const int q = e / (4 * KPGE), f = e - q * 4 * KPGE;
-    W1s[q * W1P + f] = f < din ? a.w1[u1_of(q) * din + f] : 0.f;
-  }
-  for (int e = tid; e < HID; e += MLP_BT) {
-    Bs[e] = a.b1[u1_of(e)];
-    Bs[HID + e] = a.b2[e];
-    Bs[2 * HID + e] = a.w3[e];
-  }
+  stage_weights<KPGE>(a, L, tid, MLP_BT);
   __syncthreads();
   const float b3 = a.b3[0];
+  const int64_t ntiles = (a.R + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+  RowCursor cur(a, blockIdx.x, wave, c);
+  float xn[KPGE];
+  load_x<KPGE>(a, cur, g, xn);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r = cur.r;
+    const bool rok = r < a.R;
+    float xb[KPGE];
+#pragma unroll
+    for (int s = 0; s < KPGE; ++s) xb[s] = (KPGE * g + s < a.din && rok) ? xn[s] : 0.f;
+    cur.advance(a.T);
+    load_x<KPGE>(a, cur, g, xn);
+    f32x4 h1[NB], h2[NB];
+    forward_chain<ACT, KPGE>(L, xb, c, g, h1, h2);
+    const float v = value_head<KPGE>(L, g, h2) + b3;
+    if (rok && g == 0) a.values[r] = v;
+  }
+}
 
-  // persistent gradient accumulators
-  f32x4 gW2[2][NB];        // rows q_a = 32 wave + 2 (4 g + i) + rb, columns q_b = 8 c + n
-  f32x4 gW1[2][NCB];       // rows as gW2 (positions of hidden 1), columns feature 16 n + c
-  float gb2[NB][4], gw3[NB][4];
-  float gb3 = 0.f, loss_sum = 0.f;
-  if (BWD) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-      for (int n = 0; n < NB; ++n) gW2[r][n] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-      for (int n = 0; n < NCB; ++n) gW1[r][n] = (f32x4){0, 0, 0, 0};
-    }
+// ---- forward + loss + backward: 8 waves, two roles ------------------------
+// Waves 0-3 ("chain" waves, one per SIMD) run the register-resident chains of
+// their 16 rows: forward, loss, dY2, then dH1 = W2^T dY2 and dY1.  Waves 4-7
+// ("gradient" waves, the second wave of each SIMD) own the weight-gradient
+// accumulators and contract the [batch][hidden] copies in LDS: dW2, db2 for the
+// current tile while the chain waves do dH1, and dW1 (+ db1) of the PREVIOUS
+// tile while the chain waves run the next forward.  Two waves per SIMD with
+// independent MFMA streams keep the matrix pipe busy through each other's
+// stalls (LDS latency, activation / loss VALU work, barrier skew); measured: P3
+// runs at 97 % of the MFMA rate, in P1 the gradient waves' burst of 96 MFMAs
+// delays the chain by about its own length (the arbiter does not interleave it
+// into the chain's bubbles; s_setprio does not change that).  Per tile:
+//   P1  chain: forward(i), value, loss, dY2(i) | gradient: dW1(i-1)
+//   P2  chain: store H1(i), dY2(i) to LDS      |
+//   P3  chain: dH1(i), dY1(i)                  | gradient: dW2(i), db2
+//   P4  chain: store dY1(i), X(i) to LDS       |
+template <int ACT, int KPGE>
+__global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a) {
+  constexpr int NCB = (4 * KPGE + 1 + 15) / 16;               // dW1 column blocks incl. the ones column
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const Lds<KPGE> L(smem_raw);
+  float* Th1 = L.Th1;
+  float* Tdy = L.Tdy;
+  const int din = a.din;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int role = tid >> 8;                                  // 0 chain, 1 gradient
+  const int wave = (tid >> 6) & 3;                            // row slice / output-row block
+  const int c = lane & 15, g = lane >> 4;
+  stage_weights<KPGE>(a, L, tid, 2 * MLP_BT);
+  __syncthreads();
+  const int64_t ntiles = (a.R + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+  const int P = mlp_num_params(din);
+  float* out = a.partials + (int64_t)blockIdx.x * (P + 2);
+  float* oW1 = out;
+  float* ob1 = oW1 + HID * din;
+  float* oW2 = ob1 + HID;
+  float* ob2 = oW2 + HID * HID;
+  float* ow3 = ob2 + HID;
+  float* ob3 = ow3 + HID;
+  __shared__ float sc[8];
+  float* red = Th1;                                           // [HID][4 waves] (after the tile loop)
+
+  // The chain waves carry the critical path: they win the issue arbitration of
+  // their SIMD, the gradient waves' MFMAs fill the slots they leave free.
+  if (role == 0) {
+    // ======================= chain waves =======================
+    const float b3 = a.b3[0];
+    const float inv_n = 1.f / (float)a.R;
+    float gw3[NB][4];
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { gb2[m][i] = 0.f; gw3[m][i] = 0.f; }
-  }
-
-  const int64_t ntiles = (a.R + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-  const float inv_n = 1.f / (float)a.R;
-  float* trow_h = Th1 + (wave * 16 + c) * TPT + 4 * g;       // this lane's C/D rows in the transposes
-  float* trow_d = Tdy + (wave * 16 + c) * TPT + 4 * g;
-
-  // X fragment of a tile: lane (c, g) holds X[r][KPGE g + s], s < KPGE.  Loaded
-  // one tile ahead (clamped addresses, no branches around the loads) so that
-  // the HBM latency hides behind the previous tile's MFMAs.
-  auto load_x = [&](int64_t tile, float* dst) {
-    const int64_t rr = tile * ROWS_PER_TILE + wave * 16 + c;
-    const int64_t rcl = rr < a.R ? rr : a.R - 1;
-    const int64_t ne = rcl / a.T;
-    const float* xr = a.x + ne * a.env_stride + (rcl - ne * a.T) * a.row_stride;
-#pragma unroll
-    for (int s = 0; s < KPGE; ++s) {
-      const int k = KPGE * g + s;
-      dst[s] = xr[k < din ? k : din - 1];
-    }
-  };
-  float xn[KPGE];
-  if ((int64_t)blockIdx.x < ntiles) load_x(blockIdx.x, xn);
-
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * ROWS_PER_TILE;
-    const int64_t r = row0 + wave * 16 + c;                   // this lane's batch row
-    const bool rok = r < a.R;
-    const int64_t rc = rok ? r : a.R - 1;
-
-    // ---- F1: take the prefetched fragment, start the next tile's loads
-    float xb[KPGE];
-#pragma unroll
-    for (int s = 0; s < KPGE; ++s) xb[s] = (KPGE * g + s < din && rok) ? xn[s] : 0.f;
+      for (int i = 0; i < 4; ++i) gw3[m][i] = 0.f;
+    float gb3 = 0.f, loss_sum = 0.f;
+    float* trow_h = Th1 + (wave * 16 + c) * TPT + 4 * g;     // this lane's C/D rows in the transposes
+    float* trow_d = Tdy + (wave * 16 + c) * TPT + 4 * g;
+    RowCursor cur(a, blockIdx.x, wave, c);
+    float xn[KPGE], retn, oldn = 0.f;
     {
-      const int64_t nt = tile + gridDim.x;
-      load_x(nt < ntiles ? nt : tile, xn);
+      const int64_t rcn = load_x<KPGE>(a, cur, g, xn);
+      retn = a.ret[rcn];
+      if (a.clip > 0.f) oldn = a.old_v[rcn];
     }
-    // ---- F2: Y1^T = W1 X^T + b1  (A = W1 rows by position, B = X fragment).
-    // Two row blocks at a time: a dependent accumulate needs 40 cycles but the
-    // MFMA issues every 32, so every chain is paired with a second one.
-    f32x4 h1[NB];
-    {
-      float A[2][2 * KPGE];
-      auto ld = [&](int mp, float* d) {
-        const float* p = W1s + (32 * mp + c) * W1P + KPGE * g;
+#ifdef MLPX_STAMP
+    long long stt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
+#define STAMP(k) { const long long tn = __builtin_readcyclecounter(); stt[k] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(k)
+#endif
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      STAMP(9)
+      const int64_t r = cur.r;                                // this lane's batch row
+      const bool rok = r < a.R;
+      // ---- P1: forward chain (the next tile's rows are fetched meanwhile)
+      float xb[KPGE];
 #pragma unroll
-        for (int s = 0; s < KPGE; s += 2) {
-          const f32x2 v0 = *reinterpret_cast<const f32x2*>(p + s);
-          const f32x2 v1 = *reinterpret_cast<const f32x2*>(p + 16 * W1P + s);
-          d[s] = v0.x; d[s + 1] = v0.y;
-          d[KPGE + s] = v1.x; d[KPGE + s + 1] = v1.y;
+      for (int s = 0; s < KPGE; ++s) xb[s] = (KPGE * g + s < din && rok) ? xn[s] : 0.f;
+      const float rt = retn, ov = oldn;
+      {
+        cur.advance(a.T);
+        const int64_t rcn = load_x<KPGE>(a, cur, g, xn);
+        retn = a.ret[rcn];
+        if (a.clip > 0.f) oldn = a.old_v[rcn];
+      }
+      f32x4 h1[NB], h2[NB];
+      forward_chain<ACT, KPGE>(L, xb, c, g, h1, h2);
+      STAMP(0)
+      // value, loss and dL/dv (mean over ALL rows R of the epoch), dY2
+      const float v = value_head<KPGE>(L, g, h2) + b3;
+      if (a.values && rok && g == 0) a.values[r] = v;
+      float dv;
+      {
+        const float e = v - rt;
+        float l = e * e, d = 2.f * e;
+        if (a.clip > 0.f) {
+          const float dlt = v - ov;
+          const float cl = fminf(fmaxf(dlt, -a.clip), a.clip);
+          const float e2 = ov + cl - rt;
+          if (e2 * e2 > l) { l = e2 * e2; d = (dlt > -a.clip && dlt < a.clip) ? 2.f * e2 : 0.f; }
         }
-      };
-      ld(0, A[0]);
+        if (!rok) { l = 0.f; d = 0.f; }
+        dv = d * inv_n;
+        if (g == 0) loss_sum += l;
+        if (g == 0) gb3 += dv;
+      }
+      // dY2 = dv w3 act'(H2) (in place in h2); dw3 partials
 #pragma unroll
-      for (int mp = 0; mp < NB / 2; ++mp) {
-        if (mp + 1 < NB / 2) ld(mp + 1, A[(mp + 1) & 1]);
-        f32x4 acc0 = *reinterpret_cast<const f32x4*>(Bs + 32 * mp + 4 * g);
-        f32x4 acc1 = *reinterpret_cast<const f32x4*>(Bs + 32 * mp + 16 + 4 * g);
-        fence_sched();
+      for (int m = 0; m < NB; ++m) {
+        const f32x4 w3v = *reinterpret_cast<const f32x4*>(L.Bs + 2 * HID + 16 * m + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float hv = h2[m][i];
+          gw3[m][i] += dv * hv;
+          h2[m][i] = dv * w3v[i] * act_d<ACT>(hv);
+        }
+      }
+      STAMP(1)
+      __syncthreads();                     // end P1: gradient waves finished dW1(i-1)
+      STAMP(2)
+      // ---- P2: [batch][hidden] copies of H1 and dY2
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        *reinterpret_cast<f32x4*>(trow_d + 16 * m) = h2[m];
+        *reinterpret_cast<f32x4*>(trow_h + 16 * m) = h1[m];
+      }
+      __syncthreads();                     // end P2
+      STAMP(3)
+      // ---- P3: dH1^T = W2^T dY2^T.  Step (m, j): k = h2 unit 16 m + 4 g + j,
+      // the 8 output blocks kb at once (A = W2[k][u1(kb, c)]: two float4).
+      f32x4 d1[NB];
+      {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) d1[kb] = (f32x4){0, 0, 0, 0};
+        f32x4 A[2][2];
+        const float* wb = L.W2s + (4 * g) * W2P + 16 * (c & 3) + 4 * (c >> 2);
+        auto ld = [&](int st, f32x4* d) {
+          const float* p = wb + (16 * (st >> 2) + (st & 3)) * W2P;
+          d[0] = *reinterpret_cast<const f32x4*>(p);
+          d[1] = *reinterpret_cast<const f32x4*>(p + 64);
+        };
+        ld(0, A[0]);
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+          if (st + 1 < 32) ld(st + 1, A[(st + 1) & 1]);
+          fence_sched();
+          const float b = h2[st >> 2][st & 3];
+#pragma unroll
+#ifndef MLPX_NOB2
+          for (int kb = 0; kb < NB; ++kb) d1[kb] = mfma(A[st & 1][kb >> 2][kb & 3], b, d1[kb]);
+#else
+          for (int kb = 0; kb < 1; ++kb) d1[st & 7][0] += A[st & 1][0][0] * b + A[st & 1][1][1];
+#endif
+        }
+      }
+      STAMP(4)
+      // dY1 = dH1 act'(H1)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d1[kb][i] *= act_d<ACT>(h1[kb][i]);
+      STAMP(5)
+      __syncthreads();                     // end P3: gradient waves finished dW2(i)
+      STAMP(6)
+      // ---- P4: dY1 over dY2; X tile [64 rows][features] over H1: feature f at
+      // 4 (f & 15) + (f >> 4) (zeros past D_in); feature D_in = 1 (the column
+      // that yields db1; stored after the owning lane's zero: same wave)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) *reinterpret_cast<f32x4*>(trow_d + 16 * kb) = d1[kb];
+      {
+        float* xs = Th1 + (wave * 16 + c) * XP;
 #pragma unroll
         for (int s = 0; s < KPGE; ++s) {
-          acc0 = mfma(A[mp & 1][s], xb[s], acc0);
-          acc1 = mfma(A[mp & 1][KPGE + s], xb[s], acc1);
+          const int f = KPGE * g + s;
+          xs[4 * (f & 15) + (f >> 4)] = xb[s];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
-        h1[2 * mp] = acc0;
-        h1[2 * mp + 1] = acc1;
+        if (g == 0) xs[4 * (din & 15) + (din >> 4)] = rok ? 1.f : 0.f;
       }
+      __syncthreads();                     // end P4
+      STAMP(7)
     }
-    // ---- F4: Y2^T = W2 H1^T + b2.  Step (mp, j): rows 32 mp + c and + 16, the
-    // 8 k-steps kb with B = h1[kb][j] (unit 64 (kb>>2) + 16 j + 4 g + (kb&3)).
-    f32x4 h2[NB];
-    {
-      f32x4 A[2][4];
-      const float* wb = W2s + c * W2P + 4 * g;
-      auto ld = [&](int st, f32x4* d) {
-        const float* p = wb + (32 * (st >> 2)) * W2P + 16 * (st & 3);
-        d[0] = *reinterpret_cast<const f32x4*>(p);
-        d[1] = *reinterpret_cast<const f32x4*>(p + 64);
-        d[2] = *reinterpret_cast<const f32x4*>(p + 16 * W2P);
-        d[3] = *reinterpret_cast<const f32x4*>(p + 16 * W2P + 64);
-      };
-      ld(0, A[0]);
-      f32x4 acc0, acc1;
+    __syncthreads();                       // gradient waves: dW1 of the last tile
+    // ---- dw3: reduce over the 16 batch lanes, then over the 4 chain waves
 #pragma unroll
-      for (int st = 0; st < 16; ++st) {
-        const int mp = st >> 2, j = st & 3;
-        if (st + 1 < 16) ld(st + 1, A[(st + 1) & 1]);
-        if (j == 0) {
-          acc0 = *reinterpret_cast<const f32x4*>(Bs + HID + 32 * mp + 4 * g);
-          acc1 = *reinterpret_cast<const f32x4*>(Bs + HID + 32 * mp + 16 + 4 * g);
-        }
-        fence_sched();
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-          acc0 = mfma(A[st & 1][kb >> 2][kb & 3], h1[kb][j], acc0);
-          acc1 = mfma(A[st & 1][2 + (kb >> 2)][kb & 3], h1[kb][j], acc1);
-        }
-        if (j == 3) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { acc0[i] = act_f<ACT>(acc0[i]); acc1[i] = act_f<ACT>(acc1[i]); }
-          h2[2 * mp] = acc0;
-          h2[2 * mp + 1] = acc1;
-        }
-      }
-    }
-    // ---- F5: v = w3 . H2 + b3 (sum over the 4 lane groups of a column)
-    float v = 0.f;
-#pragma unroll
-    for (int m = 0; m < NB; ++m) {
-      const f32x4 w3v = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 16 * m + 4 * g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v += w3v[i] * h2[m][i];
-    }
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    v += b3;
-    if (a.values && rok && g == 0) a.values[r] = v;
-    if (!BWD) continue;
-
-    // ---- loss and dL/dv (mean over ALL rows R of the epoch)
-    const float rt = a.ret[rc];
-    float dv;
-    {
-      const float e = v - rt;
-      float l = e * e, d = 2.f * e;
-      if (a.clip > 0.f) {
-        const float ov = a.old_v[rc];
-        const float dlt = v - ov;
-        const float cl = fminf(fmaxf(dlt, -a.clip), a.clip);
-        const float e2 = ov + cl - rt;
-        if (e2 * e2 > l) { l = e2 * e2; d = (dlt > -a.clip && dlt < a.clip) ? 2.f * e2 : 0.f; }
-      }
-      if (!rok) { l = 0.f; d = 0.f; }
-      dv = d * inv_n;
-      if (g == 0) loss_sum += l;
-      if (g == 0) gb3 += dv;
-    }
-    // ---- B1: dY2 = dv w3 act'(H2); dw3, db2 partials; [batch][hidden] copies to LDS
-    __syncthreads();                       // (A) previous tile's dW1 reads are done
-#pragma unroll
-    for (int m = 0; m < NB; ++m) {
-      const f32x4 w3v = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 16 * m + 4 * g);
-      f32x4 d;
+    for (int m = 0; m < NB; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float hv = h2[m][i];
-        gw3[m][i] += dv * hv;
-        d[i] = dv * w3v[i] * act_d<ACT>(hv);
-        gb2[m][i] += d[i];
+        float v3 = gw3[m][i];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v3 += __shfl_xor(v3, off, 16);
+        if (c == 0) red[(16 * m + 4 * g + i) * 4 + wave] = v3;
       }
-      *reinterpret_cast<f32x4*>(trow_d + 16 * m) = d;
-      *reinterpret_cast<f32x4*>(trow_h + 16 * m) = h1[m];
+    float s3 = (g == 0) ? gb3 : 0.f, sl = (g == 0) ? loss_sum : 0.f;
+    s3 = wave_sum(s3);
+    sl = wave_sum(sl);
+    if (lane == 0) { sc[wave] = s3; sc[4 + wave] = sl; }
+    __syncthreads();
+    if (tid < HID) ow3[tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+    if (tid == 0) {
+      ob3[0] = sc[0] + sc[1] + sc[2] + sc[3];
+      ob3[1] = sc[4] + sc[5] + sc[6] + sc[7];   // sum of squared errors of this WG
+      ob3[2] = 0.f;
     }
-    __syncthreads();                       // (B)
-    // ---- dW2[q_a][q_b] += sum_b dY2[b][q_a] H1[b][q_b]   (k = batch: 16 steps of 4 rows)
-    {
-      f32x2 av[2];
-      f32x4 bv[2][2];
-      auto ld = [&](int t, int buf) {
-        const int bt = 4 * t + g;
-        av[buf] = *reinterpret_cast<const f32x2*>(Tdy + bt * TPT + 32 * wave + 2 * c);
-        const float* p = Th1 + bt * TPT + 8 * c;
-        bv[buf][0] = *reinterpret_cast<const f32x4*>(p);
-        bv[buf][1] = *reinterpret_cast<const f32x4*>(p + 4);
-      };
-      ld(0, 0);
+#ifdef MLPX_STAMP
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 0)
+      for (int k = 0; k < 10; ++k) out[k] = (float)stt[k];
+#endif
+  } else {
+    // ======================= gradient waves =======================
+    f32x4 gW2[2][NB];        // rows q_a = 32 wave + 2 (4 g + i) + rb, columns q_b = 8 c + n
+    f32x4 gW1[2][NCB];       // rows as gW2 (positions of hidden 1), columns feature 16 n + c
+    float gb2[2] = {0.f, 0.f};                                // unit 32 wave + 2 c + rb, partial over g
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (t + 1 < 16) ld(t + 1, (t + 1) & 1);
-        fence_sched();
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const float b = bv[t & 1][n >> 2][n & 3];
-          gW2[0][n] = mfma(av[t & 1].x, b, gW2[0][n]);
-          gW2[1][n] = mfma(av[t & 1].y, b, gW2[1][n]);
-        }
-      }
+      for (int n = 0; n < NB; ++n) gW2[rb][n] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int n = 0; n < NCB; ++n) gW1[rb][n] = (f32x4){0, 0, 0, 0};
     }
-    // ---- B2: dH1^T = W2^T dY2^T.  Step (m, j): k = h2 unit 16 m + 4 g + j, the
-    // 8 output blocks kb at once (A = W2[k][u1(kb, c)]: two float4).
-    f32x4 d1[NB];
-    {
-      f32x4 dy2[NB];
-#pragma unroll
-      for (int m = 0; m < NB; ++m) dy2[m] = *reinterpret_cast<const f32x4*>(trow_d + 16 * m);
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) d1[kb] = (f32x4){0, 0, 0, 0};
-      f32x4 A[2][2];
-      const float* wb = W2s + (4 * g) * W2P + 16 * (c & 3) + 4 * (c >> 2);
-      auto ld = [&](int st, f32x4* d) {
-        const float* p = wb + (16 * (st >> 2) + (st & 3)) * W2P;
-        d[0] = *reinterpret_cast<const f32x4*>(p);
-        d[1] = *reinterpret_cast<const f32x4*>(p + 64);
-      };
-      ld(0, A[0]);
-#pragma unroll
-      for (int st = 0; st < 32; ++st) {
-        if (st + 1 < 32) ld(st + 1, A[(st + 1) & 1]);
-        fence_sched();
-        const float b = dy2[st >> 2][st & 3];
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) d1[kb] = mfma(A[st & 1][kb >> 2][kb & 3], b, d1[kb]);
-      }
-    }
-    // dY1 = dH1 act'(H1)  (own H1 values back from the transpose)
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(trow_h + 16 * kb);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) d1[kb][i] *= act_d<ACT>(hv[i]);
-    }
-    __syncthreads();                       // (C) all waves finished reading Tdy / Th1
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) *reinterpret_cast<f32x4*>(trow_d + 16 * kb) = d1[kb];
-    // X tile [64 rows][features] into the (now free) Th1 region: feature f at
-    // 4 (f & 15) + (f >> 4); feature D_in = 1 (the column that yields db1)
-    {
-      float* xs = Th1 + (wave * 16 + c) * XP;
-#pragma unroll
-      for (int s = 0; s < KPGE; ++s) {
-        const int f = KPGE * g + s;
-        if (f < din) xs[4 * (f & 15) + (f >> 4)] = xb[s];
-      }
-      if (g == 0) xs[4 * (din & 15) + (din >> 4)] = rok ? 1.f : 0.f;
-    }
-    __syncthreads();                       // (D)
-    // ---- dW1[q_a][f] += sum_b dY1[b][q_a] X[b][f]   (reads run 2 steps ahead)
-    {
+    // dW1[q_a][f] += sum_b dY1[b][q_a] X[b][f]   (reads run 2 steps ahead)
+    auto dw1 = [&]() {
       f32x2 av[3];
       f32x4 bv[3];
       auto ld = [&](int t, int buf) {
@@ -395,77 +545,100 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_kernel(MlpArgs a) {
         if (t + 2 < 16) ld(t + 2, (t + 2) % 3);
         fence_sched();
 #pragma unroll
+#ifndef MLPX_NODW1
         for (int n = 0; n < NCB; ++n) {
           gW1[0][n] = mfma(av[t % 3].x, bv[t % 3][n], gW1[0][n]);
           gW1[1][n] = mfma(av[t % 3].y, bv[t % 3][n], gW1[1][n]);
         }
+#else
+        for (int n = 0; n < 1; ++n) gW1[0][0][0] += av[t % 3].x * bv[t % 3][0];
+#endif
       }
+    };
+    bool first = true;
+#ifdef MLPX_STAMP
+    long long gst[4] = {0, 0, 0, 0};
+#define GSTAMP(k, t0) gst[k] += __builtin_readcyclecounter() - (t0);
+#else
+#define GSTAMP(k, t0)
+#endif
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef MLPX_STAMP
+      const long long tg0 = __builtin_readcyclecounter();
+#endif
+      if (!first) dw1();                   // P1: previous tile
+      first = false;
+      GSTAMP(0, tg0)
+      __syncthreads();                     // end P1
+      GSTAMP(1, tg0)
+      __syncthreads();                     // end P2
+#ifdef MLPX_STAMP
+      const long long tg1 = __builtin_readcyclecounter();
+#endif
+      // ---- P3: dW2[q_a][q_b] += sum_b dY2[b][q_a] H1[b][q_b]  (k = batch: 16 steps of 4 rows)
+      {
+        f32x2 av[2];
+        f32x4 bv[2][2];
+        auto ld = [&](int t, int buf) {
+          const int bt = 4 * t + g;
+          av[buf] = *reinterpret_cast<const f32x2*>(Tdy + bt * TPT + 32 * wave + 2 * c);
+          const float* p = Th1 + bt * TPT + 8 * c;
+          bv[buf][0] = *reinterpret_cast<const f32x4*>(p);
+          bv[buf][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          if (t + 1 < 16) ld(t + 1, (t + 1) & 1);
+          fence_sched();
+          gb2[0] += av[t & 1].x;
+          gb2[1] += av[t & 1].y;
+#pragma unroll
+#ifndef MLPX_NODW2
+          for (int n = 0; n < NB; ++n) {
+            const float b = bv[t & 1][n >> 2][n & 3];
+            gW2[0][n] = mfma(av[t & 1].x, b, gW2[0][n]);
+            gW2[1][n] = mfma(av[t & 1].y, b, gW2[1][n]);
+          }
+#else
+          for (int n = 0; n < 1; ++n) gW2[0][t & 7][0] += bv[t & 1][0][0] + bv[t & 1][1][1];
+#endif
+        }
+      }
+      GSTAMP(2, tg1)
+      __syncthreads();                     // end P3
+      GSTAMP(3, tg1)
+      __syncthreads();                     // end P4
     }
-  }
-  if (!BWD || a.partials == nullptr) return;
-
-  // ---- write this workgroup's partial slab: [W1 | b1 | W2 | b2 | w3 | b3 | loss | pad]
-  const int P = mlp_num_params(din);
-  float* out = a.partials + (int64_t)blockIdx.x * (P + 2);
-  float* oW1 = out;
-  float* ob1 = oW1 + HID * din;
-  float* oW2 = ob1 + HID;
-  float* ob2 = oW2 + HID * HID;
-  float* ow3 = ob2 + HID;
-  float* ob3 = ow3 + HID;
+    if (!first) dw1();                     // last tile
+    __syncthreads();
+    // ---- this workgroup's partial slab: [W1 | b1 | W2 | b2 | w3 | b3 | loss | pad]
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qa = 32 * wave + 2 * (4 * g + i) + rb;
+      for (int i = 0; i < 4; ++i) {
+        const int qa = 32 * wave + 2 * (4 * g + i) + rb;
 #pragma unroll
-      for (int n = 0; n < NB; ++n) oW2[qa * HID + u1_of(8 * c + n)] = gW2[rb][n][i];
-      const int h = u1_of(qa);
+        for (int n = 0; n < NB; ++n) oW2[qa * HID + u1_of(8 * c + n)] = gW2[rb][n][i];
+        const int h = u1_of(qa);
 #pragma unroll
-      for (int n = 0; n < NCB; ++n) {
-        const int f = 16 * n + c;
-        if (f < din) oW1[h * din + f] = gW1[rb][n][i];
-        else if (f == din) ob1[h] = gW1[rb][n][i];
+        for (int n = 0; n < NCB; ++n) {
+          const int f = 16 * n + c;
+          if (f < din) oW1[h * din + f] = gW1[rb][n][i];
+          else if (f == din) ob1[h] = gW1[rb][n][i];
+        }
       }
+      float v2 = gb2[rb];
+      v2 += __shfl_xor(v2, 16, 64);
+      v2 += __shfl_xor(v2, 32, 64);
+      if (g == 0) ob2[32 * wave + 2 * c + rb] = v2;
     }
-  }
-  // bias-like vectors: reduce over the 16 batch lanes (c) in registers, then
-  // over the 4 waves through LDS
-  __syncthreads();
-  float* red = Th1;                        // [2][HID][4 waves]
-#pragma unroll
-  for (int m = 0; m < NB; ++m)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v2 = gb2[m][i], v3 = gw3[m][i];
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        v2 += __shfl_xor(v2, off, 16);
-        v3 += __shfl_xor(v3, off, 16);
-      }
-      if (c == 0) {
-        const int h = 16 * m + 4 * g + i;
-        red[(0 * HID + h) * 4 + wave] = v2;
-        red[(1 * HID + h) * 4 + wave] = v3;
-      }
-    }
-  __syncthreads();
-  for (int e = tid; e < 2 * HID; e += MLP_BT) {
-    const float s = red[e * 4] + red[e * 4 + 1] + red[e * 4 + 2] + red[e * 4 + 3];
-    const int which = e / HID, h = e - which * HID;
-    (which == 0 ? ob2 : ow3)[h] = s;
-  }
-  // scalars: gb3 and loss live in the g == 0 lanes of every wave
-  float s3 = (g == 0) ? gb3 : 0.f, sl = (g == 0) ? loss_sum : 0.f;
-  s3 = wave_sum(s3);
-  sl = wave_sum(sl);
-  __shared__ float sc[8];
-  if (lane == 0) { sc[wave] = s3; sc[4 + wave] = sl; }
-  __syncthreads();
-  if (tid == 0) {
-    ob3[0] = sc[0] + sc[1] + sc[2] + sc[3];
-    ob3[1] = sc[4] + sc[5] + sc[6] + sc[7];   // sum of squared errors of this WG
-    ob3[2] = 0.f;
+    __syncthreads();                       // matches the chain waves' final barrier
+#ifdef MLPX_STAMP
+    __syncthreads();
+    if (tid == 256 && blockIdx.x == 0)
+      for (int k = 0; k < 4; ++k) out[10 + k] = (float)gst[k];
+#endif
   }
 }
 
@@ -534,9 +707,16 @@ template <int ACT, bool BWD, int KPGE>
 void mlp_launch(const MlpArgs& a, int grid, hipStream_t st) {
   constexpr size_t lds = mlp_lds_bytes<KPGE>();
   static_assert(lds <= 160 * 1024, "LDS budget");
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_kernel<ACT, BWD, KPGE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mlp_critic_kernel<ACT, BWD, KPGE>), dim3(grid), dim3(MLP_BT), lds, st, a);
+  if (BWD) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE>), dim3(grid), dim3(2 * MLP_BT), lds, st,
+                       a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_critic_fwd_kernel<ACT, KPGE>), dim3(grid), dim3(MLP_BT), lds, st, a);
+  }
 }
 
 template <int ACT>
