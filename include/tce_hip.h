@@ -254,6 +254,35 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- policy objective, shared (non-contextual) covariance ------------------
+ * surrogate: out[0] = -mean(exp(lp_new - lp_old) * adv), out[1] = mean ratio
+ *   (surrogate_loss, mprl/rl/agent/temporal_correlated_agent.py:718-739);
+ *   grad_lp (nullable) [M] = d out[0] / d lp_new.
+ * kl_shared: one call for what update_policy evaluates per epoch besides the
+ *   surrogate (temporal_correlated_agent.py:530-567,641-686,741-745):
+ *   out16[0..11] = means over envs of gaussian_kl_details (mean, cov, shape,
+ *   volume parts) for the pairs (new || old), (new || proj), (proj || old);
+ *   out16[12] = entropy of the projected policy; out16[13] = trust region loss
+ *   tr_coeff * mean(KL_mean(new || proj) [+ KL_cov(new || proj) if
+ *   tr_include_cov]) (projection layer get_trust_region_loss, third-party);
+ *   grad_mean [N,K] / grad_L [K,K] (nullable) = its gradients w.r.t. mean_new /
+ *   L_new (proj treated as constant).  Means [N,K]; L_* ONE lower-triangular
+ *   [K,K] factor each; ws: double [tce_kl_shared_ws_len(N)].
+ */
+int64_t tce_kl_shared_ws_len(int64_t N);
+int tce_surrogate_f32(const float* lp_new, const float* lp_old, const float* adv, int64_t M,
+                      float* out, float* grad_lp, void* stream);
+int tce_surrogate_f64(const double* lp_new, const double* lp_old, const double* adv, int64_t M,
+                      double* out, double* grad_lp, void* stream);
+int tce_kl_shared_f32(const float* mean_new, const float* mean_old, const float* mean_proj,
+                      const float* L_new, const float* L_old, const float* L_proj, int64_t N,
+                      int K, float tr_coeff, int tr_include_cov, float* out16,
+                      float* grad_mean, float* grad_L, double* ws, void* stream);
+int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const double* mean_proj,
+                      const double* L_new, const double* L_old, const double* L_proj, int64_t N,
+                      int K, double tr_coeff, int tr_include_cov, double* out16,
+                      double* grad_mean, double* grad_L, double* ws, void* stream);
+
 /* ---- optimizer: flat Adam with global-norm clipping -----------------------
  * One optimizer step over a flat parameter buffer of n elements:
  *   grad_norm_clip(clip, params)   mprl/util/util_numerical.py:244-275

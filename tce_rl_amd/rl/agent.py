@@ -22,6 +22,7 @@ from torch.optim.lr_scheduler import LinearLR
 from .. import ops, util
 from ..dist import DistContext
 from ..optim import FlatAdam
+from . import objective
 from .projection import gaussian_kl_details
 
 
@@ -194,6 +195,8 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # extension: run the critic and policy updates on two HIP streams
         self.overlap_updates = kwargs.get("overlap_updates", True)
         self.graph_policy_update = kwargs.get("graph_policy_update", True)
+        self.fused_policy_objective = kwargs.get("fused_policy_objective",
+                                                 True)
         self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
         self._policy_stream = None
 
@@ -459,7 +462,34 @@ class TemporalCorrelatedAgent(AbstractAgent):
         rec_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
         surr_gn, tr_gn = [], []
 
+        fused_ctx = None
+        if self.fused_policy_objective and not self.check_policy_balance \
+                and objective.supported(self, dataset):
+            init = self.projection.initial_entropy
+            sched = self.projection.entropy_schedule_type
+            beta = None if sched in (None, False) else \
+                self.projection.entropy_schedule(
+                    init, self.projection.target_entropy,
+                    self.projection.temperature, self.num_iterations)
+            fused_ctx = objective.Context(self, dataset, times, beta)
+
+        def epoch_fused():
+            mean_new, L_new = self.policy.policy(states)
+            policy_loss, rec17 = objective.policy_objective(mean_new, L_new,
+                                                            fused_ctx)
+            self.policy_optimizer.zero_grad(set_to_none=True)
+            policy_loss.backward()
+            g, gc = self._optimizer_step(self.policy_optimizer,
+                                         self.policy_net_params,
+                                         self.clip_grad_norm)
+            rec = torch.cat([rec17[:5], torch.stack([g, gc]).to(rec17.dtype),
+                             rec17[5:], torch.isnan(rec17[:3]).to(rec17.dtype)])
+            rec_all.index_copy_(0, rec_idx, rec[None])
+            rec_idx.add_(1)
+
         def epoch():
+            if fused_ctx is not None:
+                return epoch_fused()
             if self.check_policy_balance:
                 mean_new, L_new, pm, pL = forward()
                 s_loss, _ = self.surrogate_loss(seg_adv, lp(pm, pL),

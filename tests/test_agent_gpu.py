@@ -8,12 +8,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(num_env, epochs, overlap):
+def build(num_env, epochs, overlap, **agent_kw):
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
     cfg = tce_config("metaworld", num_env=num_env, num_basis=5, epochs=epochs,
                      evaluation_interval=0)
     cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
+    cfg["params"]["agent"]["args"].update(agent_kw)
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)
     return exp.agent, cfg
@@ -23,11 +24,15 @@ def to_cpu_params(net):
     return [p.detach().cpu().clone() for p in net.parameters()]
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_agent_step_matches_cpu_oracle(overlap):
+@pytest.mark.parametrize("overlap,fused,graph", [(False, True, True),
+                                                 (True, True, True),
+                                                 (False, False, False),
+                                                 (True, False, True)])
+def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
     from oracle.agent_oracle import OracleTCE
     N, EPOCHS = 16, 3
-    agent, cfg = build(N, EPOCHS, overlap)
+    agent, cfg = build(N, EPOCHS, overlap, fused_policy_objective=fused,
+                       graph_policy_update=graph)
     oracle = OracleTCE(cfg["params"], N)
     # identical weights
     with torch.no_grad():
@@ -180,3 +185,24 @@ def test_bbrl_agent_step():
     assert np.isfinite(res["critic_loss_mean"])
     assert np.isfinite(res["projection_kl"])
     assert res["num_global_steps"] == 2 * 256 * 500
+
+
+def test_fused_objective_reports_the_same_metrics():
+    """The fused policy objective (one autograd node) and the op-by-op path
+    return the same losses and KL diagnostics."""
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(3)
+        agent, _ = build(64, 4, False, fused_policy_objective=fused,
+                         graph_policy_update=fused)
+        torch.manual_seed(5)
+        res.append(agent.step())
+    a, b = res
+    keys = [k for k in b if k.startswith("projection_") and k.endswith("_mean")]
+    keys += ["surrogate_loss_mean", "trust_region_loss_mean", "entropy_mean",
+             "policy_loss_mean", "entropy_loss_mean", "policy_grad_norm_mean"]
+    assert len(keys) >= 18
+    for k in keys:
+        if k == "projection_time":
+            continue
+        assert a[k] == pytest.approx(b[k], rel=2e-3, abs=2e-6), k
