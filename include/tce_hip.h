@@ -254,6 +254,15 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- streams restricted to a slice of every XCD ---------------------------
+ * The critic update and the policy update of one iteration are independent
+ * (mprl/rl/agent/temporal_correlated_agent.py:55-70 runs them back to back);
+ * here they run side by side on disjoint compute units.  The stream's kernels
+ * use units [first_cu, first_cu + cus_per_xcd) of each of the 8 XCDs.
+ */
+int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream);
+int tce_stream_destroy(void* stream);
+
 /* ---- policy objective, shared (non-contextual) covariance ------------------
  * surrogate: out[0] = -mean(exp(lp_new - lp_old) * adv), out[1] = mean ratio
  *   (surrogate_loss, mprl/rl/agent/temporal_correlated_agent.py:718-739);

@@ -1,5 +1,6 @@
 // Library-level entry points of libtce_hip.so (error string, version, device).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -20,6 +21,35 @@ int tce_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// A stream whose kernels run only on `cus_per_xcd` compute units of every XCD,
+// starting at unit `first_cu` (0..31) of the XCD: lets two independent kernel
+// chains (critic epochs, policy epochs) own disjoint parts of the chip.  CU
+// mask bit b addresses XCD b % 8, unit b / 8 (measured on MI355X:
+// scripts/ubench_cumask.hip).  Returns the hipStream_t in *stream.
+int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream) {
+  TCE_CHECK_ARG(stream && first_cu >= 0 && cus_per_xcd >= 1 && first_cu + cus_per_xcd <= 32,
+                "stream_create_cu_range: bad CU range (32 units per XCD)");
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = first_cu; j < first_cu + cus_per_xcd; ++j)
+    for (int x = 0; x < 8; ++x) {
+      const int b = 8 * j + x;
+      mask[b >> 5] |= 1u << (b & 31);
+    }
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, 8, mask);
+  if (e != hipSuccess) {
+    tce_set_error(hipGetErrorString(e));
+    return 2;
+  }
+  *stream = (void*)st;
+  return 0;
+}
+
+int tce_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return 2;
+  return 0;
 }
 
 }  // extern "C"

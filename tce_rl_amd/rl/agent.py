@@ -173,6 +173,58 @@ class AbstractAgent(ABC):
                     raise Exception("NAN %s detected" % name)
 
 
+class _CriticEpochs:
+    """Full-batch critic epochs on the fused fp32-MFMA kernel: one launch does
+    forward + value loss + backward for all N*T rows (read in place from the
+    rollout buffer), a second reduces the per-workgroup gradient slabs and
+    applies Adam.  ``run`` may be called in pieces with different workgroup
+    limits (the overlapped update gives the critic the whole chip once the
+    policy epochs are done)."""
+
+    def __init__(self, agent, x, returns, old_values):
+        from .. import critic_ops
+        self.agent = agent
+        self.x, self.returns, self.old_values = x, returns, old_values
+        opt = self.opt = agent.critic_optimizer
+        run = getattr(agent, "_critic_runner", None)
+        if run is None or run.mlp is not agent.critic.net or \
+                run.flat is not opt.flat_grad:
+            run = agent._critic_runner = critic_ops.EpochRunner(
+                agent.critic.net, opt.flat_grad)
+        self.runner = run
+        opt.bind_grads()
+        self.E = agent.epochs_critic
+        # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
+        self.rows = torch.zeros(self.E, 4, dtype=torch.float32,
+                                device=agent.device)
+        self.fuse_adam = agent.dist.world == 1 and \
+            not agent.clip_grad_norm > 0
+        self.done = 0
+
+    def run(self, n, max_workgroups=0):
+        ag, opt, rows = self.agent, self.opt, self.rows
+        for e in range(self.done, min(self.E, self.done + n)):
+            self.runner.epoch(self.x, self.returns, self.old_values,
+                              ag.clip_critic, max_workgroups, stats=rows[e],
+                              adam=opt if self.fuse_adam else None)
+            if not self.fuse_adam:
+                if ag.dist.world > 1:
+                    ag.dist.allreduce_flat(opt.flat_grad)
+                    opt.step(ag.clip_grad_norm)
+                else:                   # |g|^2 comes with the reduction
+                    opt.step(ag.clip_grad_norm, sumsq=rows[e, 1:2])
+                rows[e, 2:4].copy_(opt.dev_state[1:3])
+            self.done = e + 1
+
+    def finish(self):
+        host = self.rows.cpu().numpy()                       # the only sync
+        if self.fuse_adam:                                   # no clipping
+            host[:, 2] = host[:, 3] = np.sqrt(host[:, 1])
+        return {**util.generate_stats(host[:, 0], "critic_loss"),
+                **util.generate_stats(host[:, 2], "critic_grad_norm"),
+                **util.generate_stats(host[:, 3], "clipped_critic_grad_norm")}
+
+
 class TemporalCorrelatedAgent(AbstractAgent):
     def __init__(self, policy, critic, sampler, projection,
                  dtype=torch.float32, device=torch.device("cpu"), **kwargs):
@@ -194,10 +246,17 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.check_policy_balance = False
         # extension: run the critic and policy updates on two HIP streams
         self.overlap_updates = kwargs.get("overlap_updates", True)
-        self.graph_policy_update = kwargs.get("graph_policy_update", True)
+        # hipGraph replay of the policy epochs: fewer host launches, but the
+        # node-to-node latency grows ~10x while another stream keeps the GPU
+        # busy (measured), so it only pays without the overlapped critic
+        self.graph_policy_update = kwargs.get("graph_policy_update", False)
         self.fused_policy_objective = kwargs.get("fused_policy_objective",
                                                  True)
         self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
+        self.critic_cus_per_xcd = kwargs.get("critic_cus_per_xcd", None)
+        self.adaptive_critic_split = kwargs.get("adaptive_critic_split", True)
+        self._critic_split = 0          # 0: all epochs beside the policy
+        self._critic_stream = None
         self._policy_stream = None
 
     def step(self):
@@ -277,33 +336,80 @@ class TemporalCorrelatedAgent(AbstractAgent):
         """The critic and policy updates of one iteration touch disjoint
         networks and only read the dataset, so they are independent.  The
         critic epochs (one persistent MFMA kernel each, 1 workgroup per CU) are
-        enqueued first on the main stream with a few CUs left free; the policy
-        epochs (many small latency-bound kernels) are then enqueued on a second
-        HIP stream and run beside them.  Results are identical to the
-        sequential order; the per-phase times reported are the device times of
-        each stream (HIP events)."""
+        enqueued first on the main stream with a few CUs left free (one per
+        shader engine: a policy kernel's workgroups are spread over all of
+        them); the policy epochs (many small latency-bound kernels) run beside
+        them on a second HIP stream.  The policy finishes first: the remaining
+        critic epochs wait for it and then take every CU.  The split point
+        follows the device times measured in the previous iteration.  Results
+        are identical to the sequential order; the per-phase times reported are
+        device times (HIP events)."""
         main = torch.cuda.current_stream()
         if self._policy_stream is None:
-            self._policy_stream = torch.cuda.Stream()
-        side = self._policy_stream
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self._make_update_streams()
+        side, cstream = self._policy_stream, self._critic_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        D2 = self.policy.num_dof * 2
+        ce = _CriticEpochs(self, dataset["step_states"][..., :-D2],
+                           dataset["step_returns"],
+                           dataset["step_values"][:, :-1])
+        E = ce.E
+        n1 = min(E, self._critic_split) if self._critic_split else E
         ev[0].record(main)
-        finish_critic = self.update_critic(dataset, defer=True,
-                                           max_workgroups=self.critic_workgroups)
-        ev[1].record(main)
+        cs = main if cstream is None else cstream
+        wg = self.critic_workgroups if cstream is None \
+            else 8 * self.critic_cus_per_xcd
+        if cstream is not None:
+            cstream.wait_event(ev[0])
+        with torch.cuda.stream(cs):
+            ce.run(n1, wg)
+            ev[4].record(cs)
         side.wait_event(ev[0])
         with torch.cuda.stream(side):
             ev[2].record(side)
             policy_loss_dict = self.update_policy(dataset)
             ev[3].record(side)
             finish_side = side_work() if side_work is not None else dict
+            ev[5].record(side)
+        with torch.cuda.stream(cs):
+            if n1 < E:
+                cs.wait_event(ev[5])           # the policy stream is drained
+                ce.run(E - n1, 0 if cstream is None else wg)
+            ev[1].record(cs)
         main.wait_stream(side)
-        critic_loss_dict = finish_critic()
+        if cstream is not None:
+            main.wait_stream(cstream)
+        critic_loss_dict = ce.finish()
         side_result = finish_side()
         torch.cuda.synchronize()
+        # next split: the critic epochs the policy stream needs company for
+        first_ms = ev[0].elapsed_time(ev[4]) / max(n1, 1)
+        side_ms = ev[2].elapsed_time(ev[5])
+        if self.adaptive_critic_split and cstream is None:
+            self._critic_split = int(min(E, side_ms / first_ms + 2))
         return critic_loss_dict, policy_loss_dict, \
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
+
+    def _make_update_streams(self):
+        """Second stream for the policy epochs; with ``critic_cus_per_xcd`` both
+        updates get streams bound to disjoint compute units (the critic the
+        units [32 - n, 32) of every XCD, the policy the rest)."""
+        n = self.critic_cus_per_xcd
+        if not n:
+            self._policy_stream, self._critic_stream = torch.cuda.Stream(), None
+            return
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        hs = []
+        for first, cnt in ((32 - n, n), (0, 32 - n)):
+            h = ctypes.c_void_p()
+            if lib.tce_stream_create_cu_range(first, cnt, ctypes.byref(h)):
+                raise RuntimeError(lib.tce_last_error().decode())
+            hs.append(h.value)
+        self._critic_stream = torch.cuda.ExternalStream(hs[0])
+        self._policy_stream = torch.cuda.ExternalStream(hs[1])
 
     # ---- dataset processing (GAE + segment advantage: HIP kernels) -----------
     def process_dataset(self, dataset):
@@ -374,42 +480,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 **util.generate_stats(host[2], "clipped_critic_grad_norm")}
 
     def _update_critic_fused(self, x, returns, old_values, max_workgroups=0):
-        """Full-batch critic epochs on the fused fp32-MFMA kernel: one launch
-        does forward + value loss + backward for all N*T rows (read in place
-        from the rollout buffer), a second reduces the per-workgroup gradient
-        slabs; Adam consumes the flat gradient."""
-        from .. import critic_ops
-        opt = self.critic_optimizer
-        run = getattr(self, "_critic_runner", None)
-        if run is None or run.mlp is not self.critic.net or \
-                run.flat is not opt.flat_grad:
-            run = self._critic_runner = critic_ops.EpochRunner(
-                self.critic.net, opt.flat_grad)
-        opt.bind_grads()
-        E = self.epochs_critic
-        # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
-        rows = torch.zeros(E, 4, dtype=torch.float32, device=self.device)
-        fuse_adam = self.dist.world == 1 and not self.clip_grad_norm > 0
-        for e in range(E):
-            run.epoch(x, returns, old_values, self.clip_critic, max_workgroups,
-                      stats=rows[e], adam=opt if fuse_adam else None)
-            if not fuse_adam:
-                if self.dist.world > 1:
-                    self.dist.allreduce_flat(opt.flat_grad)
-                    opt.step(self.clip_grad_norm)
-                else:                   # |g|^2 comes with the reduction
-                    opt.step(self.clip_grad_norm, sumsq=rows[e, 1:2])
-                rows[e, 2:4].copy_(opt.dev_state[1:3])
-
-        def finish():
-            host = rows.cpu().numpy()                        # the only sync
-            if fuse_adam:                                    # no clipping
-                host[:, 2] = host[:, 3] = np.sqrt(host[:, 1])
-            return {**util.generate_stats(host[:, 0], "critic_loss"),
-                    **util.generate_stats(host[:, 2], "critic_grad_norm"),
-                    **util.generate_stats(host[:, 3],
-                                          "clipped_critic_grad_norm")}
-        return finish
+        ce = _CriticEpochs(self, x, returns, old_values)
+        ce.run(self.epochs_critic, max_workgroups)
+        return ce.finish
 
     def _minibatches(self, n):
         """generate_minibatches (util_data_structure.py:378-391).  With ONE
@@ -536,6 +609,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
             rec_idx.add_(1)
 
         util.run_time_test(lock=True, key="projection", sync=False)
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), \
+            torch.cuda.Event(enable_timing=True)
+        ev_a.record()
         if self.graph_policy_update and self.dist.world == 1 and E > 2 \
                 and not self.check_policy_balance:
             # The epochs are identical launch sequences on fixed buffers: run
@@ -550,6 +626,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         else:
             for _ in range(E):
                 epoch()
+        ev_b.record()
         projection_time = util.run_time_test(lock=False, key="projection",
                                              sync=False)
 
@@ -572,6 +649,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         for i, n in enumerate(kl_names):
             out.update(util.generate_stats(kl_host[:, i], "projection_" + n))
         out["projection_time"] = projection_time
+        out["policy_epochs_device_time"] = ev_a.elapsed_time(ev_b) * 1e-3
         if self.check_policy_balance:
             sg = torch.stack(surr_gn).cpu().numpy()
             tg = torch.stack(tr_gn).cpu().numpy()
