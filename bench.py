@@ -63,10 +63,10 @@ def kernel_time_us(fn, launches=20):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r01_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2
+    (profiles/r01c_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2
     correction); None if the file is absent."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r01c_pmc.json")) as f:
             return json.load(f)["kernels"][kernel]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
@@ -75,8 +75,8 @@ def pmc_traffic(kernel):
 def roofline(agent):
     """Rooflines measured live with HIP events on the launch stream.
 
-    dominant kernel = mlp_critic_kernel (the 50 critic epochs are ~85 % of the
-    device time of a step): MFMA-bound, algorithmic flops per launch =
+    dominant kernel = mlp_critic_bwd_kernel (the 50 critic epochs are ~90 % of
+    the device time of a step): MFMA-bound, algorithmic flops per launch =
     6 * (D_in*H + H*H + H) per row (forward 2x, backward 4x) * N*T rows
     against the dense FP32 matrix peak.  GAE scan and trajectory generator:
     HBM-bound, algorithmic bytes per SURVEY 8(d)."""
@@ -94,11 +94,11 @@ def roofline(agent):
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
-    critic = {"kernel": "mlp_critic_kernel<relu,bwd> (+ mlp_reduce_kernel)",
+    critic = {"kernel": "mlp_critic_bwd_kernel<relu,10> (+ mlp_finish_kernel)",
               "bound": "mfma", "achieved": round(flops / us_c / 1e6, 2),
               "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
               "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4),
-              "traffic": pmc_traffic("mlp_critic_kernel"),
+              "traffic": pmc_traffic("mlp_critic_bwd_kernel"),
               "us_per_launch": round(us_c, 1),
               "algorithmic_flops": flops, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     del full, xs

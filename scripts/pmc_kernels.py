@@ -19,6 +19,9 @@ run = critic_ops.EpochRunner(mlp)
 for _ in range(3):
     big.fill_(1.0)
     run.epoch(x, r, r, 0.0)
+for _ in range(3):
+    big.fill_(1.0)
+    critic_ops.forward(mlp, x)
 mp = ProDMP(dtype=torch.float32, device="cuda", num_dof=4, num_basis=5, tau=5, alpha_phase=3, alpha=10, dt=0.0125, basis_bandwidth_factor=5, weights_scale=0.1, goal_scale=0.1, relative_goal=True)
 t0 = torch.zeros(N, device="cuda"); times = ops.times(t0, mp.dt, T)
 w = 0.1 * torch.randn(N, 24, device="cuda", generator=g); y0 = torch.rand(N, 4, device="cuda", generator=g); v0 = torch.zeros(N, 4, device="cuda")

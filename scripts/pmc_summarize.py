@@ -1,0 +1,57 @@
+"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+runs of scripts/pmc_kernels.py) into profiles/<tag>_pmc.json and compact CSVs.
+
+    python scripts/pmc_summarize.py <fetch_counter_collection.csv> \
+        <write_counter_collection.csv> <tag>
+
+Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts the
+128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is.
+Both counters are reported in KiB."""
+import csv, json, os, sys, collections
+
+KERNELS = ("gae_dpp_kernel", "mlp_critic_bwd_kernel", "mlp_critic_fwd_kernel",
+           "prodmp_traj_kernel")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, counter):
+    vals = collections.defaultdict(list)
+    rows = []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                vals[k].append(float(r["Counter_Value"]))
+                rows.append((r["Kernel_Name"][:100], counter, r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}, rows
+
+
+def main():
+    fpath, wpath, tag = sys.argv[1:4]
+    fetch, frows = per_kernel(fpath, "FETCH_SIZE")
+    write, wrows = per_kernel(wpath, "WRITE_SIZE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) "
+                     "-- python3 scripts/pmc_kernels.py; C2 shapes; caches flushed with a "
+                     "1 GiB fill before every launch; scripts/pmc_summarize.py",
+           "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of wide coalesced "
+                         "reads at 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE as "
+                         "is; both in KiB",
+           "kernels": {}}
+    for k in KERNELS:
+        if k in fetch and k in write:
+            fb, wb = int(fetch[k] * 1024 * 2), int(write[k] * 1024)
+            out["kernels"][k] = {"fetch_bytes_corrected": fb, "write_bytes": wb,
+                                 "traffic_bytes": fb + wb}
+    with open(os.path.join(REPO, "profiles", tag + "_pmc.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for name, rows in (("FETCH_SIZE", frows), ("WRITE_SIZE", wrows)):
+        with open(os.path.join(REPO, "profiles", "%s_pmc_%s.csv" % (tag, name)), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value_KiB"])
+            w.writerows(rows)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
