@@ -23,6 +23,21 @@ class DistContext:
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         self._flat = {}
+        self._aux_group = None
+
+    def aux_group(self):
+        """A second communicator over the same ranks (collective call: every
+        rank must reach it at the same point).  The overlapped update issues
+        the critic's and the policy's gradient all-reduces from two streams;
+        on one communicator they would be serialised in host issue order (all
+        critic epochs first), on two they proceed independently."""
+        if self.world == 1:
+            return self.group
+        if self._aux_group is None:
+            ranks = dist.get_process_group_ranks(self.group) \
+                if self.group is not None else list(range(self.world))
+            self._aux_group = dist.new_group(ranks=ranks)
+        return self._aux_group
 
     def allreduce_grads(self, params):
         if self.world == 1:
@@ -42,11 +57,12 @@ class DistContext:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def allreduce_flat(self, flat):
+    def allreduce_flat(self, flat, group=None):
         """In-place mean over ranks of an already-flat gradient buffer."""
         if self.world == 1:
             return
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM,
+                        group=self.group if group is None else group)
         flat.div_(self.world)
 
     def mean_scalar(self, x):

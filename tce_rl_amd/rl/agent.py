@@ -51,9 +51,11 @@ class AbstractAgent(ABC):
             self.get_lr_scheduler()
         self.num_iterations = 0
         self.num_global_steps = 0
+        self._policy_group = None
         if self.dist.world > 1:
             self.dist.broadcast_params(self.policy_net_params +
                                        self.critic_net_params)
+            self._policy_group = self.dist.aux_group()
 
     def get_optimizer(self, policy, critic):
         """Adam with L2-in-gradient weight decay (abstract_agent.py:62-82)."""
@@ -138,7 +140,10 @@ class AbstractAgent(ABC):
         the envs are sharded over ranks)."""
         if self.dist.world > 1:
             opt.sync_grads()
-            self.dist.allreduce_flat(opt.flat_grad)
+            # the policy's exchange has its own communicator (see dist.py)
+            self.dist.allreduce_flat(
+                opt.flat_grad, self._policy_group
+                if opt is self.policy_optimizer else None)
         opt.step(clip)
         norms = opt.dev_state[1:3].clone()      # the state is reused next step
         return norms[0], norms[1]
