@@ -1,0 +1,94 @@
+"""Kernels of the fused policy objective (csrc/objective.hip) against the CPU
+oracle / plain torch: surrogate loss, shared-covariance KL diagnostics,
+trust-region loss and its gradients."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _chol(K, g, dtype, scale=0.05):
+    from oracle import tce_oracle as O
+    diag = torch.nn.functional.softplus(torch.randn(K, generator=g,
+                                                    dtype=dtype)) + 1e-2
+    L = torch.diag(diag)
+    idx = torch.tril_indices(K, K, -1)
+    L[idx[0], idx[1]] = scale * torch.randn(idx.shape[1], generator=g,
+                                            dtype=dtype)
+    return L
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M", [1, 1000, 4096 * 24])
+def test_surrogate(dtype, M):
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    g = torch.Generator().manual_seed(M)
+    lp_new = torch.randn(M, generator=g, dtype=dtype) * 0.3
+    lp_old = lp_new + 0.1 * torch.randn(M, generator=g, dtype=dtype)
+    adv = torch.randn(M, generator=g, dtype=dtype)
+    x = lp_new.clone().requires_grad_(True)
+    ratio = (x - lp_old).exp()
+    loss = -(ratio * adv).mean()
+    loss.backward()
+    out = torch.empty(2, dtype=dtype, device="cuda")
+    grad = torch.empty(M, dtype=dtype, device="cuda")
+    a, b, c = lp_new.cuda(), lp_old.cuda(), adv.cuda()
+    call("tce_surrogate_" + sfx(dtype), ptr(a), ptr(b), ptr(c), M, ptr(out),
+         ptr(grad), stream())
+    tol = 2e-5 if dtype == torch.float32 else 1e-12
+    assert out[0].item() == pytest.approx(loss.item(), rel=tol, abs=tol)
+    assert out[1].item() == pytest.approx(ratio.mean().item(), rel=tol)
+    torch.testing.assert_close(grad.cpu(), x.grad, rtol=tol, atol=tol / M)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("N,K", [(1, 24), (100, 24), (4096, 24), (77, 63),
+                                 (300, 8)])
+@pytest.mark.parametrize("include_cov", [1, 0])
+def test_kl_shared_vs_oracle(dtype, N, K, include_cov):
+    from oracle import kl_oracle as KO
+    from tce_rl_amd import _lib
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    g = torch.Generator().manual_seed(N * 100 + K)
+    f64 = torch.float64
+    means = [0.3 * torch.randn(N, K, generator=g, dtype=f64) for _ in range(3)]
+    Ls = [_chol(K, g, f64) for _ in range(3)]
+    mn, mo, mp = means
+    Ln, Lo, Lp = Ls
+    coeff = 1.7
+    # reference in float64 on the CPU
+    mn_r, Ln_r = mn.clone().requires_grad_(True), Ln.clone().requires_grad_(True)
+    ex = lambda L: L.unsqueeze(0).expand(N, -1, -1)
+    want = []
+    for (ma, La), (mb, Lb) in (((mn_r, Ln_r), (mo, Lo)), ((mn_r, Ln_r), (mp, Lp)),
+                               ((mp, Lp), (mo, Lo))):
+        want.extend(t.mean() for t in
+                    KO.gaussian_kl_details(ma, ex(La), mb, ex(Lb)))
+    maha, cov = KO.gaussian_kl(mn_r, ex(Ln_r), mp, ex(Lp))
+    tr = coeff * ((maha + cov).mean() if include_cov else maha.mean())
+    tr.backward()
+    ent = 0.5 * K * (1 + math.log(2 * math.pi)) + Lp.diagonal().log().sum()
+    # kernel
+    d = lambda t: t.to(dtype).cuda().contiguous()
+    out = torch.empty(16, dtype=dtype, device="cuda")
+    gm = torch.empty(N, K, dtype=dtype, device="cuda")
+    gL = torch.empty(K, K, dtype=dtype, device="cuda")
+    ws = torch.empty(_lib.load().tce_kl_shared_ws_len(N), dtype=f64,
+                     device="cuda")
+    args = [d(t) for t in (mn, mo, mp, Ln, Lo, Lp)]
+    call("tce_kl_shared_" + sfx(dtype), *[ptr(t) for t in args], N, K, coeff,
+         include_cov, ptr(out), ptr(gm), ptr(gL), ptr(ws), stream())
+    tol = 3e-4 if dtype == torch.float32 else 1e-9
+    got = out.double().cpu()
+    for i, w in enumerate(want):
+        assert got[i].item() == pytest.approx(w.item(), rel=tol, abs=tol), i
+    assert got[12].item() == pytest.approx(ent.item(), rel=tol)
+    assert got[13].item() == pytest.approx(tr.item(), rel=tol, abs=tol)
+    torch.testing.assert_close(gm.double().cpu(), mn_r.grad, rtol=tol,
+                               atol=tol * mn_r.grad.abs().max().item())
+    want_gL = torch.tril(Ln_r.grad) if include_cov else torch.zeros(K, K,
+                                                                   dtype=f64)
+    torch.testing.assert_close(gL.double().cpu(), want_gL, rtol=tol,
+                               atol=tol * max(want_gL.abs().max().item(), 1.0))
