@@ -176,11 +176,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # TCE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with all ranks on the
+    # GPUs that exist (one-GPU test box); the real run is nccl, one GPU per rank
+    backend = os.environ.get("TCE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda",
-                                                               local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(
+                "cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run for N > 1"
 
     agent, cfg = build_agent(NUM_ENV, seed=rank)

@@ -198,6 +198,11 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
         pairs = select_pred_pairs(num_all=self.num_times,
                                   **self.time_pairs_config)
         self.pred_pairs = pairs.to(torch.long).to(self.device)
+        # env shards of one job use the SAME segments: rank 0's draw
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size() > 1:
+            dist.broadcast(self.pred_pairs, src=0)
         return self.pred_pairs
 
     @staticmethod

@@ -28,15 +28,16 @@ def _worker(rank, world, port, overlap, q):
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)             # ... made equal by the broadcast
     agent = exp.agent
-    torch.manual_seed(7)                     # same pair offsets on every rank
     res = None
-    for _ in range(2):
-        res = agent.step()
+    pairs = []
+    for _ in range(2):                       # ranks draw differently seeded
+        res = agent.step()                   # pair offsets; rank 0's is used
+        pairs.append(agent.sampler.pred_pairs.cpu().numpy().copy())
     flat = torch.cat([p.detach().reshape(-1).cpu()
                       for p in agent.policy.parameters + agent.critic.parameters])
     q.put((rank, flat.numpy(), float(res["critic_loss_mean"]),
            float(res["surrogate_loss_mean"]), int(res["num_global_steps"]),
-           float(res["exploration_step_rewards_mean"])))
+           float(res["exploration_step_rewards_mean"]), pairs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,7 +57,8 @@ def test_two_ranks_stay_in_lock_step(overlap):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0, c0, s0, g0, r0), (_, w1, c1, s1, g1, r1) = out
+    (_, w0, c0, s0, g0, r0, p0), (_, w1, c1, s1, g1, r1, p1) = out
+    assert all(np.array_equal(a, b) for a, b in zip(p0, p1))
     assert np.isfinite(w0).all() and np.isfinite([c0, c1, s0, s1]).all()
     assert np.array_equal(w0, w1)            # same parameters on both ranks
     assert g0 == g1 == 2 * 2 * 32 * 500      # iterations x ranks x envs x T
