@@ -333,9 +333,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
 
     # ---- critic and policy updates side by side ------------------------------
     def _can_overlap(self):
-        from .. import critic_ops
-        return self.overlap_updates and self.num_minibatchs == 1 and \
-            critic_ops.supported(self.critic.net)
+        return self.overlap_updates and self.num_minibatchs == 1
 
     def _update_overlapped(self, dataset, side_work=None):
         """The critic and policy updates of one iteration touch disjoint
@@ -355,6 +353,26 @@ class TemporalCorrelatedAgent(AbstractAgent):
         side, cstream = self._policy_stream, self._critic_stream
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         D2 = self.policy.num_dof * 2
+        from .. import critic_ops
+        if not critic_ops.supported(self.critic.net):
+            # library-GEMM critic (256-wide nets, fp64): ordinary kernels, the
+            # two streams simply share the chip
+            ev[0].record(main)
+            finish_critic = self.update_critic(dataset, defer=True)
+            ev[1].record(main)
+            side.wait_event(ev[0])
+            with torch.cuda.stream(side):
+                ev[2].record(side)
+                policy_loss_dict = self.update_policy(dataset)
+                ev[3].record(side)
+                finish_side = side_work() if side_work is not None else dict
+            main.wait_stream(side)
+            critic_loss_dict = finish_critic()
+            side_result = finish_side()
+            torch.cuda.synchronize()
+            return critic_loss_dict, policy_loss_dict, \
+                ev[0].elapsed_time(ev[1]) * 1e-3, \
+                ev[2].elapsed_time(ev[3]) * 1e-3, side_result
         ce = _CriticEpochs(self, dataset["step_states"][..., :-D2],
                            dataset["step_returns"],
                            dataset["step_values"][:, :-1])
@@ -457,7 +475,6 @@ class TemporalCorrelatedAgent(AbstractAgent):
             finish = self._update_critic_fused(states[..., :-D2], returns,
                                                old_values, max_workgroups)
             return finish if defer else finish()
-        assert not defer
         losses, norms, norms_c = [], [], []
         for _ in range(self.epochs_critic):
             for sel in self._minibatches(N * T):
@@ -478,11 +495,16 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 losses.append(loss.detach())
                 norms.append(g)
                 norms_c.append(gc)
-        host = torch.stack([torch.stack(losses), torch.stack(norms),
-                            torch.stack(norms_c)]).cpu().numpy()
-        return {**util.generate_stats(host[0], "critic_loss"),
-                **util.generate_stats(host[1], "critic_grad_norm"),
-                **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+        stacked = torch.stack([torch.stack(losses), torch.stack(norms),
+                               torch.stack(norms_c)])
+
+        def finish():
+            host = stacked.cpu().numpy()
+            return {**util.generate_stats(host[0], "critic_loss"),
+                    **util.generate_stats(host[1], "critic_grad_norm"),
+                    **util.generate_stats(host[2],
+                                          "clipped_critic_grad_norm")}
+        return finish if defer else finish()
 
     def _update_critic_fused(self, x, returns, old_values, max_workgroups=0):
         ce = _CriticEpochs(self, x, returns, old_values)

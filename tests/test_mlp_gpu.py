@@ -94,3 +94,24 @@ def test_fused_critic_c2_shape_matches_library_path():
     torch.testing.assert_close(stats[0], loss.detach(), rtol=1e-5, atol=1e-6)
     for a, p in zip(mine, mlp.parameters()):
         torch.testing.assert_close(a, p.grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("rows", [100, (1 << 15) + 77, 70000])
+def test_library_path_split_k_weight_gradient(dtype, rows):
+    """mlp_ops._Linear (split-K weight gradient) == plain F.linear autograd."""
+    from tce_rl_amd import mlp_ops
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, 48, device="cuda", dtype=dtype, generator=g)[:, :27]
+    w = torch.randn(64, 27, device="cuda", dtype=dtype, generator=g)
+    b = torch.randn(64, device="cuda", dtype=dtype, generator=g)
+    outs = []
+    for fn in (mlp_ops._Linear.apply, F.linear):
+        xx = x.clone().requires_grad_(True)
+        ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(xx, ww, bb)
+        (y.tanh().pow(2).mean()).backward()
+        outs.append((y.detach(), xx.grad, ww.grad, bb.grad))
+    tol = 2e-4 if dtype == torch.float32 else 1e-11
+    for a, r in zip(*outs):
+        torch.testing.assert_close(a, r, rtol=tol, atol=tol * r.abs().max().item())
