@@ -266,7 +266,10 @@ int tce_stream_destroy(void* stream);
 /* ---- policy objective, shared (non-contextual) covariance ------------------
  * surrogate: out[0] = -mean(exp(lp_new - lp_old) * adv), out[1] = mean ratio
  *   (surrogate_loss, mprl/rl/agent/temporal_correlated_agent.py:718-739);
- *   grad_lp (nullable) [M] = d out[0] / d lp_new.
+ *   grad_lp (nullable) [M] = d out[0] / d lp_new.  ws: double
+ *   [tce_surrogate_ws_len()], ws[0] ZEROED ONCE by the caller before the first
+ *   call (block ticket, re-armed by every call), reusable across calls on one
+ *   stream.
  * kl_shared: one call for what update_policy evaluates per epoch besides the
  *   surrogate (temporal_correlated_agent.py:530-567,641-686,741-745):
  *   out16[0..11] = means over envs of gaussian_kl_details (mean, cov, shape,
@@ -279,10 +282,11 @@ int tce_stream_destroy(void* stream);
  *   [K,K] factor each; ws: double [tce_kl_shared_ws_len(N)].
  */
 int64_t tce_kl_shared_ws_len(int64_t N);
+int64_t tce_surrogate_ws_len(void);
 int tce_surrogate_f32(const float* lp_new, const float* lp_old, const float* adv, int64_t M,
-                      float* out, float* grad_lp, void* stream);
+                      float* out, float* grad_lp, double* ws, void* stream);
 int tce_surrogate_f64(const double* lp_new, const double* lp_old, const double* adv, int64_t M,
-                      double* out, double* grad_lp, void* stream);
+                      double* out, double* grad_lp, double* ws, void* stream);
 int tce_kl_shared_f32(const float* mean_new, const float* mean_old, const float* mean_proj,
                       const float* L_new, const float* L_old, const float* L_proj, int64_t N,
                       int K, float tr_coeff, int tr_include_cov, float* out16,

@@ -14,17 +14,26 @@
 
 namespace {
 
-// out[0] = -mean(ratio * adv), out[1] = mean(ratio); grad[i] = -ratio_i adv_i / M
+// out[0] = -mean(ratio * adv), out[1] = mean(ratio); grad[i] = -ratio_i adv_i / M.
+// Grid of blocks with per-block partial sums; the block that finishes last
+// adds them in index order (deterministic) and re-arms the ticket.
+constexpr int SUR_BT = 256;
+constexpr int SUR_MAX_BLOCKS = 128;
+
 template <typename real>
-__global__ __launch_bounds__(1024) void surrogate_kernel(const real* __restrict__ lp_new,
-                                                         const real* __restrict__ lp_old,
-                                                         const real* __restrict__ adv, int64_t M,
-                                                         real* __restrict__ out,
-                                                         real* __restrict__ grad) {
-  __shared__ double red[16];
+__global__ __launch_bounds__(SUR_BT) void surrogate_kernel(const real* __restrict__ lp_new,
+                                                           const real* __restrict__ lp_old,
+                                                           const real* __restrict__ adv, int64_t M,
+                                                           real* __restrict__ out,
+                                                           real* __restrict__ grad,
+                                                           double* __restrict__ partials,
+                                                           unsigned* __restrict__ ticket) {
+  __shared__ double red[4];
+  __shared__ bool last;
   double s = 0, sr = 0;
   const real inv = real(1) / (real)M;
-  for (int64_t i = threadIdx.x; i < M; i += blockDim.x) {
+  for (int64_t i = (int64_t)blockIdx.x * SUR_BT + threadIdx.x; i < M;
+       i += (int64_t)gridDim.x * SUR_BT) {
     const real ratio = exp(lp_new[i] - lp_old[i]);
     const real ra = ratio * adv[i];
     s += (double)ra;
@@ -34,8 +43,22 @@ __global__ __launch_bounds__(1024) void surrogate_kernel(const real* __restrict_
   s = block_sum(s, red);
   sr = block_sum(sr, red);
   if (threadIdx.x == 0) {
-    out[0] = (real)(-s / (double)M);
-    out[1] = (real)(sr / (double)M);
+    partials[2 * blockIdx.x] = s;
+    partials[2 * blockIdx.x + 1] = sr;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    double ts = 0, tr = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+      ts += __builtin_nontemporal_load(partials + 2 * b);
+      tr += __builtin_nontemporal_load(partials + 2 * b + 1);
+    }
+    out[0] = (real)(-ts / (double)M);
+    out[1] = (real)(tr / (double)M);
+    *ticket = 0;
   }
 }
 
@@ -109,7 +132,7 @@ template <typename real>
 __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
     const real* __restrict__ Ln, const real* __restrict__ Lo, const real* __restrict__ Lp,
     int64_t N, int K, real coeff, int include_cov, const double* __restrict__ partials,
-    int nparts, real* __restrict__ out, real* __restrict__ gL) {
+    int nparts, real* __restrict__ out, real* __restrict__ gL, int par) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int KP = K + 1;
   double* A = reinterpret_cast<double*>(smem_raw);   // Ln
@@ -120,28 +143,51 @@ __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
   sm_load(A, Ln, K, KP, true);
   sm_load(B, Lo, K, KP, true);
   sm_load(C, Lp, K, KP, true);
-  // |Lq^-1 Lp'|_F^2 and sum log diag of X = Lq^-1 Lp' (left in X)
-  auto frob_ld = [&](const double* Lq, const double* Lpp, double& f, double& ld) {
-    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
-      const int i = e / K, j = e - i * K;
-      X[i * KP + j] = Lpp[i * KP + j];
-    }
-    __syncthreads();
-    sm_trsm_l(X, Lq, K, KP);
+  auto frob_ld = [&](const double* Xw, double& f, double& ld) {
     double lf = 0, ll = 0;
     for (int e = threadIdx.x; e < K * K; e += SM_BT) {
       const int i = e / K, j = e - i * K;
-      const double x = X[i * KP + j];
+      const double x = Xw[i * KP + j];
       lf += x * x;
       if (i == j) ll += log(x);
     }
     f = sm_block_sum(lf, red);
     ld = sm_block_sum(ll, red);
   };
+  // X = Lq^-1 Ls by forward substitution, thread `col` per column
+  auto solve_cols = [&](double* Xw, const double* Lq, const double* Ls, int col) {
+    for (int r = 0; r < K; ++r) {
+      double v = Ls[r * KP + col];
+      for (int k = 0; k < r; ++k) v -= Lq[r * KP + k] * Xw[k * KP + col];
+      Xw[r * KP + col] = v / Lq[r * KP + r];
+    }
+  };
   double f1, l1, f2, l2, f3, l3;
-  frob_ld(B, A, f1, l1);                              // new || old
-  frob_ld(B, C, f3, l3);                              // proj || old
-  frob_ld(C, A, f2, l2);                              // new || proj  (X = Lp^-1 Ln stays)
+  const int w = threadIdx.x >> 6, col = threadIdx.x & 63;
+  if (par) {
+    // the three solves on three waves: X0 = Lo^-1 Ln, X (kept) = Lp^-1 Ln, X2 = Lo^-1 Lp
+    double* X0 = X + K * KP;
+    double* X2 = X0 + K * KP;
+    if (col < K) {
+      if (w == 0) solve_cols(X0, B, A, col);
+      else if (w == 1) solve_cols(X, C, A, col);
+      else if (w == 2) solve_cols(X2, B, C, col);
+    }
+    __syncthreads();
+    frob_ld(X0, f1, l1);                                // new || old
+    frob_ld(X2, f3, l3);                                // proj || old
+    frob_ld(X, f2, l2);                                 // new || proj
+  } else {
+    if (w == 0 && col < K) solve_cols(X, B, A, col);
+    __syncthreads();
+    frob_ld(X, f1, l1);
+    if (w == 0 && col < K) solve_cols(X, B, C, col);
+    __syncthreads();
+    frob_ld(X, f3, l3);
+    if (w == 0 && col < K) solve_cols(X, C, A, col);
+    __syncthreads();
+    frob_ld(X, f2, l2);                                 // X = Lp^-1 Ln stays
+  }
   if (gL) {
     sm_trsm_lt(X, C, K, KP);                          // Sigma_proj^-1 Ln
     for (int e = threadIdx.x; e < K * K; e += SM_BT) {
@@ -178,10 +224,12 @@ __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
 
 template <typename real>
 int surrogate(const real* lp_new, const real* lp_old, const real* adv, int64_t M, real* out,
-              real* grad, hipStream_t st) {
-  TCE_CHECK_ARG(lp_new && lp_old && adv && out && M > 0, "surrogate: null buffer / bad size");
-  hipLaunchKernelGGL(surrogate_kernel<real>, dim3(1), dim3(1024), 0, st, lp_new, lp_old, adv, M,
-                     out, grad);
+              real* grad, double* ws, hipStream_t st) {
+  TCE_CHECK_ARG(lp_new && lp_old && adv && out && ws && M > 0,
+                "surrogate: null buffer / bad size");
+  const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(M, 4 * SUR_BT), SUR_MAX_BLOCKS);
+  hipLaunchKernelGGL(surrogate_kernel<real>, dim3(grid), dim3(SUR_BT), 0, st, lp_new, lp_old, adv,
+                     M, out, grad, ws + 1, reinterpret_cast<unsigned*>(ws));
   TCE_LAUNCH_CHECK();
   return 0;
 }
@@ -200,12 +248,13 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
   hipLaunchKernelGGL(kl_shared_env_kernel<real>, dim3(nblk), dim3(KE_BT), lds_e, st, mn, mo, mp,
                      Lo, Lp, N, K, coeff / (real)N, gmean, ws);
   TCE_LAUNCH_CHECK();
-  const size_t lds_m = (size_t)4 * K * (K + 1) * sizeof(double);
+  const int par = (size_t)6 * K * (K + 1) * sizeof(double) <= 150 * 1024;   // K <= 55
+  const size_t lds_m = (size_t)(par ? 6 : 4) * K * (K + 1) * sizeof(double);
   if (lds_m > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_mat_kernel<real>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
   hipLaunchKernelGGL(kl_shared_mat_kernel<real>, dim3(1), dim3(SM_BT), lds_m, st, Ln, Lo, Lp, N,
-                     K, coeff, include_cov, ws, nblk, out, gL);
+                     K, coeff, include_cov, ws, nblk, out, gL, par);
   TCE_LAUNCH_CHECK();
   return 0;
 }
@@ -216,13 +265,15 @@ extern "C" {
 
 int64_t tce_kl_shared_ws_len(int64_t N) { return 3 * ceil_div(N, KE_BT); }
 
+int64_t tce_surrogate_ws_len(void) { return 1 + 2 * SUR_MAX_BLOCKS; }
+
 int tce_surrogate_f32(const float* lp_new, const float* lp_old, const float* adv, int64_t M,
-                      float* out, float* grad_lp, void* stream) {
-  return surrogate<float>(lp_new, lp_old, adv, M, out, grad_lp, (hipStream_t)stream);
+                      float* out, float* grad_lp, double* ws, void* stream) {
+  return surrogate<float>(lp_new, lp_old, adv, M, out, grad_lp, ws, (hipStream_t)stream);
 }
 int tce_surrogate_f64(const double* lp_new, const double* lp_old, const double* adv, int64_t M,
-                      double* out, double* grad_lp, void* stream) {
-  return surrogate<double>(lp_new, lp_old, adv, M, out, grad_lp, (hipStream_t)stream);
+                      double* out, double* grad_lp, double* ws, void* stream) {
+  return surrogate<double>(lp_new, lp_old, adv, M, out, grad_lp, ws, (hipStream_t)stream);
 }
 int tce_kl_shared_f32(const float* mean_new, const float* mean_old, const float* mean_proj,
                       const float* L_new, const float* L_old, const float* L_proj, int64_t N,

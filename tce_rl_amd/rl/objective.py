@@ -53,6 +53,10 @@ class Context:
         self.tr_coeff = proj.trust_region_coeff
         self.tr_include_cov = int(pol.contextual_std or not agent.set_variance)
         self.ent_coef = float(agent.entropy_penalty_coef)
+        # surrogate kernel scratch: block ticket (zeroed once) + partials
+        self.sur_ws = torch.zeros(_lib.load().tce_surrogate_ws_len(),
+                                  dtype=torch.float64,
+                                  device=self.mean_old.device)
 
 
 class _Objective(torch.autograd.Function):
@@ -89,7 +93,7 @@ class _Objective(torch.autograd.Function):
         sur = new(2)
         glp = new(N, P)
         call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
-             N * P, ptr(sur), ptr(glp), st)
+             N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
         g_pm, g_pL = new(N, K), new(K, K)
         call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
              ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
