@@ -109,11 +109,104 @@ class MPExperiment:
             self.agent.save_agent(log_dir=self.save_model_dir, epoch=n + 1)
 
 
-def load_config(path):
-    """The experiment document of a (possibly multi-document) cw2 YAML."""
+def _deep_merge(base, over):
+    """`over` wins; dicts merge recursively (cw2 semantics for `params`)."""
+    out = copy.deepcopy(base)
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = _deep_merge(out[k], v)
+        else:
+            out[k] = copy.deepcopy(v)
+    return out
+
+
+def _set_path(d, dotted, value):
+    keys = dotted.split(".")
+    for k in keys[:-1]:
+        d = d.setdefault(k, {})
+    d[keys[-1]] = value
+
+
+def _expand(doc):
+    """cw2 `grid` (cartesian product) and `list` (zipped) sections -> one
+    experiment document per parameter combination; keys are dotted paths
+    below `params`."""
+    import itertools
+    doc = copy.deepcopy(doc)
+    grid, lst = doc.pop("grid", None), doc.pop("list", None)
+    combos = [{}]
+    if lst:
+        flat = _flatten(lst)
+        n = {len(v) for v in flat.values()}
+        assert len(n) == 1, "`list` entries must have the same length"
+        combos = [{k: v[i] for k, v in flat.items()} for i in range(n.pop())]
+    if grid:
+        flat = _flatten(grid)
+        keys = list(flat)
+        combos = [dict(c, **dict(zip(keys, vals))) for c in combos
+                  for vals in itertools.product(*(flat[k] for k in keys))]
+    out = []
+    for c in combos:
+        d = copy.deepcopy(doc)
+        for k, v in c.items():
+            _set_path(d.setdefault("params", {}), k, v)
+        if c:
+            d["_suffix"] = "_".join("%s%s" % (k.split(".")[-1], v)
+                                    for k, v in c.items())
+        out.append(d)
+    return out
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        key = prefix + k
+        if isinstance(v, dict):
+            out.update(_flatten(v, key + "."))
+        else:
+            out[key] = v
+    return out
+
+
+def load_experiments(path, exp_name=None):
+    """All experiment documents of a cw2 YAML file (the format of the
+    reference's mprl/config/*/*/*/{local,horeka,shared}.yaml), resolved the way
+    cw2 resolves them: a document named DEFAULT is merged under every other
+    one; ``import_path`` + ``import_exp`` pull an experiment from another file
+    (relative to this one) underneath the importing document; ``grid`` /
+    ``list`` sections expand into one document per combination.  YAML anchors
+    are handled by the parser.  Slurm documents are skipped."""
+    path = os.path.abspath(path)
     with open(path) as f:
         docs = [d for d in yaml.safe_load_all(f) if d]
+    default = {}
+    exps = []
     for d in docs:
+        name = d.get("name")
+        if name == "DEFAULT":
+            default = d
+        elif name == "SLURM":
+            continue
+        else:
+            exps.append(d)
+    out = []
+    for d in exps:
+        d = _deep_merge(default, d)
+        imp = d.pop("import_path", None)
+        imp_exp = d.pop("import_exp", None)
+        if imp is not None:
+            base = load_experiments(os.path.join(os.path.dirname(path), imp),
+                                    imp_exp)
+            assert base, "import_exp %r not found in %s" % (imp_exp, imp)
+            d = _deep_merge(base[0], d)
+        if exp_name is None or d.get("name") == exp_name:
+            out.extend(_expand(d))
+    return out
+
+
+def load_config(path, exp_name=None):
+    """The (first) experiment document of a cw2 YAML holding ``params``."""
+    for d in load_experiments(path, exp_name):
         if "params" in d:
             return d
     raise ValueError("no document with a `params` block in %s" % path)

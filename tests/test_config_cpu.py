@@ -1,0 +1,59 @@
+"""cw2-style YAML resolution of tce_rl_amd.mp_exp (import_path / import_exp,
+DEFAULT document, deep merge, grid / list expansion) -- SURVEY 8f(3)."""
+import os
+
+import pytest
+
+from tce_rl_amd import mp_exp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CFG = os.path.join(HERE, "golden", "cfg")
+
+
+def test_import_default_merge_and_expansion():
+    exps = mp_exp.load_experiments(os.path.join(CFG, "local.yaml"))
+    assert len(exps) == 4                     # 2 (list, zipped) x 2 (grid)
+    combos = set()
+    for e in exps:
+        p = e["params"]
+        assert e["name"] == "toy_tcp" and e["seed"] == "auto"        # DEFAULT
+        assert e["iterations"] == 7                                  # override
+        assert p["agent"]["args"]["total_iterations"] == 7
+        assert p["agent"]["args"]["epochs_policy"] == 50             # imported
+        assert p["agent"]["type"] == "TemporalCorrelatedAgent"
+        assert p["sampler"]["args"]["num_env_train"] == 4
+        assert p["policy"]["args"]["mp"]["args"]["num_dof"] == 4     # anchor
+        combos.add((p["agent"]["args"]["lr_policy"],
+                    p["mp"]["args"]["num_basis"], p["mp"]["args"]["tau"]))
+    assert combos == {(1e-4, 5, 3), (3e-4, 5, 3), (1e-4, 8, 5), (3e-4, 8, 5)}
+    cfg = mp_exp.load_config(os.path.join(CFG, "local.yaml"))
+    assert cfg["params"]["mp"]["args"]["num_basis"] == 5
+
+
+def test_named_experiment_and_plain_file():
+    shared = os.path.join(CFG, "shared.yaml")
+    assert mp_exp.load_config(shared, "other_exp")["params"]["agent"]["type"] \
+        == "BlackBoxAgent"
+    assert mp_exp.load_config(shared)["name"] == "toy_tcp"
+    assert mp_exp.load_config(shared)["iterations"] == 100
+
+
+REF = "/root/reference/mprl/config"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not here")
+def test_reference_config_files_resolve():
+    """The reference's own experiment files load unchanged (read as data)."""
+    n = 0
+    for root, _, files in os.walk(REF):
+        for f in files:
+            if f == "local.yaml":
+                cfg = mp_exp.load_config(os.path.join(root, f))
+                p = cfg["params"]
+                for blk in ("agent", "policy", "critic", "sampler",
+                            "projection", "mp"):
+                    assert "type" in p[blk] and "args" in p[blk], (root, blk)
+                assert p["agent"]["args"]["epochs_policy"] > 0
+                mp_exp.dim_policy_out(p)
+                n += 1
+    assert n >= 4
