@@ -55,5 +55,12 @@ def test_reference_config_files_resolve():
                     assert "type" in p[blk] and "args" in p[blk], (root, blk)
                 assert p["agent"]["args"]["epochs_policy"] > 0
                 mp_exp.dim_policy_out(p)
+                # every class the file names exists behind the factories
+                from tce_rl_amd.rl import agent, critic, policy, projection, \
+                    sampler
+                for mod, blk in ((agent, "agent"), (critic, "critic"),
+                                 (policy, "policy"), (sampler, "sampler"),
+                                 (projection, "projection")):
+                    assert hasattr(mod, p[blk]["type"]), (root, p[blk]["type"])
                 n += 1
     assert n >= 4
