@@ -130,7 +130,10 @@ def roofline(agent):
         "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
         "traffic": pmc_traffic("prodmp_traj_kernel"),
         "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
-        "note": "basis-table kernel + trajectory kernel"}}
+        "note": "trajectory kernel; the [T, 4+2(nb+1)] basis table "
+                "(one 10 us kernel) is built once per time grid and reused by "
+                "the ~100 trajectory / log-prob evaluations of a rollout + "
+                "update (ops._times_flags)"}}
     extra["gae_scan"] = gae
     return critic, extra
 

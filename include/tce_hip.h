@@ -90,11 +90,14 @@ int tce_segment_accrew_f64(const double* rewards, const int64_t* pairs, int P,
  * `tab` [M, 4 + 2*nbg]: host pre-computed table (y1, y2, dy1, dy2, scaled
  * position basis, scaled velocity basis) on a grid of step `scaled_dt` in
  * scaled time; nbg = num_basis + 1 <= 16; dof <= 8.
- * times [N,T]; times_general != 0: rows may differ arbitrarily (per-element
+ * times [N,T]; times_flags bit 0 set: rows may differ arbitrarily (per-element
  * basis evaluation); otherwise the rows are the sampler's affine grid and the
  * kernels share one basis table when all init_time are equal (checked on the
  * device, no host sync).  basis_ws: real [T, 4 + 2*nbg] workspace, flag_ws:
- * int[1] workspace.  out [N, T, 2*dof] = cat[pos, vel].
+ * int[1] workspace; times_flags bit 1 set: both already hold the table of
+ * exactly these times / init_time (left there by an earlier call: the table is
+ * not rebuilt -- one rollout or update evaluates the same grid ~100 times).
+ * out [N, T, 2*dof] = cat[pos, vel].
  */
 int tce_times_f32(const float* init_time, float off_first, float off_last,
                   float* times, int64_t N, int T, void* stream);
@@ -109,13 +112,13 @@ int tce_mvn_rsample_f64(const double* mean, const double* L, int64_t L_stride,
                         const double* eps, double* out, int64_t N, int K, void* stream);
 int tce_prodmp_traj_f32(const float* tab, int M, int nbg, float tau, float delay,
                         float scaled_dt, float inv_scale_g, int rel_goal,
-                        const float* times, int times_general, const float* params,
+                        const float* times, int times_flags, const float* params,
                         const float* init_time, const float* init_pos,
                         const float* init_vel, float* out, float* basis_ws,
                         int* flag_ws, int64_t N, int T, int dof, void* stream);
 int tce_prodmp_traj_f64(const double* tab, int M, int nbg, double tau, double delay,
                         double scaled_dt, double inv_scale_g, int rel_goal,
-                        const double* times, int times_general, const double* params,
+                        const double* times, int times_flags, const double* params,
                         const double* init_time, const double* init_pos,
                         const double* init_vel, double* out, double* basis_ws,
                         int* flag_ws, int64_t N, int T, int dof, void* stream);
@@ -138,21 +141,21 @@ int tce_pair_logprob_fwd_f32(
     const float* traj, const float* mean, const float* L, int64_t L_stride,
     const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
     float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
-    int times_general, const float* init_time, const float* init_pos,
+    int times_flags, const float* init_time, const float* init_pos,
     const float* init_vel, float reg, float* logp, float* basis_ws, int* flag_ws,
     float* work, int64_t N, int T, int P, int dof, void* stream);
 int tce_pair_logprob_fwd_f64(
     const double* traj, const double* mean, const double* L, int64_t L_stride,
     const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
     double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
-    int times_general, const double* init_time, const double* init_pos,
+    int times_flags, const double* init_time, const double* init_pos,
     const double* init_vel, double reg, double* logp, double* basis_ws, int* flag_ws,
     double* work, int64_t N, int T, int P, int dof, void* stream);
 int tce_pair_logprob_bwd_f32(
     const float* traj, const float* mean, const float* L, int64_t L_stride,
     const int64_t* pairs, const float* tab, int M, int nbg, float tau, float delay,
     float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
-    int times_general, const float* init_time, const float* init_pos,
+    int times_flags, const float* init_time, const float* init_pos,
     const float* init_vel, float reg, const float* grad_logp, float* grad_mean,
     float* grad_L, float* basis_ws, int* flag_ws, float* work, int64_t N, int T, int P,
     int dof, void* stream);
@@ -160,7 +163,7 @@ int tce_pair_logprob_bwd_f64(
     const double* traj, const double* mean, const double* L, int64_t L_stride,
     const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
     double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
-    int times_general, const double* init_time, const double* init_pos,
+    int times_flags, const double* init_time, const double* init_pos,
     const double* init_vel, double reg, const double* grad_logp, double* grad_mean,
     double* grad_L, double* basis_ws, int* flag_ws, double* work, int64_t N, int T,
     int P, int dof, void* stream);

@@ -567,9 +567,11 @@ template <typename real>
 int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64_t sL,
               const int64_t* pairs, const real* tab, int M, int nbg, real tau, real delay,
               real scaled_dt, real inv_scale_g, int rel_goal, const real* times,
-              int times_general, const real* t0, const real* y0, const real* v0, real reg,
+              int times_flags, const real* t0, const real* y0, const real* v0, real reg,
               real* logp, const real* gout, real* gmean, real* gL, real* B, int* flag,
               real* work, int64_t N, int T, int P, int dof, hipStream_t stream) {
+  const int times_general = times_flags & 1;
+  const bool basis_ready = (times_flags & 2) != 0;     // B / flag hold this time grid already
   TCE_CHECK_ARG(traj && mean && L && pairs && tab && times && t0 && y0 && v0 && B && flag,
                 "pair_logprob: null buffer");
   TCE_CHECK_ARG(bwd ? (gout && gmean && gL) : (logp != nullptr), "pair_logprob: null output");
@@ -579,9 +581,11 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   const int K = dof * nbg;
   TCE_CHECK_ARG(K <= 64, "pair_logprob: dof * (num_basis + 1) must be <= 64");
   MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
-  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)),
-                     dim3(256), 0, stream, mp, times, t0, N, T, B, flag);
-  TCE_LAUNCH_CHECK();
+  if (!basis_ready) {
+    hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)),
+                       dim3(256), 0, stream, mp, times, t0, N, T, B, flag);
+    TCE_LAUNCH_CHECK();
+  }
   // ---- shared-L fast path (kernels self-disable if the init times differ)
   // workspace carve (shared L only): fast-path scratch | per-env dL | sum scratch
   PFShape f{K, 2 * dof, P, nbg, dof};

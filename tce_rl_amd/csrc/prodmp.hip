@@ -138,10 +138,12 @@ __global__ __launch_bounds__(256) void prodmp_traj_kernel(
 
 template <typename real>
 int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scaled_dt,
-                real inv_scale_g, int rel_goal, const real* times, int times_general,
+                real inv_scale_g, int rel_goal, const real* times, int times_flags,
                 const real* w, const real* t0, const real* y0, const real* v0,
                 real* out, real* B, int* flag, int64_t N, int T, int dof,
                 hipStream_t stream) {
+  const int times_general = times_flags & 1;
+  const bool basis_ready = (times_flags & 2) != 0;     // B / flag hold this time grid already
   TCE_CHECK_ARG(tab && times && w && t0 && y0 && v0 && out && B && flag,
                 "prodmp_traj: null buffer");
   TCE_CHECK_ARG(N > 0 && T > 0 && M >= 2, "prodmp_traj: bad sizes");
@@ -149,9 +151,11 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
   TCE_CHECK_ARG(dof >= 1 && dof <= 8, "prodmp_traj: num_dof must be <= 8");
   MPParams<real> mp{tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal};
   const int tb = (int)ceil_div(T, 256);
-  hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0,
-                     stream, mp, times, t0, N, T, B, flag);
-  TCE_LAUNCH_CHECK();
+  if (!basis_ready) {
+    hipLaunchKernelGGL(prodmp_basis_kernel<real>, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0,
+                       stream, mp, times, t0, N, T, B, flag);
+    TCE_LAUNCH_CHECK();
+  }
   // ~2048 workgroups: each keeps its basis rows for `epb` envs
   const bool half = (dof == 4);
   const int txb = (int)ceil_div((int64_t)T * (half ? 2 : 1), 256);

@@ -221,19 +221,35 @@ def _mp_ws(mp, T, device):
                           device=device),
               torch.zeros(1, dtype=torch.int32, device=device))
         mp._ws = ws
+        mp._ws_key = None               # a fresh table: nothing cached
     return ws
+
+
+def _times_flags(mp, times_, init_time):
+    """bit 0: general (non-affine) time rows; bit 1: the basis table in the
+    mp's workspace was built for exactly these two tensors (same objects, not
+    modified since), so the kernels need not rebuild it."""
+    import weakref
+    general = 0 if getattr(times_, "_tce_affine", False) else 1
+    key = getattr(mp, "_ws_key", None)
+    sig = (times_._version, init_time._version, times_.shape)
+    ready = key is not None and key[0]() is times_ and key[1]() is init_time \
+        and key[2] == sig and getattr(mp, "_ws", None) is not None \
+        and mp._ws[0].shape[0] >= times_.shape[1]
+    mp._ws_key = (weakref.ref(times_), weakref.ref(init_time), sig)
+    return general | (2 if ready else 0)
 
 
 def prodmp_traj(mp, times_, params, init_time, init_pos, init_vel):
     """cat[pos, vel] [N, T, 2*dof] of the ProDMP with parameters [N, K]."""
     check_dev(times_, params, init_time, init_pos, init_vel)
-    general = 0 if getattr(times_, "_tce_affine", False) else 1
     t, p = _c(times_), _c(mp.pad_params(params))
     t0, y0, v0 = _c(init_time), _c(init_pos), _c(init_vel)
     N, T = t.shape
     assert p.shape == (N, mp.num_dof * mp.num_basis_g)
     out = torch.empty(N, T, 2 * mp.num_dof, dtype=p.dtype, device=p.device)
     B, flag = _mp_ws(mp, T, p.device)
+    general = _times_flags(mp, t, t0)
     call("tce_prodmp_traj_" + sfx(p.dtype), *mp.c_args(), ptr(t), general,
          ptr(p), ptr(t0), ptr(y0), ptr(v0), ptr(out), ptr(B), ptr(flag), N, T,
          mp.num_dof, stream())
@@ -257,6 +273,7 @@ class _PairLogProb(torch.autograd.Function):
         logp = torch.empty(N, P, dtype=mean.dtype, device=mean.device)
         B, flag = _mp_ws(mp, T, mean.device)
         work = _pl_work(mean, N, P, mp, sL, False)
+        general = (general & 1) | (_times_flags(mp, times_, t0) & 2)
         call("tce_pair_logprob_fwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
              ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), general,
              ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(logp), ptr(B),
@@ -277,8 +294,9 @@ class _PairLogProb(torch.autograd.Function):
                          device=mean.device)
         B, flag = _mp_ws(mp, T, mean.device)
         work = _pl_work(mean, N, P, mp, sL, True)
+        general = (ctx.general & 1) | (_times_flags(mp, times_, t0) & 2)
         call("tce_pair_logprob_bwd_" + sfx(mean.dtype), ptr(traj), ptr(mean),
-             ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), ctx.general,
+             ptr(Lc), sL, ptr(pairs), *mp.c_args(), ptr(times_), general,
              ptr(t0), ptr(y0), ptr(v0), mp.cov_reg, ptr(g), ptr(gmean),
              ptr(gL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof,
              stream())
@@ -292,10 +310,11 @@ def pair_log_prob(mp, traj, mean, L, times_, init_time, init_pos, init_vel,
     check_dev(traj, mean, L, times_, init_time, init_pos, init_vel, pred_pairs)
     assert not (mp.disable_goal or mp.disable_weights), \
         "pair log-prob needs the full [weights, goal] parameterisation"
-    general = 0 if getattr(times_, "_tce_affine", False) else 1
     Lc, sL = split_L(L)
-    return _PairLogProb.apply(_c(mean), Lc, sL, mp, _c(traj), _c(times_),
-                              general, _c(init_time), _c(init_pos),
+    times_, init_time = _c(times_), _c(init_time)
+    general = 0 if getattr(times_, "_tce_affine", False) else 1
+    return _PairLogProb.apply(_c(mean), Lc, sL, mp, _c(traj), times_,
+                              general, init_time, _c(init_pos),
                               _c(init_vel), _c(pred_pairs.to(torch.int64)))
 
 

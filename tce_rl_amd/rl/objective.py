@@ -84,9 +84,11 @@ class _Objective(torch.autograd.Function):
         logp = new(N, P)
         B, flag = ops._mp_ws(mp, T, dev)
         work = ops._pl_work(mean_new, N, P, mp, 0, True)
-        pl_args = (ptr(c.traj), ptr(pm), ptr(pL), 0, ptr(c.pairs),
-                   *mp.c_args(), ptr(c.times), c.general, ptr(c.t0),
-                   ptr(c.y0), ptr(c.v0), mp.cov_reg)
+        flags = c.general | (ops._times_flags(mp, c.times, c.t0) & 2)
+        pl = lambda f: (ptr(c.traj), ptr(pm), ptr(pL), 0, ptr(c.pairs),
+                        *mp.c_args(), ptr(c.times), f, ptr(c.t0), ptr(c.y0),
+                        ptr(c.v0), mp.cov_reg)
+        pl_args = pl(flags)
         call("tce_pair_logprob_fwd_" + s, *pl_args, ptr(logp), ptr(B),
              ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
         # ---- surrogate loss and d/d logp
@@ -95,6 +97,7 @@ class _Objective(torch.autograd.Function):
         call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
              N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
         g_pm, g_pL = new(N, K), new(K, K)
+        pl_args = pl(c.general | 2)         # the forward call left the table
         call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
              ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
         # ---- KL diagnostics, entropy, trust region loss (+ its gradients)

@@ -239,3 +239,45 @@ def test_pair_logprob_c2_size_properties(ops):
                         Lsh.expand(8, -1, -1), times_cpu, t0[sl], y0[sl],
                         v0[sl], pairs)
     torch.testing.assert_close(lp_shared.cpu()[sl], ref, rtol=1e-5, atol=2e-4)
+
+
+def test_basis_table_cache_is_invalidated_by_new_or_modified_times():
+    """ops.prodmp_traj reuses the basis table only for the very same (unmodified)
+    times / init-time tensors."""
+    import torch
+    from tce_rl_amd import ops
+    from tce_rl_amd.mp import ProDMP
+    mp = ProDMP(dtype=torch.float32, device="cuda", num_dof=4, num_basis=5,
+                tau=5, alpha_phase=3, alpha=10, dt=0.0125,
+                basis_bandwidth_factor=5, weights_scale=0.1, goal_scale=0.1,
+                relative_goal=True)
+    N, T = 300, 500
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w = 0.1 * torch.randn(N, 24, device="cuda", generator=g)
+    y0 = torch.rand(N, 4, device="cuda", generator=g)
+    v0 = torch.zeros(N, 4, device="cuda")
+    t0 = torch.zeros(N, device="cuda")
+    times = ops.times(t0, mp.dt, T)
+    a = ops.prodmp_traj(mp, times, w, t0, y0, v0)
+    assert not (ops._times_flags(mp, torch.empty_like(times), t0) & 2)
+    ops.prodmp_traj(mp, times, w, t0, y0, v0)
+    assert ops._times_flags(mp, times, t0) & 2            # same objects: cached
+    b = ops.prodmp_traj(mp, times, w, t0, y0, v0)
+    assert torch.equal(a, b)
+    # a different init time (new tensors) must rebuild the table
+    t1 = torch.full((N,), 0.25, device="cuda")
+    times1 = ops.times(t1, mp.dt, T)
+    c = ops.prodmp_traj(mp, times1, w, t1, y0, v0)
+    mp2 = ProDMP(dtype=torch.float32, device="cuda", num_dof=4, num_basis=5,
+                 tau=5, alpha_phase=3, alpha=10, dt=0.0125,
+                 basis_bandwidth_factor=5, weights_scale=0.1, goal_scale=0.1,
+                 relative_goal=True)
+    c_ref = ops.prodmp_traj(mp2, times1, w, t1, y0, v0)
+    assert torch.equal(c, c_ref) and not torch.equal(a, c)
+    # in-place modification bumps the version: rebuilt as well
+    t1.add_(0.25)
+    times2 = ops.times(t1, mp.dt, T)
+    times1.copy_(times2)
+    d = ops.prodmp_traj(mp, times1, w, t1, y0, v0)
+    d_ref = ops.prodmp_traj(mp2, times2, w, t1, y0, v0)
+    assert torch.equal(d, d_ref)
