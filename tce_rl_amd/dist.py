@@ -36,7 +36,10 @@ class DistContext:
         if self._aux_group is None:
             ranks = dist.get_process_group_ranks(self.group) \
                 if self.group is not None else list(range(self.world))
-            self._aux_group = dist.new_group(ranks=ranks)
+            try:
+                self._aux_group = dist.new_group(ranks=ranks)
+            except Exception:            # no second communicator: share one
+                self._aux_group = self.group   # (collectives serialise, still correct)
         return self._aux_group
 
     def allreduce_grads(self, params):
