@@ -161,3 +161,105 @@ class OracleTCE:
             total.backward()
             self.p_opt.step()
         return N * T
+
+
+class OracleBBRL:
+    """CPU restatement of one ``BlackBoxAgent.step()``: episode-level policy
+    (param-space Gaussian, diagonal or full), the env turns the sampled MP
+    parameters into a trajectory and an episode return, advantage R - V(s0),
+    critic regresses the return, trust-region projected policy update.
+    Follows ``mprl/rl/agent/black_box_agent.py:34-389`` and
+    ``mprl/rl/sampler/black_box_sampler.py:158-249``.  Test infrastructure."""
+
+    def __init__(self, mp_args, num_env, dim_obs, policy_hidden, critic_hidden,
+                 act, std_only, min_std, out_layer_gain, lr, epochs, mean_bound,
+                 cov_bound, tr_coeff, set_variance, norm_advantages=True,
+                 clip_advantages=0.0, clip_critic=0.0, dtype=torch.float32):
+        mpa = dict(mp_args)
+        mpa.pop("dtype", None), mpa.pop("device", None)
+        self.mp = ProDMPOracle(dtype=dtype, **mpa)
+        self.dof, self.K = self.mp.num_dof, self.mp.num_dof * self.mp.num_basis_g
+        self.N, self.dt, self.dtype = num_env, self.mp.dt, dtype
+        self.T = {0.0125: 500, 0.02: 100, 0.008: 350}[self.dt]
+        self.D = dim_obs
+        mk = lambda hid, d_out, gain: torch.nn.ParameterList(
+            [torch.nn.Parameter(t) for Wb in O.mlp_init(dim_obs, d_out, hid,
+                                                       gain, dtype) for t in Wb])
+        self.act = act
+        self.pnet = mk(policy_hidden, self.K, out_layer_gain)
+        self.cnet = mk(critic_hidden, 1, 1.0)
+        self.std_only, self.min_std = std_only, float(min_std)
+        self.var = torch.nn.Parameter(
+            O.initial_variance_vector(self.K, std_only, dtype))
+        self.p_opt = torch.optim.Adam(list(self.pnet) + [self.var], lr=lr)
+        self.c_opt = torch.optim.Adam(list(self.cnet), lr=lr)
+        self.epochs = epochs
+        self.mean_bound, self.cov_bound = mean_bound, cov_bound
+        self.tr_coeff, self.set_variance = tr_coeff, set_variance
+        self.norm_advantages, self.clip_advantages = norm_advantages, \
+            clip_advantages
+        self.clip_critic = clip_critic
+        self.forced_reset = self.forced_eps = None
+        self.last = {}
+
+    def _mlp(self, net, x):
+        ps = list(net)
+        return O.mlp_forward([(ps[i], ps[i + 1]) for i in range(0, len(ps), 2)],
+                             x, self.act)
+
+    def _policy(self, obs):
+        L = O.vector_to_cholesky(self.var[None], self.K, self.min_std,
+                                 self.std_only).expand(obs.shape[0], -1, -1)
+        return self._mlp(self.pnet, obs), L
+
+    def step(self):
+        N, T = self.N, self.T
+        goal, pos0 = self.forced_reset
+        with torch.no_grad():
+            obs = torch.zeros(N, self.D, dtype=self.dtype)
+            obs[:, :self.dof] = goal
+            obs[:, self.dof:2 * self.dof] = pos0
+            mean_old, L_old = self._policy(obs)
+            action = O.mvn_rsample(mean_old, L_old, self.forced_eps)
+            lp_old = O.mvn_log_prob(action, mean_old, L_old)
+            values = self._mlp(self.cnet, obs).squeeze(-1)
+            t0 = torch.zeros(N, dtype=self.dtype)
+            v0 = torch.zeros(N, self.dof, dtype=self.dtype)
+            pos, vel = self.mp.traj(O.get_times(t0, self.dt, T), action, t0,
+                                    pos0, v0)
+            reward = (-((pos - goal[:, None]) ** 2).sum(-1)
+                      - 1e-3 * (vel ** 2).sum(-1)).sum(-1)
+            adv = O.bbrl_advantage(reward, values, self.norm_advantages,
+                                   self.clip_advantages)
+        self.last = dict(segment_action=action, segment_log_prob=lp_old,
+                         segment_value=values, segment_reward=reward,
+                         segment_advantage=adv)
+        no_beta = torch.tensor(-float("inf"), dtype=self.dtype)  # no entropy control
+        for _ in range(self.epochs):
+            v = self._mlp(self.cnet, obs).squeeze(-1)
+            loss = O.value_loss(v, reward, values, self.clip_critic)
+            self.c_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            self.c_opt.step()
+        for _ in range(self.epochs):
+            mean_new, L_new = self._policy(obs)
+            pm, pL = KO.project(mean_new, L_new, mean_old, L_old,
+                                self.mean_bound, self.cov_bound, no_beta,
+                                contextual_std=False)
+            lp = O.mvn_log_prob(action, pm, pL)
+            s_loss, _ = O.surrogate_loss(adv, lp, lp_old)
+            tr = KO.trust_region_loss(mean_new, L_new, pm, pL, self.tr_coeff,
+                                      not self.set_variance)
+            total = s_loss + tr
+            self.p_opt.zero_grad(set_to_none=True)
+            total.backward()
+            self.p_opt.step()
+        if self.set_variance:            # black_box_agent.py:377-386
+            with torch.no_grad():
+                m, L = self._policy(obs)
+                _, pL = KO.project(m, L, mean_old, L_old, self.mean_bound,
+                                   self.cov_bound, no_beta,
+                                   contextual_std=False)
+                self.var.copy_(O.cholesky_to_vector(pL[:1], self.min_std,
+                                                    self.std_only)[0])
+        return N * T
