@@ -649,30 +649,33 @@ struct AdamArgs {
   float lr, b1, b2, eps, wd, step;       // step = count INCLUDING this update
 };
 
-// grad[p] = sum over the workgroup slabs (fixed order: 4 interleaved groups of
-// slabs, then the groups); stats[0] = mean loss, stats[1] += |grad|^2 (the caller
+// grad[p] = sum over the workgroup slabs (fixed order: FIN_GROUPS interleaved
+// groups of slabs, then the groups); stats[0] = mean loss, stats[1] += |grad|^2 (the caller
 // zeroes stats); with ad.param the Adam update of torch.optim.Adam (L2 weight
 // decay in the gradient, mprl/rl/agent/abstract_agent.py:62-82) is applied in
 // the same pass.
-__global__ __launch_bounds__(256) void mlp_finish_kernel(const float* __restrict__ partials,
-                                                         int nparts, int P, int64_t R,
-                                                         float* __restrict__ grad,
-                                                         float* __restrict__ stats, AdamArgs ad) {
-  __shared__ float part[4][64];
-  __shared__ float red[4];
+constexpr int FIN_GROUPS = 16;          // slab groups summed in parallel per column
+
+__global__ __launch_bounds__(64 * FIN_GROUPS) void mlp_finish_kernel(
+    const float* __restrict__ partials, int nparts, int P, int64_t R, float* __restrict__ grad,
+    float* __restrict__ stats, AdamArgs ad) {
+  __shared__ float part[FIN_GROUPS][64];
+  __shared__ float red[FIN_GROUPS];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + col;
   float s = 0.f;
   if (p < P + 1) {
     const float* src = partials + p;
-#pragma unroll 8
-    for (int i = grp; i < nparts; i += 4) s += src[(int64_t)i * (P + 2)];
+#pragma unroll 4
+    for (int i = grp; i < nparts; i += FIN_GROUPS) s += src[(int64_t)i * (P + 2)];
   }
   part[grp][col] = s;
   __syncthreads();
   float sq = 0.f;
   if (grp == 0 && p < P + 1) {
-    const float g0 = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    float g0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < FIN_GROUPS; ++k) g0 += part[k][col];   // fixed order
     if (p < P) {
       grad[p] = g0;
       sq = g0 * g0;
@@ -780,8 +783,8 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
     const int P = mlp_num_params(din);
     AdamArgs ad{adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps, weight_decay,
                 adam_step};
-    hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)), dim3(256), 0,
-                       st, partials, grid, P, R, grad, stats, ad);
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
+                       dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
     TCE_LAUNCH_CHECK();
   }
   return 0;
