@@ -10,6 +10,10 @@ ps = cnt.most_common(1)[0][0]
 rows = [r for r in rows if r[3] == ps]
 idx = [i for i, r in enumerate(rows) if "adam_apply" in r[0]]
 a, b = idx[-3], idx[-2]
-print("kernels in the epoch:", b - a)
-for n, s, e, st, gx, wx in rows[a + 1:b + 1]:
-    print(f"{(e - s) / 1e3:7.1f} us  grid {gx // max(wx,1):6d} x {wx:4d}  {n[:110]}")
+seg = rows[a + 1:b + 1]
+busy = sum(e - s for _, s, e, *_ in seg)
+print("kernels in the epoch:", b - a, " busy %.1f us  span %.1f us" % (busy / 1e3, (seg[-1][2] - rows[a][2]) / 1e3))
+prev = rows[a][2]
+for n, s, e, st, gx, wx in seg:
+    print(f"gap {(s - prev) / 1e3:6.1f}  {(e - s) / 1e3:7.1f} us  grid {gx // max(wx,1):6d} x {wx:4d}  {n[:100]}")
+    prev = e
