@@ -274,3 +274,26 @@ def test_fused_objective_reports_the_same_metrics():
         if k == "projection_time":
             continue
         assert a[k] == pytest.approx(b[k], rel=2e-3, abs=2e-6), k
+
+
+def test_training_improves_reward_within_the_trust_region():
+    """A short training run on the synthetic reach-like task: the exploration
+    reward rises steadily while every update stays inside the KL bounds."""
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    cfg = tce_config("metaworld", num_env=256, num_basis=5, epochs=20,
+                     evaluation_interval=0, iterations=40)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    rewards, covs, means = [], [], []
+    for i in range(40):
+        res = exp.iterate(cfg, 0, i)
+        rewards.append(res["exploration_episode_reward_mean"])
+        covs.append(res["projection_proj_old_cov_diff_max"])
+        means.append(res["projection_proj_old_mean_diff_max"])
+        assert np.isfinite(res["policy_loss_mean"])
+    p = cfg["params"]["projection"]["args"]
+    assert max(covs) <= p["cov_bound"] * 1.02
+    assert max(means) <= p["mean_bound"] * 1.02
+    assert np.mean(rewards[-5:]) > 0.6 * np.mean(rewards[:5])   # rewards are < 0
+    assert rewards[-1] > rewards[0]
