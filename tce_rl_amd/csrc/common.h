@@ -38,6 +38,40 @@ __device__ inline T wave_sum(T v) {
   return v;
 }
 
+// ---- cross-lane sums of doubles on the VALU (DPP / permlane swaps) instead of
+// LDS-routed shuffles: a double __shfl_xor is two ds_bpermute round trips.
+template <int CTRL>
+__device__ inline double dpp_perm_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over each aligned group of 8 lanes (all 8 get it)
+__device__ inline double dpp_sum8(double v) {
+  v += dpp_perm_f64<0x141>(v);          // row_half_mirror: lane i <-> 7 - i
+  v += dpp_perm_f64<0x4E>(v);           // quad_perm [2,3,0,1]
+  v += dpp_perm_f64<0xB1>(v);           // quad_perm [1,0,3,2]
+  return v;
+}
+// sum over the 64 lanes of a wave (all lanes get it)
+__device__ inline double wave_sum_f64(double v) {
+  v = dpp_sum8(v);
+  v += dpp_perm_f64<0x140>(v);          // row_mirror: the other 8-group of the row
+  {                                     // rows l ^ 16, then l ^ 32 (gfx950 swaps)
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  }
+  return v;
+}
+
 // Block-wide sum through LDS scratch (>= blockDim/64 entries); result valid in
 // every thread.  Deterministic order.
 template <typename T>

@@ -222,7 +222,7 @@ __device__ inline double klp_h(double eta, double lam, bool live) {
     const double mu = (eta + 1.0) * lam / (eta * lam + 1.0);
     t = mu - 1.0 - log(mu);
   }
-  return 0.5 * wave_sum(t);
+  return 0.5 * wave_sum_f64(t);
 }
 
 template <typename real>
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
           t = mu - 1.0 - log(mu);
           dt = (1.0 - 1.0 / mu) * lm * (1.0 - lm) * w * w;
         }
-        const double hv = 0.5 * wave_sum(t) - eps;
-        const double dh = 0.5 * wave_sum(dt);
+        const double hv = 0.5 * wave_sum_f64(t) - eps;
+        const double dh = 0.5 * wave_sum_f64(dt);
         if (hv > 0) lo = eta_n; else hi = eta_n;
         double nxt = eta_n - hv / dh;
         if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);

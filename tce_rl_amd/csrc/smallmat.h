@@ -139,32 +139,37 @@ __device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* f
         else { p = (r + pair) % (KE - 1); q = (r - pair + KE - 1) % (KE - 1); }
         if (p >= K || q >= K) { p = -1; q = -1; }   // bye
       }
+      // this lane's elements k = l8, l8 + 8, ... of both rows stay in registers
+      // for the dot products and the rotation (K <= 64: at most 8 each)
+      double xa[8], ya[8];
       double al = 0, be = 0, ga = 0;
-      if (p >= 0) {
-        for (int k = l8; k < K; k += 8) {
-          const double x = A[p * KP + k], y = A[q * KP + k];
-          al += x * x; be += y * y; ga += x * y;
-        }
-      }
 #pragma unroll
-      for (int off = 4; off > 0; off >>= 1) {
-        al += __shfl_xor(al, off, 8);
-        be += __shfl_xor(be, off, 8);
-        ga += __shfl_xor(ga, off, 8);
+      for (int i = 0; i < 8; ++i) {
+        const int k = l8 + 8 * i;
+        const bool ok = p >= 0 && k < K;
+        xa[i] = ok ? A[p * KP + k] : 0.0;
+        ya[i] = ok ? A[q * KP + k] : 0.0;
+        al += xa[i] * xa[i]; be += ya[i] * ya[i]; ga += xa[i] * ya[i];
       }
+      al = dpp_sum8(al);
+      be = dpp_sum8(be);
+      ga = dpp_sum8(ga);
       // relative off-diagonal tolerance: eigenvalues to ~1e-13 relative (the
       // bound is 5e-4 .. 5e-2; a tighter test only chases rounding noise)
       if (p >= 0 && fabs(ga) > 1e-13 * sqrt(al * be) && ga != 0.0) {
         const double zeta = (be - al) / (2.0 * ga);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int k = l8; k < K; k += 8) {
-          const double x = A[p * KP + k], y = A[q * KP + k];
-          A[p * KP + k] = c * x - s * y;
-          A[q * KP + k] = s * x + c * y;
-          const double u = Vt[p * KP + k], v = Vt[q * KP + k];
-          Vt[p * KP + k] = c * u - s * v;
-          Vt[q * KP + k] = s * u + c * v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = l8 + 8 * i;
+          if (k < K) {
+            A[p * KP + k] = c * xa[i] - s * ya[i];
+            A[q * KP + k] = s * xa[i] + c * ya[i];
+            const double u = Vt[p * KP + k], v = Vt[q * KP + k];
+            Vt[p * KP + k] = c * u - s * v;
+            Vt[q * KP + k] = s * u + c * v;
+          }
         }
         if (l8 == 0) *flag = 1;
       }
