@@ -33,10 +33,12 @@
 //    interleaved (column 8 c + n, row 32 wave + 2 c + rb), all conflict free.
 //  * db1 comes out of the dW1 MFMAs through a column of ones appended to X.
 //
-// Work decomposition: a workgroup = 4 waves = 64 batch rows per tile (16 per
-// wave), persistent over its share of the tiles; weight-gradient accumulators
-// stay in registers across tiles; one partial slab per workgroup at the end,
-// reduced by mlp_reduce_kernel.  MFMA-bound: 944 MFMAs per wave and tile.
+// Work decomposition: 64 batch rows per tile (16 per chain wave), workgroups
+// persistent over their share of the tiles.  Forward only: 4 waves.  Forward +
+// backward: 8 waves in two roles (see mlp_critic_bwd_kernel); the weight-
+// gradient accumulators stay in registers across tiles, one partial slab per
+// workgroup at the end, reduced (and fed to Adam) by mlp_finish_kernel.
+// MFMA-bound: 944 MFMAs per SIMD and tile.
 #include "common.h"
 
 namespace {
