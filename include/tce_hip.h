@@ -299,6 +299,19 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
                       int K, double tr_coeff, int tr_include_cov, double* out16,
                       double* grad_mean, double* grad_L, double* ws, void* stream);
 
+/* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
+ * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->
+ * mprl/util/util_nn.py:225-246) -- on the kernels of the fused critic epoch.
+ * grad_hidden == NULL: forward, hidden_out [R][128].  Otherwise backward of
+ * dL/dH2 = grad_hidden [R][128] (forward recomputed): grad [tce_mlp_critic_
+ * num_params(din)] receives dW1, db1, dW2, db2 in that order (trailing w3 / b3
+ * slots zero); partials as above; stats float[2] scratch zeroed by the caller. */
+int tce_mlp_hidden_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                       int64_t R, int din, const float* w1, const float* b1,
+                       const float* w2, const float* b2, int act, const float* grad_hidden,
+                       float* hidden_out, float* partials, float* grad, float* stats,
+                       void* stream);
+
 /* ---- optimizer: flat Adam with global-norm clipping -----------------------
  * One optimizer step over a flat parameter buffer of n elements:
  *   grad_norm_clip(clip, params)   mprl/util/util_numerical.py:244-275

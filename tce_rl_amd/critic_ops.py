@@ -106,3 +106,56 @@ class EpochRunner:
         for p, v in zip(self.params, self.views):
             p.grad = v
         return stats
+
+
+# ---------------------------------------------------------------------------
+# hidden layers of a wider-output net (policy mean net) on the same kernels
+# ---------------------------------------------------------------------------
+def hidden_supported(mlp, x):
+    return (mlp.dtype == torch.float32 and list(mlp.hidden_layers) == [128, 128]
+            and 1 <= mlp.dim_in <= 40 and mlp.act_func_hidden_type in _ACT
+            and x.is_cuda and x.dtype == torch.float32)
+
+
+class _Hidden2(torch.autograd.Function):
+    """h2 = act(W2 act(W1 x + b1) + b2) for x [R, D_in]; backward recomputes the
+    forward inside the fused kernel and returns dW1, db1, dW2, db2."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        xs, es, rs, T, R = _rows(x)
+        out = torch.empty(R, 128, dtype=torch.float32, device=x.device)
+        call("tce_mlp_hidden_f32", ptr(xs), es, rs, T, R, x.shape[-1], ptr(w1),
+             ptr(b1), ptr(w2), ptr(b2), act, None, ptr(out), None, None, None,
+             stream())
+        ctx.save_for_backward(xs, w1, b1, w2, b2)
+        ctx.geom = (es, rs, T, R, x.shape[-1], act)
+        return out.reshape(*x.shape[:-1], 128)
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, w1, b1, w2, b2 = ctx.saved_tensors
+        es, rs, T, R, din, act = ctx.geom
+        lib = _lib.load()
+        P = lib.tce_mlp_critic_num_params(din)
+        dev = g.device
+        g = g.reshape(R, 128)
+        g = g if g.is_contiguous() else g.contiguous()
+        partials = torch.empty(min(lib.tce_mlp_critic_grid(), (R + 63) // 64),
+                               P + 2, dtype=torch.float32, device=dev)
+        grad = torch.empty(P, dtype=torch.float32, device=dev)
+        stats = torch.zeros(2, dtype=torch.float32, device=dev)
+        call("tce_mlp_hidden_f32", ptr(xs), es, rs, T, R, din, ptr(w1), ptr(b1),
+             ptr(w2), ptr(b2), act, ptr(g), None, ptr(partials), ptr(grad),
+             ptr(stats), stream())
+        o1, o2, o3 = 128 * din, 128 * din + 128, 128 * din + 128 + 128 * 128
+        return (None, grad[:o1].view(128, din), grad[o1:o2],
+                grad[o2:o3].view(128, 128), grad[o3:o3 + 128], None)
+
+
+def hidden_forward(mlp, x):
+    """Activations of the second hidden layer [..., 128] (differentiable w.r.t.
+    the four hidden-layer parameters, not w.r.t. x)."""
+    ls = mlp.layers
+    return _Hidden2.apply(x, ls[0].weight, ls[0].bias, ls[1].weight,
+                          ls[1].bias, _ACT[mlp.act_func_hidden_type])

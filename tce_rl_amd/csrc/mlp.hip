@@ -111,6 +111,11 @@ struct MlpArgs {
   float clip;            // clip_critic (<= 0: plain MSE)
   float* values;         // forward output [R] (nullable)
   float* partials;       // [gridDim.x][P + 2] gradient slabs (+ loss sum, count) (nullable: forward only)
+  // "hidden" mode (the two hidden layers of a wider-output net, e.g. the policy
+  // mean net): forward stores H2 [R][HID] instead of the value, backward takes
+  // dL/dH2 [R][HID] instead of the value loss; w3 / b3 are not used.
+  float* hout;
+  const float* gh;
 };
 
 __host__ __device__ inline int mlp_num_params(int din) {
@@ -144,7 +149,7 @@ __device__ inline void stage_weights(const MlpArgs& a, const Lds<KPGE>& L, int t
   for (int e = tid; e < HID; e += nthreads) {
     L.Bs[e] = a.b1[u1_of(e)];
     L.Bs[HID + e] = a.b2[e];
-    L.Bs[2 * HID + e] = a.w3[e];
+    L.Bs[2 * HID + e] = a.w3 ? a.w3[e] : 0.f;
   }
 }
 
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_fwd_kernel(MlpArgs a) {
   const int c = lane & 15, g = lane >> 4;
   stage_weights<KPGE>(a, L, tid, MLP_BT);
   __syncthreads();
-  const float b3 = a.b3[0];
+  const float b3 = a.hout ? 0.f : a.b3[0];
   const int64_t ntiles = (a.R + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
   RowCursor cur(a, blockIdx.x, wave, c);
   float xn[KPGE];
@@ -305,8 +310,16 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_fwd_kernel(MlpArgs a) {
     load_x<KPGE>(a, cur, g, xn);
     f32x4 h1[NB], h2[NB];
     forward_chain<ACT, KPGE>(L, xb, c, g, h1, h2);
-    const float v = value_head<KPGE>(L, g, h2) + b3;
-    if (rok && g == 0) a.values[r] = v;
+    if (a.hout) {                          // hidden mode: H2 row, natural unit order
+      if (rok) {
+        float* dst = a.hout + r * HID + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) *reinterpret_cast<f32x4*>(dst + 16 * m) = h2[m];
+      }
+    } else {
+      const float v = value_head<KPGE>(L, g, h2) + b3;
+      if (rok && g == 0) a.values[r] = v;
+    }
   }
 }
 
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(MLP_BT, 1) void mlp_critic_fwd_kernel(MlpArgs a) {
 //   P2  chain: store H1(i), dY2(i) to LDS      |
 //   P3  chain: dH1(i), dY1(i)                  | gradient: dW2(i), db2
 //   P4  chain: store dY1(i), X(i) to LDS       |
-template <int ACT, int KPGE>
+template <int ACT, int KPGE, bool HIDDEN>
 __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a) {
   constexpr int NCB = (4 * KPGE + 1 + 15) / 16;               // dW1 column blocks incl. the ones column
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a
   // their SIMD, the gradient waves' MFMAs fill the slots they leave free.
   if (role == 0) {
     // ======================= chain waves =======================
-    const float b3 = a.b3[0];
+    const float b3 = HIDDEN ? 0.f : a.b3[0];
     const float inv_n = 1.f / (float)a.R;
     float gw3[NB][4];
 #pragma unroll
@@ -371,8 +384,8 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a
     float xn[KPGE], retn, oldn = 0.f;
     {
       const int64_t rcn = load_x<KPGE>(a, cur, g, xn);
-      retn = a.ret[rcn];
-      if (a.clip > 0.f) oldn = a.old_v[rcn];
+      retn = HIDDEN ? 0.f : a.ret[rcn];
+      if (!HIDDEN && a.clip > 0.f) oldn = a.old_v[rcn];
     }
 #ifdef MLPX_STAMP
     long long stt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -393,39 +406,53 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a
       {
         cur.advance(a.T);
         const int64_t rcn = load_x<KPGE>(a, cur, g, xn);
-        retn = a.ret[rcn];
-        if (a.clip > 0.f) oldn = a.old_v[rcn];
+        if (!HIDDEN) {
+          retn = a.ret[rcn];
+          if (a.clip > 0.f) oldn = a.old_v[rcn];
+        }
       }
       f32x4 h1[NB], h2[NB];
       forward_chain<ACT, KPGE>(L, xb, c, g, h1, h2);
       STAMP(0)
-      // value, loss and dL/dv (mean over ALL rows R of the epoch), dY2
-      const float v = value_head<KPGE>(L, g, h2) + b3;
-      if (a.values && rok && g == 0) a.values[r] = v;
-      float dv;
-      {
-        const float e = v - rt;
-        float l = e * e, d = 2.f * e;
-        if (a.clip > 0.f) {
-          const float dlt = v - ov;
-          const float cl = fminf(fmaxf(dlt, -a.clip), a.clip);
-          const float e2 = ov + cl - rt;
-          if (e2 * e2 > l) { l = e2 * e2; d = (dlt > -a.clip && dlt < a.clip) ? 2.f * e2 : 0.f; }
+      if (HIDDEN) {
+        // hidden mode: dY2 = dL/dH2 * act'(H2), the upstream gradient comes from memory
+        const float* src = a.gh + (rok ? r : a.R - 1) * HID + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(src + 16 * m);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            h2[m][i] = rok ? gv[i] * act_d<ACT>(h2[m][i]) : 0.f;
         }
-        if (!rok) { l = 0.f; d = 0.f; }
-        dv = d * inv_n;
-        if (g == 0) loss_sum += l;
-        if (g == 0) gb3 += dv;
-      }
-      // dY2 = dv w3 act'(H2) (in place in h2); dw3 partials
-#pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        const f32x4 w3v = *reinterpret_cast<const f32x4*>(L.Bs + 2 * HID + 16 * m + 4 * g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float hv = h2[m][i];
-          gw3[m][i] += dv * hv;
-          h2[m][i] = dv * w3v[i] * act_d<ACT>(hv);
+      } else {
+        // value, loss and dL/dv (mean over ALL rows R of the epoch), dY2
+        const float v = value_head<KPGE>(L, g, h2) + b3;
+        if (a.values && rok && g == 0) a.values[r] = v;
+        float dv;
+        {
+          const float e = v - rt;
+          float l = e * e, d = 2.f * e;
+          if (a.clip > 0.f) {
+            const float dlt = v - ov;
+            const float cl = fminf(fmaxf(dlt, -a.clip), a.clip);
+            const float e2 = ov + cl - rt;
+            if (e2 * e2 > l) { l = e2 * e2; d = (dlt > -a.clip && dlt < a.clip) ? 2.f * e2 : 0.f; }
+          }
+          if (!rok) { l = 0.f; d = 0.f; }
+          dv = d * inv_n;
+          if (g == 0) loss_sum += l;
+          if (g == 0) gb3 += dv;
+        }
+        // dY2 = dv w3 act'(H2) (in place in h2); dw3 partials
+  #pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          const f32x4 w3v = *reinterpret_cast<const f32x4*>(L.Bs + 2 * HID + 16 * m + 4 * g);
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float hv = h2[m][i];
+            gw3[m][i] += dv * hv;
+            h2[m][i] = dv * w3v[i] * act_d<ACT>(hv);
+          }
         }
       }
       STAMP(1)
@@ -712,11 +739,16 @@ template <int ACT, bool BWD, int KPGE>
 void mlp_launch(const MlpArgs& a, int grid, hipStream_t st) {
   constexpr size_t lds = mlp_lds_bytes<KPGE>();
   static_assert(lds <= 160 * 1024, "LDS budget");
-  if (BWD) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE>),
+  if (BWD && a.gh != nullptr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE>), dim3(grid), dim3(2 * MLP_BT), lds, st,
-                       a);
+    hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE, true>), dim3(grid), dim3(2 * MLP_BT), lds,
+                       st, a);
+  } else if (BWD) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE, false>), dim3(grid), dim3(2 * MLP_BT), lds,
+                       st, a);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -768,7 +800,7 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_CHECK_ARG(!adam_param || (bwd && adam_m && adam_v && adam_state && adam_step >= 1.f),
                 "mlp_critic: fused Adam needs the backward pass and its state buffers");
   MlpArgs a{x, env_stride, row_stride, T, R, din, w1, b1, w2, b2, w3, b3,
-            returns, old_values, clip, values, partials};
+            returns, old_values, clip, values, partials, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = ceil_div(R, ROWS_PER_TILE);
   int cap = tce_mlp_critic_grid();
@@ -785,6 +817,49 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
     const int P = mlp_num_params(din);
     AdamArgs ad{adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps, weight_decay,
                 adam_step};
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
+                       dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
+    TCE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+
+// The two hidden layers D_in -> 128 -> 128 of a network with a wider output
+// (the policy mean net, mprl/rl/policy/abstract_policy.py:58-99 ->
+// mprl/util/util_nn.py:225-246) on the same kernels.  grad_hidden == NULL:
+// forward, hidden_out [R][128] = act(W2 act(W1 x + b1) + b2).  Otherwise
+// backward of dL/dH2 = grad_hidden [R][128] (the forward is recomputed): grad
+// [num_params] receives dW1, db1, dW2, db2 in that order (the trailing w3 / b3
+// slots are zero); partials as for tce_mlp_critic_f32; stats: float[2] scratch,
+// zeroed by the caller.
+int tce_mlp_hidden_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                       int64_t R, int din, const float* w1, const float* b1,
+                       const float* w2, const float* b2, int act, const float* grad_hidden,
+                       float* hidden_out, float* partials, float* grad, float* stats,
+                       void* stream) {
+  TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && R > 0 && T > 0, "mlp_hidden: null buffer / bad sizes");
+  TCE_CHECK_ARG(din >= 1 && din <= MAX_DIN, "mlp_hidden: 1 <= D_in <= 40");
+  TCE_CHECK_ARG(act >= 0 && act <= 3, "mlp_hidden: unknown activation");
+  const bool bwd = grad_hidden != nullptr;
+  TCE_CHECK_ARG(bwd ? (partials && grad && stats) : (hidden_out != nullptr),
+                "mlp_hidden: output buffers missing");
+  MlpArgs a{x, env_stride, row_stride, T, R, din, w1, b1, w2, b2, nullptr, nullptr,
+            nullptr, nullptr, 0.f, nullptr, bwd ? partials : nullptr,
+            bwd ? nullptr : hidden_out, grad_hidden};
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = ceil_div(R, ROWS_PER_TILE);
+  const int grid = (int)tmin<int64_t>(tce_mlp_critic_grid(), ntiles);
+  switch (act) {
+    case 0: mlp_go<ACT_TANH>(bwd, a, grid, st); break;
+    case 1: mlp_go<ACT_RELU>(bwd, a, grid, st); break;
+    case 2: mlp_go<ACT_LEAKY>(bwd, a, grid, st); break;
+    default: mlp_go<ACT_SOFTPLUS>(bwd, a, grid, st); break;
+  }
+  TCE_LAUNCH_CHECK();
+  if (bwd) {
+    const int P = mlp_num_params(din);
+    AdamArgs ad{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
                        dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
     TCE_LAUNCH_CHECK();

@@ -54,6 +54,12 @@ def forward(mlp, x):
             and x.numel() >= 4096 * mlp.dim_in:
         return critic_ops.forward(mlp, x)         # fused MFMA forward
     layers = mlp.layers
+    if critic_ops.hidden_supported(mlp, x) and not x.requires_grad \
+            and mlp.act_func_last_type is None:
+        # both hidden layers (forward and backward) in the fused MFMA kernels,
+        # only the output layer is a library GEMM
+        h2 = critic_ops.hidden_forward(mlp, x)
+        return F.linear(h2, layers[-1].weight, layers[-1].bias)
     act = _ACT[mlp.act_func_hidden_type]
     for i in range(len(mlp.hidden_layers)):
         x = act(_Linear.apply(x, layers[i].weight, layers[i].bias))

@@ -115,3 +115,38 @@ def test_library_path_split_k_weight_gradient(dtype, rows):
     tol = 2e-4 if dtype == torch.float32 else 1e-11
     for a, r in zip(*outs):
         torch.testing.assert_close(a, r, rtol=tol, atol=tol * r.abs().max().item())
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "leaky_relu", "softplus"])
+@pytest.mark.parametrize("din,rows,dout", [(39, 300, 24), (27, 4096, 63),
+                                           (7, 1, 3), (40, 65, 1)])
+def test_hidden_layers_on_the_fused_kernels(act, din, rows, dout):
+    """Policy-sized nets: both hidden layers (forward + backward) run in the
+    fused MFMA kernels (tce_mlp_hidden_f32), the output layer is a GEMM."""
+    from tce_rl_amd import critic_ops, mlp_ops
+    from tce_rl_amd.nn import MLP
+    torch.manual_seed(din)
+    mlp = MLP("m", din, dout, [128, 128], "orthogonal", 0.01, act, None,
+              torch.float32, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, din + 9, device="cuda", generator=g)[:, :din]
+    up = torch.randn(rows, dout, device="cuda", generator=g)
+    assert critic_ops.hidden_supported(mlp, x)
+    y = mlp_ops.forward(mlp, x)
+    (y * up).sum().backward()
+    got = [y.detach()] + [p.grad.clone() for p in mlp.parameters()]
+    ref = {}
+    for dtype in (torch.float64, torch.float32):
+        ws = [p.detach().to(dtype).requires_grad_(True)
+              for p in mlp.parameters()]
+        h = x.to(dtype)
+        h = ACTS[act](F.linear(h, ws[0], ws[1]))
+        h = ACTS[act](F.linear(h, ws[2], ws[3]))
+        yy = F.linear(h, ws[4], ws[5])
+        (yy * up.to(dtype)).sum().backward()
+        ref[dtype] = [yy.detach()] + [w.grad for w in ws]
+    for a, r64, r32 in zip(got, ref[torch.float64], ref[torch.float32]):
+        e = (a.double() - r64).abs().max().item()
+        e32 = (r32.double() - r64).abs().max().item()
+        scale = r64.abs().max().item()
+        assert e <= 4 * e32 + 1e-5 * scale + 1e-7, (a.shape, e, e32, scale)
