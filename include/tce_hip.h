@@ -96,7 +96,9 @@ int tce_segment_accrew_f64(const double* rewards, const int64_t* pairs, int P,
  * device, no host sync).  basis_ws: real [T, 4 + 2*nbg] workspace, flag_ws:
  * int[1] workspace; times_flags bit 1 set: both already hold the table of
  * exactly these times / init_time (left there by an earlier call: the table is
- * not rebuilt -- one rollout or update evaluates the same grid ~100 times).
+ * not rebuilt -- one rollout or update evaluates the same grid ~100 times);
+ * pair log-prob only, bit 2 set: `work` still holds the per-pair factors of
+ * this very L from the forward call (the backward then skips that kernel).
  * out [N, T, 2*dof] = cat[pos, vel].
  */
 int tce_times_f32(const float* init_time, float off_first, float off_last,

@@ -572,6 +572,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
               real* work, int64_t N, int T, int P, int dof, hipStream_t stream) {
   const int times_general = times_flags & 1;
   const bool basis_ready = (times_flags & 2) != 0;     // B / flag hold this time grid already
+  const bool prep_ready = (times_flags & 4) != 0;      // work holds pair_prep of this L already
   TCE_CHECK_ARG(traj && mean && L && pairs && tab && times && t0 && y0 && v0 && B && flag,
                 "pair_logprob: null buffer");
   TCE_CHECK_ARG(bwd ? (gout && gmean && gL) : (logp != nullptr), "pair_logprob: null output");
@@ -613,9 +614,11 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   if (fast) {
     real* wsp = work;                                      // [P][pf_ws_pair]
     real* spart = wsp + (int64_t)P * pf_ws_pair(f);        // [nblk][P][R*R+1]
-    hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256), 0, stream, L, pairs, B,
-                       flag, reg, wsp, f);
-    TCE_LAUNCH_CHECK();
+    if (!prep_ready) {
+      hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256), 0, stream, L, pairs, B,
+                         flag, reg, wsp, f);
+      TCE_LAUNCH_CHECK();
+    }
     const size_t lds = env_lds(EB);
     TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: fast path LDS");
     if (bwd) {

@@ -97,7 +97,7 @@ class _Objective(torch.autograd.Function):
         call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
              N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
         g_pm, g_pL = new(N, K), new(K, K)
-        pl_args = pl(c.general | 2)         # the forward call left the table
+        pl_args = pl(c.general | 2 | 4)     # the forward call left table + pair factors
         call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
              ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
         # ---- KL diagnostics, entropy, trust region loss (+ its gradients)
