@@ -297,3 +297,43 @@ def test_training_improves_reward_within_the_trust_region():
     assert max(means) <= p["mean_bound"] * 1.02
     assert np.mean(rewards[-5:]) > 0.6 * np.mean(rewards[:5])   # rewards are < 0
     assert rewards[-1] > rewards[0]
+
+
+@pytest.mark.parametrize("opts", [
+    dict(num_minibatchs=4),
+    dict(clip_critic=0.5, clip_advantages=2.0, clip_grad_norm=0.5),
+    dict(segment_advantage="accumulate", norm_advantages=False),
+    dict(segment_advantage="accumulated_rewards"),
+    dict(use_gae=False, discount_factor=0.99),
+    dict(set_variance=True, entropy_penalty_coef=0.01),
+    dict(_contextual=True),
+    dict(_std_only=True),
+    dict(fused_policy_objective=False, graph_policy_update=True,
+         overlap_updates=False),
+    dict(balance_check=1),
+], ids=lambda o: "-".join(o))
+def test_agent_option_matrix(opts):
+    """Every agent / policy switch of the reference configs runs two
+    iterations on the GPU path and yields finite metrics."""
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    opts = dict(opts)
+    cfg = tce_config("metaworld", num_env=48, num_basis=5, epochs=2,
+                     evaluation_interval=0)
+    vna = cfg["params"]["policy"]["args"]["variance_net_args"]
+    if opts.pop("_contextual", False):
+        vna.update(contextual=True, avg_neuron=64, num_hidden=2, shape=0.0)
+    if opts.pop("_std_only", False):
+        vna["std_only"] = True
+    cfg["params"]["agent"]["args"].update(opts)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    for i in range(2):
+        res = exp.iterate(cfg, 0, i)
+    for k in ("critic_loss_mean", "surrogate_loss_mean", "policy_loss_mean",
+              "entropy_mean", "trust_region_loss_mean",
+              "projection_proj_old_cov_diff_mean", "policy_grad_norm_mean",
+              "exploration_segment_advantage_mean"):
+        assert np.isfinite(res[k]), k
+    for p in exp.agent.policy.parameters + exp.agent.critic.parameters:
+        assert torch.isfinite(p).all()
