@@ -11,7 +11,6 @@ import copy
 import os
 import sys
 
-import torch
 import yaml
 
 from . import util

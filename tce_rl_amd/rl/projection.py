@@ -20,8 +20,6 @@ The covariance step runs in ``ops.kl_cov_projection`` (one workgroup per
 matrix; with a non-contextual covariance only ONE matrix is projected and the
 result is broadcast, exactly like the reference layer does).
 """
-import math
-
 import numpy as np
 import torch
 

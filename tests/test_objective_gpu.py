@@ -10,7 +10,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _chol(K, g, dtype, scale=0.05):
-    from oracle import tce_oracle as O
     diag = torch.nn.functional.softplus(torch.randn(K, generator=g,
                                                     dtype=dtype)) + 1e-2
     L = torch.diag(diag)
