@@ -8,10 +8,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(num_env, epochs, overlap, **agent_kw):
+def build(num_env, epochs, overlap, env="metaworld", num_basis=5, **agent_kw):
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
-    cfg = tce_config("metaworld", num_env=num_env, num_basis=5, epochs=epochs,
+    cfg = tce_config(env, num_env=num_env, num_basis=num_basis, epochs=epochs,
                      evaluation_interval=0)
     cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
     cfg["params"]["agent"]["args"].update(agent_kw)
@@ -29,9 +29,22 @@ def to_cpu_params(net):
                                                  (False, False, False),
                                                  (True, False, True)])
 def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
+    _agent_vs_oracle(overlap, fused, graph, "metaworld", 5)
+
+
+@pytest.mark.parametrize("env,nb", [("metaworld", 8), ("box_push", 8),
+                                    ("box_push", 3)])
+def test_agent_step_matches_cpu_oracle_other_shapes(env, nb):
+    """K 36 (the reference's Metaworld basis count) and the 7-dof box-pushing
+    shapes (K 63 / 28, T 100, 256-wide leaky-relu critic on the library path)."""
+    _agent_vs_oracle(True, True, False, env, nb)
+
+
+def _agent_vs_oracle(overlap, fused, graph, env, nb):
     from oracle.agent_oracle import OracleTCE
     N, EPOCHS = 16, 3
-    agent, cfg = build(N, EPOCHS, overlap, fused_policy_objective=fused,
+    agent, cfg = build(N, EPOCHS, overlap, env=env, num_basis=nb,
+                       fused_policy_objective=fused,
                        graph_policy_update=graph)
     oracle = OracleTCE(cfg["params"], N)
     # identical weights
@@ -43,14 +56,15 @@ def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
         oracle.var.copy_(agent.policy.variance_net.variable.cpu())
     # identical env state and noise
     g = torch.Generator().manual_seed(7)
-    goal = torch.rand(N, 4, generator=g) * 2 - 1
-    pos0 = 0.1 * (torch.rand(N, 4, generator=g) * 2 - 1)
-    eps = torch.randn(N, 24, generator=g)
+    dof = agent.policy.num_dof
+    goal = torch.rand(N, dof, generator=g) * 2 - 1
+    pos0 = 0.1 * (torch.rand(N, dof, generator=g) * 2 - 1)
+    eps = torch.randn(N, agent.policy.dim_out, generator=g)
     env = agent.sampler.train_envs
 
     def reset():
         env.goal = goal.cuda()
-        z = torch.zeros(N, 4, device="cuda")
+        z = torch.zeros(N, dof, device="cuda")
         return env._obs(torch.zeros(N, device="cuda"), pos0.cuda(), z)
     env.reset = reset
     orig_sample = agent.policy.sample
