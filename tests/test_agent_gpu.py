@@ -33,10 +33,11 @@ def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
 
 
 @pytest.mark.parametrize("env,nb", [("metaworld", 8), ("box_push", 8),
-                                    ("box_push", 3)])
+                                    ("box_push", 3), ("table_tennis", 3)])
 def test_agent_step_matches_cpu_oracle_other_shapes(env, nb):
     """K 36 (the reference's Metaworld basis count) and the 7-dof box-pushing
-    shapes (K 63 / 28, T 100, 256-wide leaky-relu critic on the library path)."""
+    shapes (K 63 / 28, T 100, 256-wide leaky-relu critic on the library path);
+    table tennis: T 350, phase delay, tanh policy, MDP-reward re-shaping."""
     _agent_vs_oracle(True, True, False, env, nb)
 
 
