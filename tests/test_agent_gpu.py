@@ -8,11 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(num_env, epochs, overlap, env="metaworld", num_basis=5, **agent_kw):
+def build(num_env, epochs, overlap, env="metaworld", num_basis=5,
+          dtype="float32", **agent_kw):
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
     cfg = tce_config(env, num_env=num_env, num_basis=num_basis, epochs=epochs,
-                     evaluation_interval=0)
+                     evaluation_interval=0, dtype=dtype)
     cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
     cfg["params"]["agent"]["args"].update(agent_kw)
     exp = MPExperiment()
@@ -32,19 +33,21 @@ def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
     _agent_vs_oracle(overlap, fused, graph, "metaworld", 5)
 
 
-@pytest.mark.parametrize("env,nb", [("metaworld", 8), ("box_push", 8),
-                                    ("box_push", 3), ("table_tennis", 3)])
-def test_agent_step_matches_cpu_oracle_other_shapes(env, nb):
+@pytest.mark.parametrize("env,nb,dtype", [
+    ("metaworld", 8, "float32"), ("box_push", 8, "float32"),
+    ("box_push", 3, "float32"), ("table_tennis", 3, "float32"),
+    ("box_push", 3, "float64"), ("metaworld", 5, "float64")])
+def test_agent_step_matches_cpu_oracle_other_shapes(env, nb, dtype):
     """K 36 (the reference's Metaworld basis count) and the 7-dof box-pushing
     shapes (K 63 / 28, T 100, 256-wide leaky-relu critic on the library path);
     table tennis: T 350, phase delay, tanh policy, MDP-reward re-shaping."""
-    _agent_vs_oracle(True, True, False, env, nb)
+    _agent_vs_oracle(True, True, False, env, nb, dtype)
 
 
-def _agent_vs_oracle(overlap, fused, graph, env, nb):
+def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32"):
     from oracle.agent_oracle import OracleTCE
     N, EPOCHS = 16, 3
-    agent, cfg = build(N, EPOCHS, overlap, env=env, num_basis=nb,
+    agent, cfg = build(N, EPOCHS, overlap, env=env, num_basis=nb, dtype=dtype,
                        fused_policy_objective=fused,
                        graph_policy_update=graph)
     oracle = OracleTCE(cfg["params"], N)
@@ -58,15 +61,16 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb):
     # identical env state and noise
     g = torch.Generator().manual_seed(7)
     dof = agent.policy.num_dof
-    goal = torch.rand(N, dof, generator=g) * 2 - 1
-    pos0 = 0.1 * (torch.rand(N, dof, generator=g) * 2 - 1)
-    eps = torch.randn(N, agent.policy.dim_out, generator=g)
+    td = torch.float64 if dtype == "float64" else torch.float32
+    goal = (torch.rand(N, dof, generator=g) * 2 - 1).to(td)
+    pos0 = (0.1 * (torch.rand(N, dof, generator=g) * 2 - 1)).to(td)
+    eps = torch.randn(N, agent.policy.dim_out, generator=g).to(td)
     env = agent.sampler.train_envs
 
     def reset():
         env.goal = goal.cuda()
-        z = torch.zeros(N, dof, device="cuda")
-        return env._obs(torch.zeros(N, device="cuda"), pos0.cuda(), z)
+        z = torch.zeros(N, dof, device="cuda", dtype=td)
+        return env._obs(torch.zeros(N, device="cuda", dtype=td), pos0.cuda(), z)
     env.reset = reset
     orig_sample = agent.policy.sample
     agent.policy.sample = lambda **kw: orig_sample(**kw, eps=eps.cuda())
