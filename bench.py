@@ -61,6 +61,24 @@ def kernel_time_us(fn, launches=20):
     return best
 
 
+def kernel_time_cold_us(fn, launches=5):
+    """Device time of ONE launch of `fn` right after a 1 GiB fill has displaced
+    its inputs from the L2 / 256 MB Infinity Cache (per-launch HIP events)."""
+    flush = torch.empty(1 << 28, device="cuda")
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    ts = []
+    fn()
+    for _ in range(launches):
+        flush.fill_(1.0)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes
     (profiles/r01c_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2
@@ -108,12 +126,20 @@ def roofline(agent):
     d[:, -1] = True
     tl = torch.zeros_like(d)
     us = kernel_time_us(lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True))
+    us_cold = kernel_time_cold_us(lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True))
     alg = N * T * 18 + N * 4
     gae = {"kernel": "gae_dpp_kernel<float,true,true,8>", "bound": "hbm",
            "achieved": round(alg / us / 1e3, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
            "traffic": pmc_traffic("gae_dpp_kernel"),
-           "us_per_launch": round(us, 2), "algorithmic_bytes": alg}
+           "us_per_launch": round(us, 2), "algorithmic_bytes": alg,
+           "cold": {"us_per_launch": round(us_cold, 2),
+                    "achieved": round(alg / us_cold / 1e3, 1),
+                    "frac": round(alg / us_cold / 1e3 / HBM_PEAK_GBS, 4),
+                    "note": "inputs evicted by a 1 GiB fill before the launch; "
+                            "the back-to-back figure above re-reads its 37 MB "
+                            "from the 256 MB Infinity Cache, as the step does "
+                            "(values and rewards were just produced)"}}
     # trajectory generator (write-bound): T*2*dof*4 B written per env
     mp = agent.policy.mp
     K = mp.num_dof * mp.num_basis_g
@@ -123,6 +149,8 @@ def roofline(agent):
     y0 = torch.rand(N, mp.num_dof, device="cuda", generator=g)
     v0 = torch.zeros(N, mp.num_dof, device="cuda")
     us2 = kernel_time_us(lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0))
+    us2_cold = kernel_time_cold_us(
+        lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0))
     alg2 = N * (T * 2 * mp.num_dof * 4 + 4 * (K + 2 * mp.num_dof + 1))
     extra = {"prodmp_traj": {
         "bound": "hbm", "achieved": round(alg2 / us2 / 1e3, 1),
@@ -130,6 +158,7 @@ def roofline(agent):
         "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
         "traffic": pmc_traffic("prodmp_traj_kernel"),
         "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
+        "cold_us_per_launch": round(us2_cold, 2),
         "note": "trajectory kernel; the [T, 4+2(nb+1)] basis table "
                 "(one 10 us kernel) is built once per time grid and reused by "
                 "the ~100 trajectory / log-prob evaluations of a rollout + "
