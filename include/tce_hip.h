@@ -324,14 +324,18 @@ int tce_mlp_hidden_f32(const float* x, int64_t env_stride, int64_t row_stride, i
  *     temporal_correlated_agent.py:361-366,597-612, black_box_agent.py:160-166,330-339.
  * state: 4 elements on the device = {step count (incremented by the call),
  *   |g| before clipping, |g| after, clip factor}.  sumsq_in (nullable): |g|^2
- *   already reduced by the producer (tce_mlp_critic_f32 stats[1]).
+ *   already reduced by the producer (tce_mlp_critic_f32 stats[1]).  grad_scale:
+ *   the gradient is taken as grad_scale * grad (1 / world size after a summing
+ *   all-reduce of the env shards' gradients), norms included.
  */
 int tce_adam_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                       float* state, const float* sumsq_in, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, float clip, void* stream);
+                      float eps, float weight_decay, float clip, float grad_scale,
+                      void* stream);
 int tce_adam_flat_f64(double* param, const double* grad, double* m, double* v, int64_t n,
                       double* state, const double* sumsq_in, double lr, double beta1,
-                      double beta2, double eps, double weight_decay, double clip, void* stream);
+                      double beta2, double eps, double weight_decay, double clip,
+                      double grad_scale, void* stream);
 
 /* ---- fused critic MLP epoch (exact-fp32 MFMA) ----------------------------
  * Forward (+ value loss + backward when `partials` != NULL) of the value

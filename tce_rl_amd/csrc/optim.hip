@@ -15,7 +15,8 @@ namespace {
 template <typename real>
 __global__ __launch_bounds__(1024) void adam_prep_kernel(const real* __restrict__ grad, int64_t n,
                                                          const real* __restrict__ sumsq_in,
-                                                         real* __restrict__ state, real clip) {
+                                                         real* __restrict__ state, real clip,
+                                                         real gscale) {
   __shared__ real red[16];
   real sq = 0;
   if (sumsq_in == nullptr) {
@@ -25,13 +26,13 @@ __global__ __launch_bounds__(1024) void adam_prep_kernel(const real* __restrict_
     sq = sumsq_in[0];
   }
   if (threadIdx.x == 0) {
-    const real before = sqrt(sq);
+    const real before = sqrt(sq) * gscale;           // norm of the scaled gradient
     real coef = 1;
     if (clip > real(0)) coef = tmin(clip / (before + real(1e-6)), real(1));
     state[0] += real(1);
     state[1] = before;
     state[2] = before * coef;
-    state[3] = coef;
+    state[3] = coef * gscale;                        // factor applied to the raw gradient
   }
 }
 
@@ -61,10 +62,10 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(real* __restrict__ p,
 template <typename real>
 int adam_flat(real* param, const real* grad, real* m, real* v, int64_t n, real* state,
               const real* sumsq_in, real lr, real b1, real b2, real eps, real wd, real clip,
-              hipStream_t st) {
+              real gscale, hipStream_t st) {
   TCE_CHECK_ARG(param && grad && m && v && state && n > 0, "adam_flat: null buffer / bad size");
   hipLaunchKernelGGL(adam_prep_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, sumsq_in,
-                     state, clip);
+                     state, clip, gscale);
   TCE_LAUNCH_CHECK();
   const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 256), 2048);
   hipLaunchKernelGGL(adam_apply_kernel<real>, dim3(grid), dim3(256), 0, st, param, grad, m, v, n,
@@ -79,15 +80,17 @@ extern "C" {
 
 int tce_adam_flat_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                       float* state, const float* sumsq_in, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, float clip, void* stream) {
+                      float eps, float weight_decay, float clip, float grad_scale,
+                      void* stream) {
   return adam_flat<float>(param, grad, m, v, n, state, sumsq_in, lr, beta1, beta2, eps,
-                          weight_decay, clip, (hipStream_t)stream);
+                          weight_decay, clip, grad_scale, (hipStream_t)stream);
 }
 int tce_adam_flat_f64(double* param, const double* grad, double* m, double* v, int64_t n,
                       double* state, const double* sumsq_in, double lr, double beta1,
-                      double beta2, double eps, double weight_decay, double clip, void* stream) {
+                      double beta2, double eps, double weight_decay, double clip,
+                      double grad_scale, void* stream) {
   return adam_flat<double>(param, grad, m, v, n, state, sumsq_in, lr, beta1, beta2, eps,
-                           weight_decay, clip, (hipStream_t)stream);
+                           weight_decay, clip, grad_scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

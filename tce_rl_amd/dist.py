@@ -60,13 +60,15 @@ class DistContext:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def allreduce_flat(self, flat, group=None):
-        """In-place mean over ranks of an already-flat gradient buffer."""
+    def allreduce_flat(self, flat, group=None, average=True):
+        """In-place sum (average=False) or mean over ranks of an already-flat
+        gradient buffer."""
         if self.world == 1:
             return
         dist.all_reduce(flat, op=dist.ReduceOp.SUM,
                         group=self.group if group is None else group)
-        flat.div_(self.world)
+        if average:
+            flat.div_(self.world)
 
     def mean_scalar(self, x):
         if self.world == 1:

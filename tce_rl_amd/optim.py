@@ -73,10 +73,11 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = gv
 
     @torch.no_grad()
-    def step(self, clip=0.0, sumsq=None):
+    def step(self, clip=0.0, sumsq=None, grad_scale=1.0):
         """One Adam step on the flat buffers; returns the gradient norm before
         and after clipping as 0-dim device tensors (valid until the next
-        step)."""
+        step).  grad_scale: factor on the stored gradient (1 / world after a
+        summing all-reduce)."""
         g = self.param_groups[0]
         self.sync_grads()
         self.host_step += 1
@@ -84,7 +85,8 @@ class FlatAdam(torch.optim.Optimizer):
              ptr(self.flat_grad), ptr(self.m), ptr(self.v),
              self.flat_param.numel(), ptr(self.dev_state), ptr(sumsq),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-             float(g["eps"]), float(g["weight_decay"]), float(clip), stream())
+             float(g["eps"]), float(g["weight_decay"]), float(clip),
+             float(grad_scale), stream())
         return self.dev_state[1], self.dev_state[2]
 
     def state_dict(self):

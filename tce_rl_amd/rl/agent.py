@@ -143,8 +143,8 @@ class AbstractAgent(ABC):
             # the policy's exchange has its own communicator (see dist.py)
             self.dist.allreduce_flat(
                 opt.flat_grad, self._policy_group
-                if opt is self.policy_optimizer else None)
-        opt.step(clip)
+                if opt is self.policy_optimizer else None, average=False)
+        opt.step(clip, grad_scale=1.0 / self.dist.world)   # mean over ranks
         norms = opt.dev_state[1:3].clone()      # the state is reused next step
         return norms[0], norms[1]
 
@@ -214,8 +214,8 @@ class _CriticEpochs:
                               adam=opt if self.fuse_adam else None)
             if not self.fuse_adam:
                 if ag.dist.world > 1:
-                    ag.dist.allreduce_flat(opt.flat_grad)
-                    opt.step(ag.clip_grad_norm)
+                    ag.dist.allreduce_flat(opt.flat_grad, average=False)
+                    opt.step(ag.clip_grad_norm, grad_scale=1.0 / ag.dist.world)
                 else:                   # |g|^2 comes with the reduction
                     opt.step(ag.clip_grad_norm, sumsq=rows[e, 1:2])
                 rows[e, 2:4].copy_(opt.dev_state[1:3])

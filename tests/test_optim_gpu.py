@@ -143,3 +143,25 @@ def test_cu_range_stream_runs_kernels():
     st.synchronize()
     assert stats is not None
     assert lib.tce_stream_destroy(h) == 0
+
+
+def test_grad_scale_equals_scaling_the_gradient():
+    """step(grad_scale=s) == step on s * grad (the multi-GPU mean of summed
+    shard gradients), norms and clipping included."""
+    from tce_rl_amd.optim import FlatAdam
+    res = []
+    for scaled in (True, False):
+        ps = [torch.nn.Parameter(p.clone().cuda())
+              for p in _params(torch.float32, 3)]
+        opt = FlatAdam(ps, lr=1e-3, weight_decay=1e-3)
+        g = torch.Generator().manual_seed(9)
+        for _ in range(3):
+            for p in ps:
+                gr = torch.randn(p.shape, generator=g).cuda()
+                p.grad.copy_(gr if scaled else gr * 0.125)
+            nb, na = opt.step(0.3, grad_scale=0.125 if scaled else 1.0)
+        res.append(([p.detach().clone() for p in ps], nb.item(), na.item()))
+    for a, b in zip(res[0][0], res[1][0]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)
+    assert res[0][2] == pytest.approx(res[1][2], rel=1e-6)
