@@ -29,10 +29,42 @@ class RunningMeanStd:
         self.var = torch.ones(shape, dtype=self.dtype, device=self.device)
         self.count = epsilon
 
-    def update(self, arr, group=None):
-        if group is not None:
-            raise NotImplementedError("use update() per rank + merge_ranks()")
-        self.count = ops.rms_update(arr, self.mean, self.var, self.count)
+    def update(self, arr):
+        """RunningMeanStd.update.  With the envs sharded over ranks the batch
+        statistics are those of the GLOBAL batch (pooled over the ranks before
+        the running merge), so every rank keeps the same normalisation and it
+        equals the single-process result."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
+            self.count = ops.rms_update(arr, self.mean, self.var, self.count)
+            return
+        # local batch moments through the same kernel (merge into an empty state)
+        bm = torch.zeros_like(self.mean)
+        bv = torch.zeros_like(self.var)
+        n_loc = ops.rms_update(arr, bm, bv, 0.0)
+        D = bm.numel()
+        w = dist.get_world_size()
+        mine = torch.cat([bm.double().reshape(-1), bv.double().reshape(-1),
+                          bm.new_full((1,), float(n_loc)).double()])
+        allr = mine.new_empty(w, 2 * D + 1)
+        dist.all_gather_into_tensor(allr, mine[None])
+        n = allr[:, -1:]                                   # [w, 1]
+        m, v = allr[:, :D], allr[:, D:2 * D]
+        n_g = n.sum()
+        mean_g = (n * m).sum(0) / n_g
+        m2_g = ((n - 1) * v + n * (m - mean_g) ** 2).sum(0)
+        var_g = m2_g / (n_g - 1)                           # unbiased, global batch
+        # update_from_moments (util_numerical.py:322-337)
+        mean, var = self.mean.double().reshape(-1), self.var.double().reshape(-1)
+        delta = mean_g - mean
+        tot = self.count + n_g
+        new_mean = mean + delta * n_g / tot
+        M2 = var * self.count + var_g * n_g + delta ** 2 * self.count * n_g / tot
+        self.mean.copy_(new_mean.reshape(self.mean.shape))
+        self.var.copy_((M2 / tot).reshape(self.var.shape))
+        self.count = self.count + float(sum(float(c) for c in
+                                            allr[:, -1].tolist()))
 
     def save(self, log_dir, epoch):
         path = util.get_training_state_save_path(log_dir, self.name, epoch)

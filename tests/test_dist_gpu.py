@@ -35,6 +35,10 @@ def _worker(rank, world, port, overlap, q):
         pairs.append(agent.sampler.pred_pairs.cpu().numpy().copy())
     flat = torch.cat([p.detach().reshape(-1).cpu()
                       for p in agent.policy.parameters + agent.critic.parameters])
+    rms = agent.sampler.obs_rms
+    flat = torch.cat([flat, rms.mean.detach().reshape(-1).cpu().float(),
+                      rms.var.detach().reshape(-1).cpu().float(),
+                      torch.tensor([float(rms.count)])])
     q.put((rank, flat.numpy(), float(res["critic_loss_mean"]),
            float(res["surrogate_loss_mean"]), int(res["num_global_steps"]),
            float(res["exploration_step_rewards_mean"]), pairs))
@@ -60,6 +64,56 @@ def test_two_ranks_stay_in_lock_step(overlap):
     (_, w0, c0, s0, g0, r0, p0), (_, w1, c1, s1, g1, r1, p1) = out
     assert all(np.array_equal(a, b) for a, b in zip(p0, p1))
     assert np.isfinite(w0).all() and np.isfinite([c0, c1, s0, s1]).all()
-    assert np.array_equal(w0, w1)            # same parameters on both ranks
+    assert np.array_equal(w0, w1)            # same parameters AND obs statistics
     assert g0 == g1 == 2 * 2 * 32 * 500      # iterations x ranks x envs x T
     assert r0 != r1                          # the shards really differ
+
+
+def _rms_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from tce_rl_amd import ops
+    from tce_rl_amd.rl.sampler import RunningMeanStd
+    g = torch.Generator().manual_seed(5)
+    batches = [torch.randn(3000, 48, generator=g) * 3 + 1,
+               torch.randn(1000, 48, generator=g) - 2]
+    rms = RunningMeanStd(shape=(48,), dtype="torch.float32", device="cuda")
+    for b in batches:                         # unequal shards on purpose
+        cut = (2 * b.shape[0]) // 3
+        rms.update((b[:cut] if rank == 0 else b[cut:]).cuda())
+    out = [rms.mean.cpu(), rms.var.cpu(), torch.tensor([rms.count])]
+    if rank == 0:                             # single-process result, same kernel
+        mean = torch.zeros(48, device="cuda")
+        var = torch.ones(48, device="cuda")
+        count = 1e-4
+        for b in batches:
+            count = ops.rms_update(b.cuda(), mean, var, count)
+        out += [mean.cpu(), var.cpu(), torch.tensor([count])]
+    q.put((rank, [t.double().numpy() for t in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_obs_statistics_equal_the_single_process_ones():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_rms_worker, args=(r, 2, port, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m0, v0, c0, m_ref, v_ref, c_ref = out[0]
+    m1, v1, c1 = out[1]
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1) and c0 == c1
+    np.testing.assert_allclose(m0, m_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v0, v_ref, rtol=1e-5, atol=1e-6)
+    assert c0[0] == pytest.approx(c_ref[0])
