@@ -101,6 +101,10 @@ class MPExperiment:
         return self.agent.evaluate(render=False)[0]
 
     def save_state(self, cw_config, rep, n):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() \
+                and dist.get_rank() != 0:
+            return                        # replicas are identical: rank 0 writes
         if self.save_model_dir and (
                 (n + 1) % self.save_model_interval == 0
                 or (n + 1) == cw_config["iterations"]):
