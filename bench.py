@@ -196,6 +196,12 @@ def cpu_baseline():
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON record): everything else that
+    # libraries print there (RCCL / gloo banners at communicator creation) is
+    # sent to stderr by pointing fd 1 at fd 2 until the record is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -277,7 +283,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

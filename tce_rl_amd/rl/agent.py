@@ -409,7 +409,16 @@ class TemporalCorrelatedAgent(AbstractAgent):
         first_ms = ev[0].elapsed_time(ev[4]) / max(n1, 1)
         side_ms = ev[2].elapsed_time(ev[5])
         if self.adaptive_critic_split and cstream is None:
-            self._critic_split = int(min(E, side_ms / first_ms + 2))
+            split = int(min(E, side_ms / first_ms + 2))
+            if self.dist.world > 1:
+                # every rank must issue its collectives in the same order (the
+                # critic's first part, the policy's, the critic's rest): agree
+                # on the largest split
+                import torch.distributed as dist
+                t = torch.tensor([split], device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
+                split = int(t.item())
+            self._critic_split = split
         return critic_loss_dict, policy_loss_dict, \
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
