@@ -370,6 +370,23 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        float* adam_state, float lr, float beta1, float beta2, float eps,
                        float weight_decay, float adam_step, void* stream);
 
+/* The backward launch of tce_mlp_critic_f32 (same buffers and contract;
+ * partials != NULL required) on the f16 matrix cores with SPLIT operands: every
+ * fp32 operand is carried as hi = f16(x), lo = f16((x - hi) 2^11) and every
+ * product as hi*hi + 2^-11 (hi*lo + lo*hi) accumulated in fp32 -- 22+ significand
+ * bits per operand, results within fp32 summation-order noise of the exact-fp32
+ * kernel (tests/test_mlp16_gpu.py) at 3/16 of its matrix-core cycles.  Operands
+ * must lie inside the f16 range (|x| < 65504); larger inputs give inf / nan in
+ * stats[0], which the caller checks as it does for the fp32 kernel. */
+int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                         int64_t R, int din, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3,
+                         int act, const float* returns, const float* old_values, float clip,
+                         float* values, float* partials, float* grad, float* stats,
+                         int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                         float* adam_state, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float adam_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,10 +52,14 @@ class EpochRunner:
     """Holds the flat gradient buffer (p.grad are views of it) and the
     per-workgroup partial slabs for repeated critic epochs."""
 
-    def __init__(self, mlp, flat=None):
+    def __init__(self, mlp, flat=None, arith="f32"):
         """flat: gradient buffer to fill (the optimizer's flat gradient, in
-        parameter order W1, b1, W2, b2, w3, b3); allocated if omitted."""
+        parameter order W1, b1, W2, b2, w3, b3); allocated if omitted.
+        arith: "f32" (exact-fp32 matrix cores, csrc/mlp.hip) or "f16x2" (split
+        f16 operands on the f16 matrix cores, csrc/mlp16.hip)."""
         assert supported(mlp)
+        assert arith in ("f32", "f16x2"), arith
+        self.entry = "tce_mlp_critic_" + arith
         self.mlp = mlp
         lib = _lib.load()
         self.P = lib.tce_mlp_critic_num_params(mlp.dim_in)
@@ -99,7 +103,7 @@ class EpochRunner:
                   float(g["weight_decay"]), float(adam.host_step))
         else:
             ad = (None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
-        call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, self.mlp.dim_in,
+        call(self.entry, ptr(xs), es, rs, T, R, self.mlp.dim_in,
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
              ptr(self.flat), ptr(stats), int(max_workgroups), *ad, stream())

@@ -39,56 +39,12 @@
 // gradient accumulators stay in registers across tiles, one partial slab per
 // workgroup at the end, reduced (and fed to Adam) by mlp_finish_kernel.
 // MFMA-bound: 944 MFMAs per SIMD and tile.
-#include "common.h"
+#include "mlp_shared.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int HID = 128;
-constexpr int NB = HID / 16;          // 8 blocks of 16 hidden units
-constexpr int W2P = 136;              // LDS pitch of W2 (see header)
-constexpr int TPT = 132;              // pitch of the [64 batch][hidden] transposes
-constexpr int XP = 68;                // pitch of the X tile stashed for dW1
-constexpr int MLP_BT = 256;
-constexpr int ROWS_PER_TILE = 64;
-constexpr int MAX_DIN = 40;
-
-enum { ACT_TANH = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SOFTPLUS = 3 };
-
-template <int ACT>
-__device__ inline float act_f(float y) {
-  if (ACT == ACT_TANH) return tanhf(y);
-  if (ACT == ACT_RELU) return y > 0.f ? y : 0.f;
-  if (ACT == ACT_LEAKY) return y > 0.f ? y : 0.01f * y;
-  return y > 20.f ? y : log1pf(expf(y));
-}
-// derivative expressed with the OUTPUT h = act(y)
-template <int ACT>
-__device__ inline float act_d(float h) {
-  if (ACT == ACT_TANH) return 1.f - h * h;
-  if (ACT == ACT_RELU) return h > 0.f ? 1.f : 0.f;
-  if (ACT == ACT_LEAKY) return h > 0.f ? 1.f : 0.01f;
-  return 1.f - expf(-h);
-}
-
 __device__ inline f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-// v summed over the lanes l, l ^ 16, l ^ 32, l ^ 48 (all four get the total):
-// two VALU swaps (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two
-// LDS-routed shuffles.
-__device__ inline float sum_lane_groups(float v) {
-  {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  return v;
 }
 // nothing moves across: keeps the next step's LDS reads ahead of this step's MFMAs
 __device__ inline void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
@@ -97,29 +53,6 @@ __device__ inline void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
 __host__ __device__ inline int u1_of(int q) {
   const int kb = q >> 4, r = q & 15;
   return 64 * (kb >> 2) + 16 * (r & 3) + 4 * (r >> 2) + (kb & 3);
-}
-
-struct MlpArgs {
-  const float* x;        // states, row r = (n, t): x + (n * env_stride + t * row_stride)
-  int64_t env_stride, row_stride;
-  int T;                 // rows per env
-  int64_t R;             // total rows
-  int din;               // input features used (first din of each row)
-  const float *w1, *b1, *w2, *b2, *w3, *b3;   // torch Linear layout [out][in]
-  const float* ret;      // returns [R]
-  const float* old_v;    // old values [R] (clipped loss) or nullptr
-  float clip;            // clip_critic (<= 0: plain MSE)
-  float* values;         // forward output [R] (nullable)
-  float* partials;       // [gridDim.x][P + 2] gradient slabs (+ loss sum, count) (nullable: forward only)
-  // "hidden" mode (the two hidden layers of a wider-output net, e.g. the policy
-  // mean net): forward stores H2 [R][HID] instead of the value, backward takes
-  // dL/dH2 [R][HID] instead of the value loss; w3 / b3 are not used.
-  float* hout;
-  const float* gh;
-};
-
-__host__ __device__ inline int mlp_num_params(int din) {
-  return HID * din + HID + HID * HID + HID + HID + 1;
 }
 
 // LDS carve shared by both kernels.  KPGE: input features per lane group
@@ -152,32 +85,6 @@ __device__ inline void stage_weights(const MlpArgs& a, const Lds<KPGE>& L, int t
     L.Bs[2 * HID + e] = a.w3 ? a.w3[e] : 0.f;
   }
 }
-
-// This lane's batch row r = tile * 64 + 16 w + c as (env, step), advanced by
-// gridDim.x tiles at a time without a division in the tile loop.
-struct RowCursor {
-  int64_t r, ne;        // row index (unclamped), env
-  int t;                // step inside the env
-  int64_t dn;           // per advance: envs
-  int dt;               //              steps
-  int64_t dr;           //              rows
-  int64_t last_ne;      // (R - 1) as (env, step): rows past the end read this one
-  int last_t;
-  __device__ RowCursor(const MlpArgs& a, int64_t tile, int w, int c) {
-    r = tile * ROWS_PER_TILE + w * 16 + c;
-    ne = r / a.T;
-    t = (int)(r - ne * a.T);
-    dr = (int64_t)gridDim.x * ROWS_PER_TILE;
-    dn = dr / a.T;
-    dt = (int)(dr - dn * a.T);
-    last_ne = (a.R - 1) / a.T;
-    last_t = (int)((a.R - 1) - last_ne * a.T);
-  }
-  __device__ void advance(int T) {
-    r += dr; ne += dn; t += dt;
-    if (t >= T) { t -= T; ++ne; }
-  }
-};
 
 // X fragment of the cursor's row: lane group g holds X[r][KPGE g + s], s < KPGE
 // (clamped addresses, no branches around the loads); returns the clamped row.
@@ -668,64 +575,6 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a
     if (tid == 256 && blockIdx.x == 0)
       for (int k = 0; k < 4; ++k) out[10 + k] = (float)gst[k];
 #endif
-  }
-}
-
-// Optional Adam step fused into the slab reduction (no clipping: the clip factor
-// needs the global norm first; then the caller runs tce_adam_flat instead).
-struct AdamArgs {
-  float *param, *m, *v, *state;          // param == nullptr: gradient only
-  float lr, b1, b2, eps, wd, step;       // step = count INCLUDING this update
-};
-
-// grad[p] = sum over the workgroup slabs (fixed order: FIN_GROUPS interleaved
-// groups of slabs, then the groups); stats[0] = mean loss, stats[1] += |grad|^2 (the caller
-// zeroes stats); with ad.param the Adam update of torch.optim.Adam (L2 weight
-// decay in the gradient, mprl/rl/agent/abstract_agent.py:62-82) is applied in
-// the same pass.
-constexpr int FIN_GROUPS = 16;          // slab groups summed in parallel per column
-
-__global__ __launch_bounds__(64 * FIN_GROUPS) void mlp_finish_kernel(
-    const float* __restrict__ partials, int nparts, int P, int64_t R, float* __restrict__ grad,
-    float* __restrict__ stats, AdamArgs ad) {
-  __shared__ float part[FIN_GROUPS][64];
-  __shared__ float red[FIN_GROUPS];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int p = blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (p < P + 1) {
-    const float* src = partials + p;
-#pragma unroll 4
-    for (int i = grp; i < nparts; i += FIN_GROUPS) s += src[(int64_t)i * (P + 2)];
-  }
-  part[grp][col] = s;
-  __syncthreads();
-  float sq = 0.f;
-  if (grp == 0 && p < P + 1) {
-    float g0 = 0.f;
-#pragma unroll
-    for (int k = 0; k < FIN_GROUPS; ++k) g0 += part[k][col];   // fixed order
-    if (p < P) {
-      grad[p] = g0;
-      sq = g0 * g0;
-      if (ad.param) {
-        const float w = ad.param[p];
-        const float g = ad.wd != 0.f ? g0 + ad.wd * w : g0;
-        const float mi = ad.b1 * ad.m[p] + (1.f - ad.b1) * g;
-        const float vi = ad.b2 * ad.v[p] + (1.f - ad.b2) * g * g;
-        ad.m[p] = mi;
-        ad.v[p] = vi;
-        const float bc1 = 1.f - powf(ad.b1, ad.step), bc2s = sqrtf(1.f - powf(ad.b2, ad.step));
-        ad.param[p] = w - (ad.lr / bc1) * mi / (sqrtf(vi) / bc2s + ad.eps);
-      }
-    } else {
-      stats[0] = g0 / (float)R;                                // mean loss
-    }
-  }
-  const float tot = block_sum(sq, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&stats[1], tot);
-    if (ad.param && blockIdx.x == 0) ad.state[0] = ad.step;
   }
 }
 
