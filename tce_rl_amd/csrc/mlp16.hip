@@ -49,6 +49,13 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 struct Frag { u32 r[4]; };               // 8 f16: one A or B operand
 
+#ifndef M16_RING
+#define M16_RING 3          // operand ring of the chain loops (reads run RING - 1 steps ahead)
+#endif
+#ifndef M16_GRING
+#define M16_GRING 2         // B-operand ring of the gradient loops
+#endif
+constexpr int RING = M16_RING, GRING = M16_GRING;
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 constexpr int P1B = 96, P2B = 256, PTB = 256, PXB = 128;      // image pitches, bytes
 constexpr int W1_IMG = HID * P1B, W2_IMG = HID * P2B;        // bytes per part
@@ -73,11 +80,14 @@ __device__ inline u32 pk_f16(float a, float b) {
   const h2v v = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(u32, v);
 }
-// (a, b) -> packed hi parts and packed scaled lo parts
+// (a, b) -> packed hi parts and packed scaled lo parts (v_cvt_pk_f16_f32, two
+// v_cvt_f32_f16, the residuals, v_cvt_pk_f16_f32)
 __device__ inline void split2(float a, float b, u32& hi, u32& lo) {
-  const h2v h = {(_Float16)a, (_Float16)b};
+  const f32x2 v = {a, b};
+  const h2v h = __builtin_convertvector(v, h2v);
+  const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * LO_SCALE;
   hi = __builtin_bit_cast(u32, h);
-  lo = pk_f16((a - (float)h.x) * LO_SCALE, (b - (float)h.y) * LO_SCALE);
+  lo = __builtin_bit_cast(u32, __builtin_convertvector(r, h2v));
 }
 // element `half` (0 / 1) of a packed {hi, lo} pair back to fp32
 __device__ inline float join_parts(u32 hi, u32 lo, int half) {
@@ -100,6 +110,11 @@ __device__ inline u32x2 lds_tr64(const char* p) {
       (__attribute__((address_space(3))) fp4*)(p));
   return __builtin_bit_cast(u32x2, v);
 }
+// a value the optimizer must treat as new here: keeps per-phase address
+// arithmetic (one v_xad_u32 per read) from being hoisted out of the tile loop
+// as dozens of loop-invariant registers
+__device__ inline int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ inline float freshf(float v) { asm volatile("" : "+v"(v)); return v; }
 // nothing moves across: keeps the reads of a later step ahead of this step's MFMAs
 __device__ inline void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
 __device__ inline void put2(Frag& f, int s, u32x2 v) { f.r[2 * s] = v.x; f.r[2 * s + 1] = v.y; }
@@ -176,8 +191,7 @@ __device__ inline int64_t load_x16(const MlpArgs& a, const RowCursor& cur, int g
   return in ? cur.r : a.R - 1;
 }
 
-// NKB1: 32-feature k-steps of layer 1 (features 0 .. D_in - 1 plus the ones
-// column at D_in that yields db1): 1 for D_in <= 31, else 2.
+// NKB1: 32-feature k-steps of layer 1: 1 for D_in <= 32, else 2.
 template <int ACT, int NKB1>
 __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Args aa) {
   constexpr int NCB = NKB1 == 1 ? 2 : 3;                       // 16-feature blocks of dW1
@@ -219,10 +233,10 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
       for (int i = 0; i < 4; ++i) gw3[m][i] = 0.f;
     float gb3 = 0.f, loss_sum = 0.f;
     const int trow = wave * 16 + c;                            // this lane's row in the tile images
-    const int tsw = swzT(trow);
+    const int tsw0 = swzT(trow);
     const char* w1rd = sm + OFF_W1 + c * P1B + 16 * g;         // + 16 mb P1B + 64 kb
-    const int w2sw = swz2(c);                                  // forward rows 16 mb + c
-    const int w2tsw = swz2(krow);                              // transposed rows 32 kb + 16 s + 4 g + q
+    const int w2sw0 = swz2(c);                                 // forward rows 16 mb + c
+    const int w2tsw0 = swz2(krow);                             // transposed rows 32 kb + 16 s + 4 g + q
     RowCursor cur(a, blockIdx.x, wave, c);
     float xn[8 * NKB1], retn, oldn = 0.f;
     {
@@ -230,6 +244,13 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
       retn = a.ret[rcn];
       if (a.clip > 0.f) oldn = a.old_v[rcn];
     }
+#ifdef M16_STAMP
+    long long stt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
+#define STAMP(k) { const long long tn = __builtin_readcyclecounter(); stt[k] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(k)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int64_t r = cur.r;
       const bool rok = r < a.R;
@@ -239,62 +260,59 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
       asm volatile("" : "+v"(bs_off));
       const float* Bs = reinterpret_cast<const float*>(sm + bs_off);
       // ---- P1: forward chain
+      // (features past D_in hold finite duplicates: their W1 columns are zero and
+      // their dW1 columns are dropped; rows past R get dL/dv = 0 below)
       Frag Xh[NKB1], Xl[NKB1];
 #pragma unroll
-      for (int kb = 0; kb < NKB1; ++kb) {
-        float xv[8];
+      for (int kb = 0; kb < NKB1; ++kb)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int f = 32 * kb + 8 * g + j;
-          xv[j] = !rok ? 0.f : (f < din ? xn[8 * kb + j] : (f == din ? 1.f : 0.f));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) split2(xv[2 * i], xv[2 * i + 1], Xh[kb].r[i], Xl[kb].r[i]);
-      }
+        for (int i = 0; i < 4; ++i)
+          split2(xn[8 * kb + 2 * i], xn[8 * kb + 2 * i + 1], Xh[kb].r[i], Xl[kb].r[i]);
       const float rt = retn, ov = oldn;
+      STAMP(0)
       // F2: Y1^T = W1 X^T + b1, packed at once to the B operands of layer 2.
       // Step st = (unit block mb, k-step kb); operand reads run 2 steps ahead.
-      constexpr bool SIGN_ONLY = ACT == ACT_RELU || ACT == ACT_LEAKY;   // act' needs the sign of h1 only
       Frag H1h[NKT], H1l[NKT];
-      u32 h1pos = 0;                       // bit 4 mb + i: h1[mb][i] > 0
       {
         constexpr int NST = NB * NKB1;
-        Frag Ah[3], Al[3];
+        Frag Ah[RING], Al[RING];
         auto ld = [&](int st, int b) {
           const char* p = w1rd + 16 * (st / NKB1) * P1B + 64 * (st % NKB1);
           Ah[b] = *reinterpret_cast<const Frag*>(p);
           Al[b] = *reinterpret_cast<const Frag*>(p + W1_IMG);
         };
-        ld(0, 0);
-        ld(1, 1);
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) ld(i, i);
         f32x4 accM, accX, tprev;
+        f32x4 biasn = *reinterpret_cast<const f32x4*>(Bs + 4 * g);      // read one block ahead
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
           const int mb = st / NKB1, kb = st % NKB1;
-          if (st + 2 < NST) ld(st + 2, (st + 2) % 3);
+          if (st + RING - 1 < NST) ld(st + RING - 1, (st + RING - 1) % RING);
+          f32x4 biasc = biasn;
+          if (kb == 0 && mb + 1 < NB) biasn = *reinterpret_cast<const f32x4*>(Bs + 16 * (mb + 1) + 4 * g);
           fence_sched();
           if (kb == 0) {
-            accM = *reinterpret_cast<const f32x4*>(Bs + 16 * mb + 4 * g);
+            accM = biasc;
             accX = (f32x4){0, 0, 0, 0};
           }
-          mma3(Ah[st % 3], Al[st % 3], Xh[kb], Xl[kb], accM, accX);
+          mma3(Ah[st % RING], Al[st % RING], Xh[kb], Xl[kb], accM, accX);
           if (kb == NKB1 - 1) {
             f32x4 t;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              t[i] = act_f<ACT>(accM[i] + accX[i] * LO_INV);
-              if (SIGN_ONLY) h1pos |= t[i] > 0.f ? 1u << (4 * mb + i) : 0u;
-            }
+            for (int i = 0; i < 4; ++i) t[i] = act_f<ACT>(accM[i] + accX[i] * LO_INV);
             if (mb & 1) pack_parts(tprev, t, H1h[mb >> 1], H1l[mb >> 1]);
             else tprev = t;
           }
         }
       }
+      STAMP(1)
       // F4: Y2^T = W2 H1^T + b2.  Step st = (h2 block mb, k-step kb).
       f32x4 h2[NB];
       float vdot = 0.f;                    // w3 . H2 of this lane's units
       {
-        Frag Ah[3], Al[3];
+        const int w2sw = fresh(w2sw0);
+        Frag Ah[RING], Al[RING];
         auto ld = [&](int st, int b) {
           const char* rowp = sm + OFF_W2 + (16 * (st >> 2) + c) * P2B;
 #pragma unroll
@@ -304,21 +322,33 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
             put2(Al[b], s, lds_rd64(rowp + W2_IMG + off));
           }
         };
-        ld(0, 0);
-        ld(1, 1);
-        f32x4 accM, accX;
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) ld(i, i);
+        f32x4 accM, accX, w3v;
+        f32x4 biasn = *reinterpret_cast<const f32x4*>(Bs + HID + 4 * g);  // read one block ahead
 #pragma unroll
         for (int st = 0; st < NB * NKT; ++st) {
           const int mb = st >> 2, kb = st & 3;
-          if (st + 2 < NB * NKT) ld(st + 2, (st + 2) % 3);
+#ifndef M16_F4_NOLD
+          if (st + RING - 1 < NB * NKT) ld(st + RING - 1, (st + RING - 1) % RING);
+#endif
+          f32x4 biasc = biasn;
+          if (kb == 0) {
+            if (mb + 1 < NB) biasn = *reinterpret_cast<const f32x4*>(Bs + HID + 16 * (mb + 1) + 4 * g);
+            w3v = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 16 * mb + 4 * g);
+          }
           fence_sched();
           if (kb == 0) {
-            accM = *reinterpret_cast<const f32x4*>(Bs + HID + 16 * mb + 4 * g);
+            accM = biasc;
             accX = (f32x4){0, 0, 0, 0};
           }
-          mma3(Ah[st % 3], Al[st % 3], H1h[kb], H1l[kb], accM, accX);
+#ifdef M16_F4_NOMFMA
+          asm volatile("" :: "v"(Ah[st % RING].r[0]), "v"(Ah[st % RING].r[1]), "v"(Ah[st % RING].r[2]), "v"(Ah[st % RING].r[3]),
+                       "v"(Al[st % RING].r[0]), "v"(Al[st % RING].r[1]), "v"(Al[st % RING].r[2]), "v"(Al[st % RING].r[3]));
+#else
+          mma3(Ah[st % RING], Al[st % RING], H1h[kb], H1l[kb], accM, accX);
+#endif
           if (kb == NKT - 1) {
-            const f32x4 w3v = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 16 * mb + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               h2[mb][i] = act_f<ACT>(accM[i] + accX[i] * LO_INV);
@@ -327,6 +357,7 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           }
         }
       }
+      STAMP(2)
       // value, loss and dL/dv (mean over ALL rows R of the epoch)
       float dv;
       {
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
             const f32x4 w3v = *reinterpret_cast<const f32x4*>(Bs + 2 * HID + 16 * m + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float hv = h2[m][i];
+              const float hv = freshf(h2[m][i]);
               gw3[m][i] += dv * hv;
               t[ps][i] = dvs * w3v[i] * act_d<ACT>(hv);
             }
@@ -367,7 +398,9 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           fence_sched();
         }
       }
+      STAMP(3)
       __syncthreads();                     // end P1: gradient waves finished dW1(i-1)
+      STAMP(4)
       // ---- P2: [batch][unit] images of H1 and dY2; the next tile's rows are fetched meanwhile
       {
         cur.advance(a.T);
@@ -376,6 +409,7 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
         if (a.clip > 0.f) oldn = a.old_v[rcn];
       }
       {
+        const int tsw = fresh(tsw0);
         char* th = sm + OFF_TH + trow * PTB;
         char* td = sm + OFF_TD + trow * PTB;
 #pragma unroll
@@ -388,12 +422,15 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           *reinterpret_cast<u32x2*>(td + T_IMG + off) = (u32x2){Dl[kb].r[2 * s], Dl[kb].r[2 * s + 1]};
         }
       }
+      STAMP(5)
       __syncthreads();                     // end P2
+      STAMP(6)
       // ---- P3: dH1^T = W2^T dY2^T (A = W2 through the transpose read), dY1.
       // Step st = (hidden-1 block pb, k-step kb over h2).
       Frag E1h[NKT], E1l[NKT];
       {
-        Frag Ah[3], Al[3];
+        const int w2tsw = fresh(w2tsw0);
+        Frag Ah[RING], Al[RING];
         auto ld = [&](int st, int b) {
           const int pb = st >> 2, kb = st & 3;
 #pragma unroll
@@ -403,34 +440,43 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
             put2(Al[b], s, lds_tr64(p + W2_IMG));
           }
         };
-        ld(0, 0);
-        ld(1, 1);
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) ld(i, i);
         f32x4 accM, accX, dprev;
+        // H1 of block pb (this lane's own stores of P2), for act'
+        const int tswr = fresh(tsw0);
+        const char* hrow = sm + OFF_TH + trow * PTB;
+        u32x2 hh[2], hl[2];
 #pragma unroll
         for (int st = 0; st < NB * NKT; ++st) {
           const int pb = st >> 2, kb = st & 3;
-          if (st + 2 < NB * NKT) ld(st + 2, (st + 2) % 3);
+          if (st + RING - 1 < NB * NKT) ld(st + RING - 1, (st + RING - 1) % RING);
+          if (kb == 0) {
+            const int off = (32 * pb + 8 * g) ^ tswr;
+            hh[pb & 1] = lds_rd64(hrow + off);
+            hl[pb & 1] = lds_rd64(hrow + T_IMG + off);
+          }
           fence_sched();
           if (kb == 0) { accM = (f32x4){0, 0, 0, 0}; accX = (f32x4){0, 0, 0, 0}; }
-          mma3(Ah[st % 3], Al[st % 3], Dh[kb], Dl[kb], accM, accX);
+          mma3(Ah[st % RING], Al[st % RING], Dh[kb], Dl[kb], accM, accX);
           if (kb == NKT - 1) {
             const int pb2 = pb >> 1, ps = pb & 1;
             f32x4 d;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float hv = SIGN_ONLY
-                  ? ((h1pos >> (4 * pb + i)) & 1u ? 1.f : 0.f)
-                  : join_parts(H1h[pb2].r[2 * ps + (i >> 1)], H1l[pb2].r[2 * ps + (i >> 1)], i & 1);
-              d[i] = (accM[i] + accX[i] * LO_INV) * act_d<ACT>(hv);
-            }
+            for (int i = 0; i < 4; ++i)
+              d[i] = (accM[i] + accX[i] * LO_INV) *
+                     act_d<ACT>(join_parts(hh[pb & 1][i >> 1], hl[pb & 1][i >> 1], i & 1));
             if (ps) pack_parts(dprev, d, E1h[pb2], E1l[pb2]);
             else dprev = d;
           }
         }
       }
+      STAMP(7)
       __syncthreads();                     // end P3: gradient waves finished dW2(i)
+      STAMP(8)
       // ---- P4: dY1 image over dY2, X image over H1
       {
+        const int tsw = fresh(tsw0);
         char* td = sm + OFF_TD + trow * PTB;
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
@@ -450,7 +496,9 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           }
         }
       }
+      STAMP(9)
       __syncthreads();                     // end P4
+      STAMP(10)
     }
     __syncthreads();                       // gradient waves: dW1 of the last tile
     // ---- dw3: reduce over the 16 batch lanes, then over the 4 chain waves
@@ -474,12 +522,17 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
       ob3[1] = sc[4] + sc[5] + sc[6] + sc[7];   // sum of squared errors of this WG
       ob3[2] = 0.f;
     }
+#ifdef M16_STAMP
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 0)
+      for (int k = 0; k < 12; ++k) out[k] = (float)stt[k];
+#endif
   } else {
     // ======================= gradient waves =======================
     // this wave's output rows: unit blocks mb = 2 wave + mi (h2 for dW2, hidden-1 for dW1)
     f32x4 gW2M[2][NB], gW2X[2][NB];      // [mi][p block]: rows 4 g + i, column c
     f32x4 gW1M[2][NCB], gW1X[2][NCB];    // [mi][feature block]
-    f32x4 gb2[2];
+    f32x4 gb2[2], gb1[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -487,9 +540,11 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
 #pragma unroll
       for (int n = 0; n < NCB; ++n) { gW1M[mi][n] = (f32x4){0, 0, 0, 0}; gW1X[mi][n] = (f32x4){0, 0, 0, 0}; }
       gb2[mi] = (f32x4){0, 0, 0, 0};
+      gb1[mi] = (f32x4){0, 0, 0, 0};
     }
-    const int tsw = swzT(krow);
-    const int xsw = swzX(krow);
+    const int tsw0 = swzT(krow);
+    const int xsw0 = swzX(krow);
+    int tsw = tsw0, xsw = xsw0;
     const Frag ones = {{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}};     // 1.0
     const Frag ones_lo = {{0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u}};  // 2^-11
     // A fragments of this wave's two unit blocks from the Td image, k-step kb
@@ -506,7 +561,9 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
     };
     // dW1[unit][f] += sum_b dY1[b][unit] X[b][f].  Step st = (batch k-step kb, feature block n).
     auto dw1 = [&]() {
-      Frag ah[2], al[2], Bh[3], Bl[3];
+      tsw = fresh(tsw0);
+      xsw = fresh(xsw0);
+      Frag ah[2], al[2], Bh[GRING], Bl[GRING];
       auto ldb = [&](int st, int b) {
         const int kb = st / NCB, n = st % NCB;
 #pragma unroll
@@ -517,28 +574,45 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
         }
       };
       load_a(0, ah, al);
-      ldb(0, 0);
-      ldb(1, 1);
+#pragma unroll
+      for (int i = 0; i < GRING - 1; ++i) ldb(i, i);
 #pragma unroll
       for (int st = 0; st < 2 * NCB; ++st) {
         const int n = st % NCB;
-        if (st + 2 < 2 * NCB) ldb(st + 2, (st + 2) % 3);
+        if (st + GRING - 1 < 2 * NCB) ldb(st + GRING - 1, (st + GRING - 1) % GRING);
         fence_sched();
-        mma3(ah[0], al[0], Bh[st % 3], Bl[st % 3], gW1M[0][n], gW1X[0][n]);
-        mma3(ah[1], al[1], Bh[st % 3], Bl[st % 3], gW1M[1][n], gW1X[1][n]);
+        if (n == 0) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            gb1[mi] = mfma16(ah[mi], ones, gb1[mi]);
+            gb1[mi] = mfma16(al[mi], ones_lo, gb1[mi]);
+          }
+        }
+        mma3(ah[0], al[0], Bh[st % GRING], Bl[st % GRING], gW1M[0][n], gW1X[0][n]);
+        mma3(ah[1], al[1], Bh[st % GRING], Bl[st % GRING], gW1M[1][n], gW1X[1][n]);
         if (st == NCB - 1) { fence_sched(); load_a(1, ah, al); }
       }
     };
+#ifdef M16_STAMP
+    long long gst[4] = {0, 0, 0, 0};
+    long long gprev = __builtin_readcyclecounter();
+#define GSTAMP(k) { const long long tn = __builtin_readcyclecounter(); gst[k] += tn - gprev; gprev = tn; }
+#else
+#define GSTAMP(k)
+#endif
     bool first = true;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       if (!first) dw1();                   // P1: previous tile
       first = false;
+      GSTAMP(0)
       __syncthreads();                     // end P1
       __syncthreads();                     // end P2
+      GSTAMP(1)
       // ---- P3: dW2[h2][p] += sum_b dY2[b][h2] H1[b][p], db2 through a ones operand.
       // Step st = (batch k-step kb, hidden-1 block n).
       {
-        Frag ah[2], al[2], Bh[3], Bl[3];
+        tsw = fresh(tsw0);
+        Frag ah[2], al[2], Bh[GRING], Bl[GRING];
         auto ldb = [&](int st, int b) {
           const int kb = st >> 3, n = st & 7;
 #pragma unroll
@@ -549,12 +623,12 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           }
         };
         load_a(0, ah, al);
-        ldb(0, 0);
-        ldb(1, 1);
+#pragma unroll
+        for (int i = 0; i < GRING - 1; ++i) ldb(i, i);
 #pragma unroll
         for (int st = 0; st < 2 * NB; ++st) {
           const int n = st & 7;
-          if (st + 2 < 2 * NB) ldb(st + 2, (st + 2) % 3);
+          if (st + GRING - 1 < 2 * NB) ldb(st + GRING - 1, (st + GRING - 1) % GRING);
           fence_sched();
           if (n == 0) {
 #pragma unroll
@@ -563,13 +637,15 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
               gb2[mi] = mfma16(al[mi], ones_lo, gb2[mi]);
             }
           }
-          mma3(ah[0], al[0], Bh[st % 3], Bl[st % 3], gW2M[0][n], gW2X[0][n]);
-          mma3(ah[1], al[1], Bh[st % 3], Bl[st % 3], gW2M[1][n], gW2X[1][n]);
+          mma3(ah[0], al[0], Bh[st % GRING], Bl[st % GRING], gW2M[0][n], gW2X[0][n]);
+          mma3(ah[1], al[1], Bh[st % GRING], Bl[st % GRING], gW2M[1][n], gW2X[1][n]);
           if (st == NB - 1) { fence_sched(); load_a(1, ah, al); }
         }
       }
+      GSTAMP(2)
       __syncthreads();                     // end P3
       __syncthreads();                     // end P4
+      GSTAMP(3)
     }
     if (!first) dw1();                     // last tile
     __syncthreads();
@@ -588,18 +664,25 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
           const int f = 16 * n + c;
           const float v = (gW1M[mi][n][i] + gW1X[mi][n][i] * LO_INV) * ig;
           if (f < din) oW1[u * din + f] = v;
-          else if (f == din) ob1[u] = v;
         }
-        if (c == 0) ob2[u] = gb2[mi][i] * ig;
+        if (c == 0) {
+          ob1[u] = gb1[mi][i] * ig;
+          ob2[u] = gb2[mi][i] * ig;
+        }
       }
     }
     __syncthreads();                       // matches the chain waves' final barrier
+#ifdef M16_STAMP
+    __syncthreads();
+    if (tid == 256 && blockIdx.x == 0)
+      for (int k = 0; k < 4; ++k) out[12 + k] = (float)gst[k];
+#endif
   }
 }
 
 template <int ACT>
 void launch16(const Mlp16Args& aa, int grid, hipStream_t st) {
-  if (aa.a.din <= 31) {
+  if (aa.a.din <= 32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd16_kernel<ACT, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES);
     hipLaunchKernelGGL((mlp_critic_bwd16_kernel<ACT, 1>), dim3(grid), dim3(2 * MLP_BT), LDS16_BYTES,
