@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 NUM_ENV, NUM_BASIS, EPOCHS = 4096, 5, 50
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix (dense, = vector peak)
+F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 matrix, dense (no sparsity)
 
 
 def build_agent(num_env, seed):
@@ -109,6 +110,8 @@ def roofline(agent):
     saved = [p.grad for p in net.parameters()]
     run = critic_ops.EpochRunner(net)
     us_c = kernel_time_us(lambda: run.epoch(xs, rets, rets, 0.0), launches=5)
+    run16 = critic_ops.EpochRunner(net, arith="f16x2")
+    us_c16 = kernel_time_us(lambda: run16.epoch(xs, rets, rets, 0.0), launches=5)
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
@@ -119,6 +122,17 @@ def roofline(agent):
               "traffic": pmc_traffic("mlp_critic_bwd_kernel"),
               "us_per_launch": round(us_c, 1),
               "algorithmic_flops": flops, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+    critic16 = {
+        "kernel": "mlp_critic_bwd16_kernel<relu,2> (+ mlp_finish_kernel)",
+        "bound": "mfma", "achieved": round(flops / us_c16 / 1e6, 2),
+        "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": round(flops / us_c16 / 1e6 / F16_MFMA_PEAK_TF, 4),
+        "traffic": None, "us_per_launch": round(us_c16, 1),
+        "algorithmic_flops": flops,
+        "mfma_flops_issued": 3 * flops,
+        "frac_issued": round(3 * flops / us_c16 / 1e6 / F16_MFMA_PEAK_TF, 4),
+        "dtype": "f16x2 split operands, fp32 accumulate "
+                 "(v_mfma_f32_16x16x32_f16; 3 MFMAs per product)"}
     del full, xs
     r = torch.randn(N, T, device="cuda", generator=g)
     v = torch.randn(N, T + 1, device="cuda", generator=g)
@@ -164,6 +178,7 @@ def roofline(agent):
                 "the ~100 trajectory / log-prob evaluations of a rollout + "
                 "update (ops._times_flags)"}}
     extra["gae_scan"] = gae
+    extra["critic_split_f16"] = critic16
     return critic, extra
 
 
@@ -207,6 +222,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-f16", action="store_true",
+                    help="skip the second timed region (critic_arith=f16x2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,6 +272,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, pol_time = tt.tolist()
 
+    # the same K steps (after W warm-up steps) with the critic epochs on the
+    # split-f16 kernel (agent option critic_arith="f16x2"), reported beside
+    # the fp32 figure as "split_f16_critic"
+    fast = None
+    if not args.no_split_f16:
+        agent.critic_arith = "f16x2"
+        agent._critic_split = 0
+        for _ in range(args.warmup):
+            agent.step()
+        barrier()
+        t1 = time.perf_counter()
+        pol16 = 0.0
+        for _ in range(args.steps):
+            res = agent.step()
+            pol16 += res["update_policy_time"]
+        barrier()
+        el16 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el16, pol16], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el16, pol16 = tt.tolist()
+        fast = (el16, pol16)
+        agent.critic_arith = "f32"
+
     if rank == 0:
         env_steps = world * NUM_ENV * T * args.steps
         print("[bench] timed region: %.3f s" % elapsed, file=sys.stderr,
@@ -281,6 +322,18 @@ def main():
                        "parallelism": "env-shard x%d" % world},
             "roofline": roof, "roofline_extra": extra,
         }
+        if fast is not None:
+            out["split_f16_critic"] = {
+                "what": "the same workload with the 50 critic epochs on the "
+                        "split-f16 matrix-core kernel (agent option "
+                        "critic_arith=f16x2: fp32 operands carried as two f16 "
+                        "parts, fp32 accumulate; parity-tested to the fp32 "
+                        "kernel's own tolerances)",
+                "value": round(env_steps / fast[0], 1), "unit": "env-steps/s",
+                "ms_per_step": round(fast[0] / args.steps * 1e3, 2),
+                "policy_updates_per_sec": round(
+                    EPOCHS * args.steps / fast[1], 2),
+                "roofline": extra["critic_split_f16"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -10,6 +10,10 @@ for wg in [int(a) for a in sys.argv[2:]] or (0, 208, 224, 240, 248):
     a["critic_workgroups"] = wg or 256
     if os.environ.get("NO_GRAPH"):
         a["graph_policy_update"] = False
+    if os.environ.get("GRAPH"):
+        a["graph_policy_update"] = True
+    if os.environ.get("CRITIC_ARITH"):
+        a["critic_arith"] = os.environ["CRITIC_ARITH"]
     if wg < 0:                       # -n: CU-masked streams, n units per XCD for the critic
         a["critic_cus_per_xcd"] = -wg
     exp = MPExperiment(); exp.initialize(cfg, 0, None)

@@ -59,6 +59,7 @@ class EpochRunner:
         f16 operands on the f16 matrix cores, csrc/mlp16.hip)."""
         assert supported(mlp)
         assert arith in ("f32", "f16x2"), arith
+        self.arith = arith
         self.entry = "tce_mlp_critic_" + arith
         self.mlp = mlp
         lib = _lib.load()

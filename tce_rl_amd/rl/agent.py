@@ -192,10 +192,11 @@ class _CriticEpochs:
         self.x, self.returns, self.old_values = x, returns, old_values
         opt = self.opt = agent.critic_optimizer
         run = getattr(agent, "_critic_runner", None)
+        arith = getattr(agent, "critic_arith", "f32")
         if run is None or run.mlp is not agent.critic.net or \
-                run.flat is not opt.flat_grad:
+                run.flat is not opt.flat_grad or run.arith != arith:
             run = agent._critic_runner = critic_ops.EpochRunner(
-                agent.critic.net, opt.flat_grad)
+                agent.critic.net, opt.flat_grad, arith=arith)
         self.runner = run
         opt.bind_grads()
         self.E = agent.epochs_critic
@@ -257,6 +258,12 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.graph_policy_update = kwargs.get("graph_policy_update", False)
         self.fused_policy_objective = kwargs.get("fused_policy_objective",
                                                  True)
+        # arithmetic of the fused critic epoch: "f32" = exact-fp32 matrix cores
+        # (csrc/mlp.hip), "f16x2" = split-f16 operands on the f16 matrix cores
+        # (csrc/mlp16.hip: fp32-grade results, 2.4x faster)
+        self.critic_arith = kwargs.get("critic_arith", "f32")
+        if self.critic_arith not in ("f32", "f16x2"):
+            raise NotImplementedError("critic_arith %r" % (self.critic_arith,))
         self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
         self.critic_cus_per_xcd = kwargs.get("critic_cus_per_xcd", None)
         self.adaptive_critic_split = kwargs.get("adaptive_critic_split", True)

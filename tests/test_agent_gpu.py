@@ -44,12 +44,19 @@ def test_agent_step_matches_cpu_oracle_other_shapes(env, nb, dtype):
     _agent_vs_oracle(True, True, False, env, nb, dtype)
 
 
-def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32"):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_agent_step_matches_cpu_oracle_split_f16_critic(overlap):
+    """critic_arith="f16x2" (split-f16 matrix-core critic epochs) is held to
+    the same tolerances against the CPU oracle as the exact-fp32 kernel."""
+    _agent_vs_oracle(overlap, True, False, "metaworld", 5, critic_arith="f16x2")
+
+
+def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32", **kw):
     from oracle.agent_oracle import OracleTCE
     N, EPOCHS = 16, 3
     agent, cfg = build(N, EPOCHS, overlap, env=env, num_basis=nb, dtype=dtype,
                        fused_policy_objective=fused,
-                       graph_policy_update=graph)
+                       graph_policy_update=graph, **kw)
     oracle = OracleTCE(cfg["params"], N)
     # identical weights
     with torch.no_grad():
