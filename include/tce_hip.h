@@ -197,6 +197,10 @@ int tce_sum_dim0_f64(const double* x, double* out, double* ws, int64_t N, int64_
  *   C++ cpp_projection / ITPAL solver, conda_env.sh:34) followed by the entropy
  *   control scaling; beta: device scalar or NULL.  ctx: double
  *   [B, tce_kl_cov_proj_ctx_len(K)] saved for the backward call.  K <= 64.
+ *   warm_start != 0: ctx still holds the result of a previous call for nearby
+ *   inputs (the previous policy epoch: same B, K, slightly different L): its
+ *   eigenvectors start the Jacobi iteration (2-3 sweeps instead of 8-10); the
+ *   first such call must find ctx zero-filled.
  */
 int tce_chol_build_fwd_f32(const float* vec, float* L, int64_t B, int K, int nvec,
                            float min_std, void* stream);
@@ -221,10 +225,12 @@ int tce_kl_cov_part_f64(int bwd, const double* L, const double* L_old,
 int64_t tce_kl_cov_proj_ctx_len(int K);
 int tce_kl_cov_proj_fwd_f32(const float* L, const float* L_old, int64_t L_old_stride,
                             double eps_cov, const float* beta, int entropy_eq,
-                            float* proj_L, double* ctx, int64_t B, int K, void* stream);
+                            float* proj_L, double* ctx, int64_t B, int K, int warm_start,
+                            void* stream);
 int tce_kl_cov_proj_fwd_f64(const double* L, const double* L_old, int64_t L_old_stride,
                             double eps_cov, const double* beta, int entropy_eq,
-                            double* proj_L, double* ctx, int64_t B, int K, void* stream);
+                            double* proj_L, double* ctx, int64_t B, int K, int warm_start,
+                            void* stream);
 int tce_kl_cov_proj_bwd_f32(const float* L, const float* L_old, int64_t L_old_stride,
                             const float* proj_L, const double* ctx,
                             const float* grad_proj, float* grad_L, int64_t B, int K,

@@ -6,6 +6,8 @@ from tce_rl_amd.mp_exp import MPExperiment
 wg = int(sys.argv[1]) if len(sys.argv) > 1 else 224
 cfg = tce_config("metaworld", num_env=4096, num_basis=5, epochs=50, evaluation_interval=0)
 cfg["params"]["agent"]["args"]["critic_workgroups"] = wg
+if os.environ.get("CRITIC_ARITH"):
+    cfg["params"]["agent"]["args"]["critic_arith"] = os.environ["CRITIC_ARITH"]
 exp = MPExperiment(); exp.initialize(cfg, 0, None)
 for i in range(4):
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -229,12 +229,13 @@ template <typename real>
 __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     const real* __restrict__ L, const real* __restrict__ Lo, int64_t sLo, double eps,
     const real* __restrict__ beta, int entropy_eq, real* __restrict__ projL,
-    double* __restrict__ ctx, int K) {
+    double* __restrict__ ctx, int K, int warm_start) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int KP = K + 1;
   double* A = reinterpret_cast<double*>(smem_raw);   // A -> rotated -> Y
   double* Vt = A + K * KP;
   double* Los = Vt + K * KP;                          // Lo -> S -> Lp
+  double* Tmp = Los + K * KP;                         // warm start scratch
   __shared__ double lam[64];
   __shared__ double red[4];
   __shared__ double s_eta;
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
   const bool active = kl0 > eps;                      // block-uniform
   double eta = 0;
   if (active) {
-    sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP);
+    // warm start: ctx still holds the eigenvectors of the previous call (its
+    // "active" slot says whether it wrote any)
+    const bool warm = warm_start && cb[(int64_t)K * K + K + 1] == 1.0;
+    sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP, warm ? cb : nullptr, Tmp);
     if (threadIdx.x < 64) {
       const bool live = threadIdx.x < K;
       const double lm = live ? lam[threadIdx.x] : 1.0;
@@ -547,14 +551,16 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
   int tce_kl_cov_proj_fwd_##SFX(const REAL* L, const REAL* L_old,                 \
                                 int64_t L_old_stride, double eps_cov,             \
                                 const REAL* beta, int entropy_eq, REAL* proj_L,   \
-                                double* ctx, int64_t B, int K, void* stream) {    \
+                                double* ctx, int64_t B, int K, int warm_start,    \
+                                void* stream) {                                   \
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && B > 0 && K > 0 && K <= 64,       \
                   "kl_cov_proj: bad arguments (K <= 64)");                        \
-    const size_t lds = 3 * (size_t)K * (K + 1) * sizeof(double);                  \
+    const size_t lds = 4 * (size_t)K * (K + 1) * sizeof(double);                  \
     set_lds(kl_cov_proj_fwd_kernel<REAL>, lds);                                   \
     hipLaunchKernelGGL(kl_cov_proj_fwd_kernel<REAL>, dim3((unsigned)B),           \
                        dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,           \
-                       L_old_stride, eps_cov, beta, entropy_eq, proj_L, ctx, K);  \
+                       L_old_stride, eps_cov, beta, entropy_eq, proj_L, ctx, K,   \
+                       warm_start);                                               \
     TCE_LAUNCH_CHECK();                                                           \
     return 0;                                                                     \
   }                                                                               \

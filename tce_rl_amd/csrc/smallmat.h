@@ -120,10 +120,31 @@ __device__ inline double sm_block_sum(double v, double* scratch) { return block_
 // mutually orthogonal.  Then A A^T(original) = Q diag(lam) Q^T with
 // Q[i][k] = Vt[k][i], lam[k] = |row k of A|^2.  8 lanes per row pair, K/2
 // independent pairs per round (round-robin tournament), one barrier per round.
-__device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* flag, int K, int KP) {
-  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
-    const int i = e / K, j = e - i * K;
-    Vt[i * KP + j] = (i == j) ? 1.0 : 0.0;
+// warm (nullable, with scratch T [K][KP]): an orthogonal K x K matrix (row-major,
+// global memory) that nearly diagonalises A A^T already -- the Vt of a previous
+// call for a nearby A.  The iteration then starts from Vt = warm, A = warm A and
+// needs 2-3 sweeps instead of 8-10.
+__device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* flag, int K, int KP,
+                                      const double* warm = nullptr, double* T = nullptr) {
+  if (warm != nullptr) {
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) Vt[(e / K) * KP + (e % K)] = warm[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      double acc = 0;
+      for (int k = 0; k < K; ++k) acc += Vt[i * KP + k] * A[k * KP + j];
+      T[i * KP + j] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      A[i * KP + j] = T[i * KP + j];
+    }
+  } else {
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      Vt[i * KP + j] = (i == j) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
   const int KE = (K + 1) & ~1;          // even player count (K odd: one bye)

@@ -517,7 +517,7 @@ class _KLCovProj(torch.autograd.Function):
         cbuf = torch.empty(B, n, dtype=torch.float64, device=L.device)
         call("tce_kl_cov_proj_fwd_" + sfx(L.dtype), ptr(L), ptr(Lo), sLo,
              float(eps_cov), ptr(beta), int(bool(entropy_eq)), ptr(proj),
-             ptr(cbuf), B, K, stream())
+             ptr(cbuf), B, K, 0, stream())
         ctx.save_for_backward(L, Lo, proj, cbuf)
         ctx.sLo = sLo
         return proj

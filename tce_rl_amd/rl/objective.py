@@ -53,6 +53,10 @@ class Context:
         self.tr_coeff = proj.trust_region_coeff
         self.tr_include_cov = int(pol.contextual_std or not agent.set_variance)
         self.ent_coef = float(agent.entropy_penalty_coef)
+        K = self.mean_old.shape[-1]
+        self.proj_ctx = torch.zeros(_lib.load().tce_kl_cov_proj_ctx_len(K),
+                                    dtype=torch.float64,
+                                    device=self.mean_old.device)
         # surrogate kernel scratch: block ticket (zeroed once) + partials
         self.sur_ws = torch.zeros(_lib.load().tce_surrogate_ws_len(),
                                   dtype=torch.float64,
@@ -75,11 +79,13 @@ class _Objective(torch.autograd.Function):
              ptr(c.L_old), 0, float(c.eps_mean), None, ptr(pm), None, None, N,
              K, st)
         pL = new(1, K, K)
-        cbuf = torch.empty(_lib.load().tce_kl_cov_proj_ctx_len(K),
-                           dtype=torch.float64, device=dev)
+        # one context buffer per update: the next epoch's eigen-decomposition
+        # starts from this epoch's eigenvectors (the backward kernel below has
+        # consumed the context by then)
+        cbuf = c.proj_ctx
         call("tce_kl_cov_proj_fwd_" + s, ptr(L_new), ptr(c.L_old), 0,
              float(c.eps_cov), ptr(c.beta), c.entropy_eq, ptr(pL), ptr(cbuf),
-             1, K, st)
+             1, K, 1, st)
         # ---- pair log-prob of the stored trajectories under the projection
         logp = new(N, P)
         B, flag = ops._mp_ws(mp, T, dev)

@@ -204,3 +204,36 @@ def test_kl_cov_projection_fp32_close(ops):
     ref = torch.linalg.cholesky(pc)
     out = ops.kl_cov_projection(L.float().cuda(), L_o.float().cuda(), 5e-4)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("K", [24, 63])
+def test_kl_cov_projection_warm_start(ops, K):
+    """warm_start: a chain of 12 slowly drifting covariances (the policy epochs
+    of one update), each projection started from the previous call's
+    eigenvectors left in the context buffer == the cold projection and its
+    backward, to double-precision rounding."""
+    from tce_rl_amd import _lib
+    from tce_rl_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(200 + K)
+    L_o = rand_chol(K, 1.0, g, 1)
+    L = rand_chol(K, 1.0, g, 1)
+    D = 0.01 * torch.tril(torch.randn(1, K, K, generator=g, dtype=F64))
+    W = torch.randn(1, K, K, generator=g, dtype=F64).cuda()
+    n = _lib.load().tce_kl_cov_proj_ctx_len(K)
+    ctx = torch.zeros(1, n, dtype=F64, device="cuda")
+    Lo_g = L_o.cuda()
+    for step in range(12):
+        Lk = (L + step * D).cuda().contiguous()
+        warm = torch.empty_like(Lk)
+        call("tce_kl_cov_proj_fwd_f64", ptr(Lk), ptr(Lo_g), 0, 5e-3, None, 0,
+             ptr(warm), ptr(ctx), 1, K, 1, stream())
+        gw = torch.empty_like(Lk)
+        call("tce_kl_cov_proj_bwd_f64", ptr(Lk), ptr(Lo_g), 0, ptr(warm),
+             ptr(ctx), ptr(W), ptr(gw), 1, K, stream())
+        Lr = Lk.clone().requires_grad_(True)
+        cold = ops.kl_cov_projection(Lr, Lo_g, 5e-3)
+        (cold * W).sum().backward()
+        assert ctx[0, K * K + K + 1].item() == 1.0          # projection active
+        torch.testing.assert_close(warm, cold.detach(), rtol=1e-10, atol=1e-11)
+        torch.testing.assert_close(torch.tril(gw), torch.tril(Lr.grad),
+                                   rtol=1e-7, atol=1e-9)
