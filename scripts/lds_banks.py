@@ -88,9 +88,11 @@ def report(P2, swz2, P1, swz1, PT, swzT, PX, swzX):
 
 
 if __name__ == "__main__":
-    print("== padded, no swizzle (P2 288, P1 144, PT 288, PX 144)")
     none = lambda r: 0
+    print("== padded, no swizzle (P2 288, P1 144, PT 288, PX 144)")
     report(288, none, 144, none, 288, none, 144, none)
-    print("== candidate")
-    report(256, lambda r: (((r >> 3) & 1) << 4) ^ ((r & 7) << 5), 96, none,
-           256, lambda r: (r & 7) << 5, 128, lambda r: (r & 7) << 4)
+    print("== csrc/mlp16.hip: P2 256 swz2, P1 96, PT 256 swzT, PX 128 swzX")
+    swz2 = lambda r: ((r & 7) << 5) ^ (((r >> 3) & 1) << 4)
+    swzT = lambda r: ((r & 3) << 5) ^ (((r >> 2) & 1) * 0x88) ^ (((r >> 3) & 1) << 4)
+    swzX = lambda r: (r & 7) << 4
+    report(256, swz2, 96, none, 256, swzT, 128, swzX)
