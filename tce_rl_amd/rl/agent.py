@@ -258,6 +258,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.graph_policy_update = kwargs.get("graph_policy_update", False)
         self.fused_policy_objective = kwargs.get("fused_policy_objective",
                                                  True)
+        # the fused objective's epoch without autograd (rl/objective.py:
+        # DirectEpoch): half the launches of an epoch
+        self.direct_policy_epoch = kwargs.get("direct_policy_epoch", True)
         # arithmetic of the fused critic epoch: "f32" = exact-fp32 matrix cores
         # (csrc/mlp.hip), "f16x2" = split-f16 operands on the f16 matrix cores
         # (csrc/mlp16.hip: fp32-grade results, 2.4x faster)
@@ -589,7 +592,20 @@ class TemporalCorrelatedAgent(AbstractAgent):
                     self.projection.temperature, self.num_iterations)
             fused_ctx = objective.Context(self, dataset, times, beta)
 
+        direct = None
+        if fused_ctx is not None and self.direct_policy_epoch and \
+                not self.graph_policy_update and \
+                objective.DirectEpoch.supported(self, states):
+            direct = objective.DirectEpoch(self, states, fused_ctx)
+        epoch_no = [0]
+
         def epoch_fused():
+            if direct is not None:
+                # no autograd, no device-side record index: the epoch number
+                # is known on the host (NaN flags are derived on the host too)
+                direct.run(rec_all[epoch_no[0], :19])
+                epoch_no[0] += 1
+                return
             mean_new, L_new = self.policy.policy(states)
             policy_loss, rec17 = objective.policy_objective(mean_new, L_new,
                                                             fused_ctx)
@@ -674,6 +690,8 @@ class TemporalCorrelatedAgent(AbstractAgent):
                                              sync=False)
 
         rec_host = rec_all.cpu().numpy()                  # ONE copy
+        if direct is not None:
+            rec_host[:, 19:22] = np.isnan(rec_host[:, :3])
         for name, bad in zip(("surrogate_loss", "entropy_loss",
                               "trust_region_loss"),
                              rec_host[:, 19:22].any(axis=0)):

@@ -63,69 +63,77 @@ class Context:
                                   device=self.mean_old.device)
 
 
+def evaluate(mean_new, L_new, c):
+    """The objective of one epoch and its gradient, kernels only (no autograd):
+    -> (g_mean [N, K], g_L [K, K], sur [2], out [16]) with sur[0] the surrogate
+    loss and out = {12 KL means, entropy, trust region loss, -, -}."""
+    N, K = mean_new.shape
+    dt, dev = mean_new.dtype, mean_new.device
+    s = sfx(dt)
+    st = stream()
+    mp = c.mp
+    T, P = c.times.shape[1], c.pairs.shape[0]
+    new = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
+    # ---- projection: mean (closed form per env), covariance (one matrix)
+    pm = new(N, K)
+    call("tce_vec_env_" + s, 1, 0, ptr(mean_new), ptr(c.mean_old),
+         ptr(c.L_old), 0, float(c.eps_mean), None, ptr(pm), None, None, N,
+         K, st)
+    pL = new(1, K, K)
+    # one context buffer per update: the next epoch's eigen-decomposition
+    # starts from this epoch's eigenvectors (the backward kernel below has
+    # consumed the context by then)
+    cbuf = c.proj_ctx
+    call("tce_kl_cov_proj_fwd_" + s, ptr(L_new), ptr(c.L_old), 0,
+         float(c.eps_cov), ptr(c.beta), c.entropy_eq, ptr(pL), ptr(cbuf),
+         1, K, 1, st)
+    # ---- pair log-prob of the stored trajectories under the projection
+    logp = new(N, P)
+    B, flag = ops._mp_ws(mp, T, dev)
+    work = ops._pl_work(mean_new, N, P, mp, 0, True)
+    flags = c.general | (ops._times_flags(mp, c.times, c.t0) & 2)
+    pl = lambda f: (ptr(c.traj), ptr(pm), ptr(pL), 0, ptr(c.pairs),
+                    *mp.c_args(), ptr(c.times), f, ptr(c.t0), ptr(c.y0),
+                    ptr(c.v0), mp.cov_reg)
+    pl_args = pl(flags)
+    call("tce_pair_logprob_fwd_" + s, *pl_args, ptr(logp), ptr(B),
+         ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
+    # ---- surrogate loss and d/d logp
+    sur = new(2)
+    glp = new(N, P)
+    call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
+         N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
+    g_pm, g_pL = new(N, K), new(K, K)
+    pl_args = pl(c.general | 2 | 4)     # the forward call left table + pair factors
+    call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
+         ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
+    # ---- KL diagnostics, entropy, trust region loss (+ its gradients)
+    out = new(16)
+    g_mean, g_L = new(N, K), new(K, K)
+    ws = torch.empty(_lib.load().tce_kl_shared_ws_len(N),
+                     dtype=torch.float64, device=dev)
+    call("tce_kl_shared_" + s, ptr(mean_new), ptr(c.mean_old), ptr(pm),
+         ptr(L_new), ptr(c.L_old), ptr(pL), N, K, float(c.tr_coeff),
+         c.tr_include_cov, ptr(out), ptr(g_mean), ptr(g_L), ptr(ws), st)
+    if c.ent_coef != 0.0:           # d(-coef * entropy(proj)) / d proj_L
+        g_pL = g_pL - c.ent_coef * torch.diag(1.0 / pL[0].diagonal())
+    # ---- back through the projection
+    gm_p = new(N, K)
+    call("tce_vec_env_" + s, 1, 1, ptr(mean_new), ptr(c.mean_old),
+         ptr(c.L_old), 0, float(c.eps_mean), ptr(g_pm), None, ptr(gm_p),
+         None, N, K, st)
+    gL_p = new(1, K, K)
+    call("tce_kl_cov_proj_bwd_" + s, ptr(L_new), ptr(c.L_old), 0, ptr(pL),
+         ptr(cbuf), ptr(g_pL), ptr(gL_p), 1, K, st)
+    g_mean.add_(gm_p)
+    g_L.add_(gL_p[0])
+    return g_mean, g_L, sur, out
+
+
 class _Objective(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean_new, L_new, c):
-        N, K = mean_new.shape
-        dt, dev = mean_new.dtype, mean_new.device
-        s = sfx(dt)
-        st = stream()
-        mp = c.mp
-        T, P = c.times.shape[1], c.pairs.shape[0]
-        new = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
-        # ---- projection: mean (closed form per env), covariance (one matrix)
-        pm = new(N, K)
-        call("tce_vec_env_" + s, 1, 0, ptr(mean_new), ptr(c.mean_old),
-             ptr(c.L_old), 0, float(c.eps_mean), None, ptr(pm), None, None, N,
-             K, st)
-        pL = new(1, K, K)
-        # one context buffer per update: the next epoch's eigen-decomposition
-        # starts from this epoch's eigenvectors (the backward kernel below has
-        # consumed the context by then)
-        cbuf = c.proj_ctx
-        call("tce_kl_cov_proj_fwd_" + s, ptr(L_new), ptr(c.L_old), 0,
-             float(c.eps_cov), ptr(c.beta), c.entropy_eq, ptr(pL), ptr(cbuf),
-             1, K, 1, st)
-        # ---- pair log-prob of the stored trajectories under the projection
-        logp = new(N, P)
-        B, flag = ops._mp_ws(mp, T, dev)
-        work = ops._pl_work(mean_new, N, P, mp, 0, True)
-        flags = c.general | (ops._times_flags(mp, c.times, c.t0) & 2)
-        pl = lambda f: (ptr(c.traj), ptr(pm), ptr(pL), 0, ptr(c.pairs),
-                        *mp.c_args(), ptr(c.times), f, ptr(c.t0), ptr(c.y0),
-                        ptr(c.v0), mp.cov_reg)
-        pl_args = pl(flags)
-        call("tce_pair_logprob_fwd_" + s, *pl_args, ptr(logp), ptr(B),
-             ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
-        # ---- surrogate loss and d/d logp
-        sur = new(2)
-        glp = new(N, P)
-        call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
-             N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
-        g_pm, g_pL = new(N, K), new(K, K)
-        pl_args = pl(c.general | 2 | 4)     # the forward call left table + pair factors
-        call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
-             ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
-        # ---- KL diagnostics, entropy, trust region loss (+ its gradients)
-        out = new(16)
-        g_mean, g_L = new(N, K), new(K, K)
-        ws = torch.empty(_lib.load().tce_kl_shared_ws_len(N),
-                         dtype=torch.float64, device=dev)
-        call("tce_kl_shared_" + s, ptr(mean_new), ptr(c.mean_old), ptr(pm),
-             ptr(L_new), ptr(c.L_old), ptr(pL), N, K, float(c.tr_coeff),
-             c.tr_include_cov, ptr(out), ptr(g_mean), ptr(g_L), ptr(ws), st)
-        if c.ent_coef != 0.0:           # d(-coef * entropy(proj)) / d proj_L
-            g_pL = g_pL - c.ent_coef * torch.diag(1.0 / pL[0].diagonal())
-        # ---- back through the projection
-        gm_p = new(N, K)
-        call("tce_vec_env_" + s, 1, 1, ptr(mean_new), ptr(c.mean_old),
-             ptr(c.L_old), 0, float(c.eps_mean), ptr(g_pm), None, ptr(gm_p),
-             None, N, K, st)
-        gL_p = new(1, K, K)
-        call("tce_kl_cov_proj_bwd_" + s, ptr(L_new), ptr(c.L_old), 0, ptr(pL),
-             ptr(cbuf), ptr(g_pL), ptr(gL_p), 1, K, st)
-        g_mean.add_(gm_p)
-        g_L.add_(gL_p[0])
+        g_mean, g_L, sur, out = evaluate(mean_new, L_new, c)
         ctx.save_for_backward(g_mean, g_L)
         # {surrogate, entropy loss, trust region loss, total, entropy, kl x 12}
         ent = out[12]
@@ -147,3 +155,109 @@ def policy_objective(mean_new, L_new, context):
     base = base if base.is_contiguous() else base.contiguous()
     mean_new = mean_new if mean_new.is_contiguous() else mean_new.contiguous()
     return _Objective.apply(mean_new, base, context)
+
+
+class DirectEpoch:
+    """One policy epoch of the fused objective WITHOUT autograd: forward of the
+    mean net (two 128-wide hidden layers in the fused MFMA kernel + the output
+    GEMM) and of the Cholesky head, ``evaluate`` (objective + its gradient),
+    then the parameter gradients written straight into the optimizer's flat
+    gradient buffer -- the output layer's two GEMMs, the hidden layers' fused
+    backward kernel, the Cholesky head's backward -- and the record row.  Same
+    arithmetic as the autograd path (``policy_objective`` + ``backward()``; the
+    parity tests run both), ~30 launches per epoch instead of ~56: the policy
+    epochs are bound by launch overhead.
+
+    Applies to the configuration the fused objective itself applies to plus:
+    float32 mean net D_in <= 40 -> 128 -> 128 -> K without an output
+    activation, parameters in a ``FlatAdam`` in the order mean net, variance
+    variable."""
+
+    @staticmethod
+    def supported(agent, states):
+        from .. import critic_ops
+        from ..optim import FlatAdam
+        pol, opt = agent.policy, agent.policy_optimizer
+        net = pol.mean_net
+        if not isinstance(opt, FlatAdam) or pol.contextual_cov:
+            return False
+        if not (critic_ops.hidden_supported(net, states)
+                and net.act_func_last_type is None and states.dim() == 2):
+            return False
+        params = list(net.parameters()) + [pol.variance_net.variable]
+        return len(params) == len(opt._params) and \
+            all(a is b for a, b in zip(params, opt._params))
+
+    def __init__(self, agent, states, context):
+        from .. import critic_ops
+        self.agent, self.c = agent, context
+        pol = agent.policy
+        self.net, self.opt = pol.mean_net, agent.policy_optimizer
+        self.var = pol.variance_net.variable
+        self.x = states if states.is_contiguous() else states.contiguous()
+        self.N, self.din = self.x.shape
+        self.K, self.min_std = pol.dim_out, float(pol.min_std)
+        self.act = critic_ops._ACT[self.net.act_func_hidden_type]
+        dev, lib = self.x.device, _lib.load()
+        ls = self.net.layers
+        self.w = [ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias]
+        self.w3, self.b3 = ls[2].weight, ls[2].bias
+        # views of the flat gradient: hidden layers | W3 | b3 | variance vector
+        P = lib.tce_mlp_critic_num_params(self.din)
+        flat = self.opt.flat_grad
+        o3 = 128 * self.din + 128 + 128 * 128 + 128
+        o4 = o3 + self.K * 128
+        o5 = o4 + self.K
+        nvec = self.var.numel()
+        assert o5 + nvec == flat.numel() and o3 + 129 <= flat.numel()
+        self.P = P
+        self.g_w3 = flat[o3:o4].view(self.K, 128)
+        self.g_b3 = flat[o4:o5]
+        self.g_var = flat[o5:o5 + nvec]
+        self.nvec = nvec
+        self.partials = torch.empty(min(lib.tce_mlp_critic_grid(),
+                                        (self.N + 63) // 64), P + 2,
+                                    dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.zero1 = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def run(self, rec_row):
+        """One epoch; rec_row [19] receives {surrogate, entropy loss, trust
+        region loss, total, entropy, |g|, |g| clipped, 12 KL means}."""
+        c, st = self.c, stream()
+        x, N, K, din = self.x, self.N, self.K, self.din
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32,
+                                         device=x.device)
+        self.opt.bind_grads()
+        with torch.no_grad():
+            # ---- forward
+            h2 = new(N, 128)
+            call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
+                 *[ptr(t) for t in self.w], self.act, None, ptr(h2), None,
+                 None, None, st)
+            mean = torch.addmm(self.b3, h2, self.w3.t())
+            L = new(1, K, K)
+            call("tce_chol_build_fwd_f32", ptr(self.var), ptr(L), 1, K,
+                 self.nvec, self.min_std, st)
+            g_mean, g_L, sur, out = evaluate(mean, L[0], c)
+            # ---- backward into the flat gradient.  The hidden layers' launch
+            # fills [0, P) (its w3 / b3 slots with zeros), so it goes first.
+            gh = torch.mm(g_mean, self.w3)
+            call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
+                 *[ptr(t) for t in self.w], self.act, ptr(gh), None,
+                 ptr(self.partials), ptr(self.opt.flat_grad), ptr(self.stats),
+                 st)
+            torch.mm(g_mean.t(), h2, out=self.g_w3)
+            torch.sum(g_mean, 0, out=self.g_b3)
+            call("tce_chol_build_bwd_f32", ptr(self.var), ptr(g_L),
+                 ptr(self.g_var), 1, K, self.nvec, st)
+            ag = self.agent
+            ag._optimizer_step(self.opt, ag.policy_net_params,
+                               ag.clip_grad_norm)
+            # ---- record
+            entl = self.zero1 if c.ent_coef == 0.0 else \
+                (-c.ent_coef) * out[12:13]
+            total = sur[:1] + out[13:14] if c.ent_coef == 0.0 else \
+                sur[:1] + out[13:14] + entl
+            torch.cat([sur[:1], entl, out[13:14], total, out[12:13],
+                       self.opt.dev_state[1:3], out[:12]], out=rec_row)
