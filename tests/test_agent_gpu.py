@@ -28,9 +28,35 @@ def to_cpu_params(net):
 @pytest.mark.parametrize("overlap,fused,graph", [(False, True, True),
                                                  (True, True, True),
                                                  (False, False, False),
-                                                 (True, False, True)])
+                                                 (True, False, True),
+                                                 (False, True, False),
+                                                 (True, True, False)])
 def test_agent_step_matches_cpu_oracle(overlap, fused, graph):
+    """fused + graph: the objective as one autograd node, epochs replayed from a
+    HIP graph; fused without graph: the epoch without autograd
+    (objective.DirectEpoch); not fused: op by op."""
     _agent_vs_oracle(overlap, fused, graph, "metaworld", 5)
+
+
+def test_direct_epoch_equals_autograd_epoch():
+    """The policy epoch without autograd (DirectEpoch) and the same epoch
+    through the autograd node: same parameters and metrics after 3 epochs."""
+    out = []
+    for direct in (True, False):
+        torch.manual_seed(3)
+        agent, _ = build(32, 3, False, direct_policy_epoch=direct,
+                         graph_policy_update=False)
+        torch.manual_seed(5)
+        res = agent.step()
+        out.append((res, [p.detach().clone()
+                          for p in agent.policy.parameters]))
+    (ra, pa), (rb, pb) = out
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    for k in ("surrogate_loss_mean", "trust_region_loss_mean", "entropy_mean",
+              "policy_grad_norm_mean", "projection_new_old_cov_diff_mean",
+              "projection_proj_old_mean_diff_mean"):
+        assert abs(ra[k] - rb[k]) <= 1e-5 * abs(rb[k]) + 1e-7, k
 
 
 @pytest.mark.parametrize("env,nb,dtype", [
