@@ -47,7 +47,7 @@ typedef unsigned u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-struct Frag { u32 r[4]; };               // 8 f16: one A or B operand
+struct alignas(16) Frag { u32 r[4]; };   // 8 f16: one A or B operand (read from LDS as 16 bytes)
 
 #ifndef M16_RING
 #define M16_RING 3          // operand ring of the chain loops (reads run RING - 1 steps ahead)
