@@ -167,6 +167,21 @@ class AbstractAgent(ABC):
         cur.wait_stream(self._graph_stream)
         return graph
 
+    def _run_epochs(self, epoch, E, opt, graph):
+        """E identical epochs (fixed buffers, no host reads).  graph: the first
+        epoch runs eagerly, the second is recorded into a HIP graph and replayed
+        -- the ~100 launches of an epoch leave the host."""
+        if graph and E > 2 and self.dist.world == 1:
+            epoch()
+            g = self._capture(epoch)
+            for _ in range(E - 1):
+                g.replay()
+            opt.host_step += E - 2                # the capture counted one
+            self._last_graphs = getattr(self, "_last_graphs", [])[-3:] + [g]
+        else:
+            for _ in range(E):
+                epoch()
+
     @staticmethod
     def _check_nan(flags):
         """One host read for all NaN flags of an update."""
@@ -768,6 +783,12 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
     """black_box_agent.py: episode-level advantage R - V(s0), critic regresses
     the episode return, param-space log-prob; otherwise the same update."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # the epochs of both updates are ~100 launch-bound kernels each and
+        # nothing else runs beside them: replay them from HIP graphs
+        self.graph_epochs = kwargs.get("graph_epochs", True)
+
     def step(self):
         self.num_iterations += 1
         util.run_time_test(lock=True, key="sampling")
@@ -812,24 +833,46 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         states = dataset["segment_state"]
         old_values, returns = dataset["segment_value"], \
             dataset["segment_reward"]
-        losses, norms, norms_c = [], [], []
-        for _ in range(self.epochs_critic):
-            for sel in self._minibatches(states.shape[0]):
-                s_in, v_old, ret = (states, old_values, returns) \
-                    if sel is None else (states[sel], old_values[sel],
-                                         returns[sel])
-                loss = self.value_loss(self.critic.critic(s_in).squeeze(-1),
-                                       ret, v_old)
+        E = self.epochs_critic
+        if self.num_minibatchs == 1:
+            # per-epoch record {loss, |g|, |g| clipped}, written on the device
+            rec = torch.zeros(E, 3, dtype=self.dtype, device=self.device)
+            idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+            def epoch():
+                loss = self.value_loss(
+                    self.critic.critic(states).squeeze(-1), returns,
+                    old_values)
                 self.critic_optimizer.zero_grad(set_to_none=True)
                 loss.backward()
                 g, gc = self._optimizer_step(self.critic_optimizer,
                                              self.critic_net_params,
                                              self.clip_grad_norm)
-                losses.append(loss.detach())
-                norms.append(g)
-                norms_c.append(gc)
-        host = torch.stack([torch.stack(losses), torch.stack(norms),
-                            torch.stack(norms_c)]).cpu().numpy()
+                rec.index_copy_(0, idx, torch.stack(
+                    [loss.detach(), g, gc])[None])
+                idx.add_(1)
+
+            self._run_epochs(epoch, E, self.critic_optimizer,
+                             self.graph_epochs)
+            host = rec.cpu().numpy().T
+        else:
+            losses, norms, norms_c = [], [], []
+            for _ in range(E):
+                for sel in self._minibatches(states.shape[0]):
+                    s_in, v_old, ret = states[sel], old_values[sel], \
+                        returns[sel]
+                    loss = self.value_loss(
+                        self.critic.critic(s_in).squeeze(-1), ret, v_old)
+                    self.critic_optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
+                    g, gc = self._optimizer_step(self.critic_optimizer,
+                                                 self.critic_net_params,
+                                                 self.clip_grad_norm)
+                    losses.append(loss.detach())
+                    norms.append(g)
+                    norms_c.append(gc)
+            host = torch.stack([torch.stack(losses), torch.stack(norms),
+                                torch.stack(norms_c)]).cpu().numpy()
         return {**util.generate_stats(host[0], "critic_loss"),
                 **util.generate_stats(host[1], "critic_grad_norm"),
                 **util.generate_stats(host[2], "clipped_critic_grad_norm")}
@@ -844,9 +887,12 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         if self.projection.initial_entropy is None:
             ent0 = self.policy.entropy([mean_old, L_old]).mean()
             self.projection.initial_entropy = self.dist.mean_scalar(ent0)
-        rows, nan_flags = [], []
-        mean_new = L_new = proj_mean = proj_L = None
-        for _ in range(self.epochs_policy):
+        E = self.epochs_policy
+        rec = torch.zeros(E, 7, dtype=self.dtype, device=self.device)
+        idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+        last = {}
+
+        def epoch():
             mean_new, L_new = self.policy.policy(states)
             proj_mean, proj_L = self.projection(
                 self.policy, (mean_new, L_new), (mean_old, L_old),
@@ -860,21 +906,29 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             trust_region_loss = self.projection.get_trust_region_loss(
                 self.policy, (mean_new, L_new), (proj_mean, proj_L),
                 set_variance=self.set_variance)
-            nan_flags.append(torch.isnan(torch.stack(
-                [surrogate_loss.detach(), entropy_loss.detach(),
-                 trust_region_loss.detach()])))
             policy_loss = surrogate_loss + entropy_loss + trust_region_loss
             self.policy_optimizer.zero_grad(set_to_none=True)
             policy_loss.backward()
             g, gc = self._optimizer_step(self.policy_optimizer,
                                          self.policy_net_params,
                                          self.clip_grad_norm)
-            rows.append(torch.stack([
+            rec.index_copy_(0, idx, torch.stack([
                 surrogate_loss.detach(), entropy_loss.detach(),
                 trust_region_loss.detach(), policy_loss.detach(),
-                entropy.detach(), g, gc]))
-        self._check_nan(nan_flags)
-        host = torch.stack(rows).cpu().numpy()
+                entropy.detach(), g, gc])[None])
+            idx.add_(1)
+            # the last epoch's distributions (fixed graph buffers when replayed)
+            last["t"] = (mean_new.detach(), ops.detach_L(L_new),
+                         proj_mean.detach(), ops.detach_L(proj_L))
+
+        self._run_epochs(epoch, E, self.policy_optimizer, self.graph_epochs)
+        host = rec.cpu().numpy()                          # ONE copy
+        for name, bad in zip(("surrogate_loss", "entropy_loss",
+                              "trust_region_loss"),
+                             np.isnan(host[:, :3]).any(axis=0)):
+            if bad:
+                raise Exception("NAN %s detected" % name)
+        mean_new, L_new, proj_mean, proj_L = last["t"]
         names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
                  "policy_loss", "entropy", "policy_grad_norm",
                  "clipped_policy_grad_norm")
@@ -882,8 +936,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         for i, n in enumerate(names):
             out.update(util.generate_stats(host[:, i], n))
         metrics = self.projection.compute_metrics(
-            self.policy, (mean_new.detach(), ops.detach_L(L_new)),
-            (proj_mean.detach(), ops.detach_L(proj_L)), self.num_iterations)
+            self.policy, (mean_new, L_new), (proj_mean, proj_L),
+            self.num_iterations)
         mh = torch.stack([v.to(self.dtype) for v in metrics.values()]) \
             .cpu().numpy()
         out.update({"projection_" + k: float(v)

@@ -246,6 +246,27 @@ def test_bbrl_agent_step():
     assert res["num_global_steps"] == 2 * 256 * 500
 
 
+def test_bbrl_graph_epochs_equal_eager_epochs():
+    """BlackBoxAgent: epochs replayed from HIP graphs (default) == the same
+    epochs launched eagerly (5 epochs: one eager, one captured, four replays)."""
+    out = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        agent, _ = build_bbrl(64, 5)
+        agent.graph_epochs = graph
+        agent.evaluation_interval = 0
+        torch.manual_seed(1)
+        res = agent.step()
+        out.append((res, [p.detach().clone() for p in
+                          agent.policy.parameters + agent.critic.parameters]))
+    (ra, pa), (rb, pb) = out
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+    for k in ("critic_loss_mean", "surrogate_loss_mean", "policy_grad_norm_mean",
+              "projection_kl", "entropy_mean"):
+        assert abs(ra[k] - rb[k]) <= 1e-6 * abs(rb[k]) + 1e-8, k
+
+
 def test_bbrl_step_matches_cpu_oracle():
     """One BlackBoxAgent.step() (a16) against the CPU oracle step on the same
     weights, env state and parameter noise."""
