@@ -82,13 +82,15 @@ def kernel_time_cold_us(fn, launches=5):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r01c_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2
-    correction); None if the file is absent."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r01c_pmc.json")) as f:
-            return json.load(f)["kernels"][kernel]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    (profiles/r01e_pmc.json, else r01c: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, FETCH x2 correction); None if absent."""
+    for tag in ("r01e", "r01c"):
+        try:
+            with open(os.path.join(REPO, "profiles", tag + "_pmc.json")) as f:
+                return json.load(f)["kernels"][kernel]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def roofline(agent):
@@ -127,7 +129,8 @@ def roofline(agent):
         "bound": "mfma", "achieved": round(flops / us_c16 / 1e6, 2),
         "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": round(flops / us_c16 / 1e6 / F16_MFMA_PEAK_TF, 4),
-        "traffic": None, "us_per_launch": round(us_c16, 1),
+        "traffic": pmc_traffic("mlp_critic_bwd16_kernel"),
+        "us_per_launch": round(us_c16, 1),
         "algorithmic_flops": flops,
         "mfma_flops_issued": 3 * flops,
         "frac_issued": round(3 * flops / us_c16 / 1e6 / F16_MFMA_PEAK_TF, 4),

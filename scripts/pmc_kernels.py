@@ -19,6 +19,10 @@ run = critic_ops.EpochRunner(mlp)
 for _ in range(3):
     big.fill_(1.0)
     run.epoch(x, r, r, 0.0)
+run16 = critic_ops.EpochRunner(mlp, arith="f16x2")
+for _ in range(3):
+    big.fill_(1.0)
+    run16.epoch(x, r, r, 0.0)
 for _ in range(3):
     big.fill_(1.0)
     critic_ops.forward(mlp, x)

@@ -9,8 +9,8 @@ Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts the
 Both counters are reported in KiB."""
 import csv, json, os, sys, collections
 
-KERNELS = ("gae_dpp_kernel", "mlp_critic_bwd_kernel", "mlp_critic_fwd_kernel",
-           "prodmp_traj_kernel")
+KERNELS = ("gae_dpp_kernel", "mlp_critic_bwd_kernel", "mlp_critic_bwd16_kernel",
+           "mlp_critic_fwd_kernel", "prodmp_traj_kernel")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
