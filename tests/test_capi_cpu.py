@@ -38,3 +38,28 @@ def test_no_cpu_fallback():
     d = torch.zeros(2, 4, dtype=torch.bool)
     with pytest.raises(RuntimeError, match="HIP device only"):
         ops.gae(r, v, d, d, 1.0, 0.95)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of the package (nor bench.py's
+    timed path) may import it; bench.py only does so inside cpu_baseline()."""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    for path in (root / "tce_rl_amd").rglob("*.py"):
+        tree = ast.parse(path.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.")
+                           for n in names), path
+    bench = ast.parse((root / "bench.py").read_text())
+    for fn in [n for n in bench.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                   ("oracle" in (getattr(n, "module", None) or "") or
+                    any("oracle" in a.name for a in n.names))
+                   for n in ast.walk(fn))
+        assert not uses or fn.name == "cpu_baseline", fn.name
