@@ -80,3 +80,31 @@ def test_split_f16_c2_shape_matches_fp32_kernel():
     assert abs(sa[0] - sb[0]).item() <= 2e-6 * abs(sa[0]).item()
     assert (ga - gb).abs().max().item() <= 2e-5 * ga.abs().max().item()
     assert ((ga - gb).norm() / ga.norm()).item() <= 5e-6
+
+
+def test_split_f16_values_output_and_overflow_is_reported():
+    """The launch can also emit the values; operands beyond the f16 range do not
+    pass silently: the loss comes back non-finite (the agent's NaN check)."""
+    from tce_rl_amd import _lib, critic_ops
+    from tce_rl_amd._lib import call, ptr, stream
+    mlp = make(24, "tanh", 2)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(1000, 24, device="cuda", generator=g)
+    ret = torch.randn(1000, device="cuda", generator=g)
+    lib = _lib.load()
+    P = lib.tce_mlp_critic_num_params(24)
+    partials = torch.empty(lib.tce_mlp_critic_grid(), P + 2, device="cuda")
+    grad, stats = torch.empty(P, device="cuda"), torch.zeros(2, device="cuda")
+    vals = torch.empty(1000, device="cuda")
+    ws = [ptr(p) for p in mlp.parameters()]
+    call("tce_mlp_critic_f16x2", ptr(x), 0, 24, 1000, 1000, 24, *ws, 0, ptr(ret),
+         None, 0.0, ptr(vals), ptr(partials), ptr(grad), ptr(stats), 0, None,
+         None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, stream())
+    ref = critic_ops.forward(mlp, x.expand(5, 1000, 24).contiguous())[0, :, 0]
+    torch.testing.assert_close(vals, ref, rtol=1e-5, atol=1e-6)
+    stats.zero_()
+    big = x * 1e6                                   # |x| > 65504
+    call("tce_mlp_critic_f16x2", ptr(big), 0, 24, 1000, 1000, 24, *ws, 0,
+         ptr(ret), None, 0.0, None, ptr(partials), ptr(grad), ptr(stats), 0,
+         None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, stream())
+    assert not torch.isfinite(stats[0]).item()
