@@ -239,6 +239,11 @@ class _CriticEpochs:
 
     def finish(self):
         host = self.rows.cpu().numpy()                       # the only sync
+        if self.runner.arith == "f16x2" and not np.isfinite(host[:, 0]).all():
+            raise RuntimeError(
+                "critic_arith=f16x2: the critic loss is not finite -- an "
+                "operand (observation, activation, weight) left the f16 range "
+                "(|x| < 65504); use critic_arith=f32 for this task")
         if self.fuse_adam:                                   # no clipping
             host[:, 2] = host[:, 3] = np.sqrt(host[:, 1])
         return {**util.generate_stats(host[:, 0], "critic_loss"),
