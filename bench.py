@@ -213,13 +213,44 @@ def cpu_baseline():
                       "(T 500, 50 critic + 50 policy epochs), %.1f s" % (n, dt)}
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` from a plain shell (WORLD_SIZE unset): this
+    process has not touched the GPU and never will -- it starts the N ranks as
+    fresh children through torch.distributed.run (no exec), relays rank 0's
+    JSON line and returns the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_split_f16:
+        cmd.append("--no-split-f16")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in r.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        print("[bench] no JSON line from rank 0", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
-    # stdout carries exactly ONE line (the JSON record): everything else that
-    # libraries print there (RCCL / gloo banners at communicator creation) is
-    # sent to stderr by pointing fd 1 at fd 2 until the record is written
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -228,10 +259,23 @@ def main():
     ap.add_argument("--no-split-f16", action="store_true",
                     help="skip the second timed region (critic_arith=f16x2)")
     args = ap.parse_args()
+    # N > 1 without a launcher: become the launcher BEFORE any GPU call
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    # stdout carries exactly ONE line (the JSON record): everything else that
+    # libraries print there (RCCL / gloo banners at communicator creation) is
+    # sent to stderr by pointing fd 1 at fd 2 until the record is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" %
+                         (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # TCE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with all ranks on the
@@ -240,22 +284,44 @@ def main():
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TCE_FORCE_DIST=1: a world of ONE rank still creates the RCCL
+    # communicators and takes the sharded code path (all-reduces included) --
+    # the way to run the N > 1 path through RCCL on a one-GPU box
+    force = world == 1 and os.environ.get("TCE_FORCE_DIST") == "1"
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+    if world > 1 or force:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(
                 "cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, "launch with torch.distributed.run for N > 1"
 
-    agent, cfg = build_agent(NUM_ENV, seed=rank)
+    # the GLOBAL env count: MPExperiment gives every rank NUM_ENV of them and
+    # the env / noise seed `seed + rank`
+    agent, cfg = build_agent(NUM_ENV * world, seed=0)
+    assert agent.sampler.num_env_train == NUM_ENV
     T = agent.sampler.num_times
 
+    is_dist = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if is_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def over_ranks(vals):
+        """max over ranks of each value, plus every rank's first value."""
+        if not is_dist:
+            return vals, [vals[0]]
+        tt = torch.tensor(vals, device="cuda", dtype=torch.float64)
+        every = torch.empty(world, len(vals), device="cuda",
+                            dtype=torch.float64)
+        dist.all_gather_into_tensor(every, tt[None])
+        return every.max(0).values.tolist(), every[:, 0].tolist()
 
     for _ in range(args.warmup):
         agent.step()
@@ -269,11 +335,7 @@ def main():
         pol_time += res["update_policy_time"]
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed, pol_time], device="cuda",
-                          dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, pol_time = tt.tolist()
+    (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
 
     # the same K steps (after W warm-up steps) with the critic epochs on the
     # split-f16 kernel (agent option critic_arith="f16x2"), reported beside
@@ -292,11 +354,7 @@ def main():
             pol16 += res["update_policy_time"]
         barrier()
         el16 = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([el16, pol16], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el16, pol16 = tt.tolist()
-        fast = (el16, pol16)
+        fast, _ = over_ranks([el16, pol16])
         agent.critic_arith = "f32"
 
     if rank == 0:
@@ -323,6 +381,11 @@ def main():
                        "num_env_per_gpu": NUM_ENV, "num_times": T,
                        "num_basis": NUM_BASIS, "epochs": EPOCHS,
                        "parallelism": "env-shard x%d" % world},
+            "backend": (dist.get_backend() if is_dist else None),
+            "rccl_ranks": (dist.get_world_size() if is_dist and
+                           dist.get_backend() == "nccl" else 0),
+            "ms_per_step_per_rank": [round(t / args.steps * 1e3, 2)
+                                     for t in per_rank],
             "roofline": roof, "roofline_extra": extra,
         }
         if fast is not None:
@@ -341,7 +404,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if is_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -69,6 +69,10 @@ int tce_normalize_f64(const double* x, double* y, int64_t n, const double* stats
  * `accumulate` (temporal_correlated_agent.py:211-228): out[n,p] =
  * sum_{t=a..b inclusive} f(adv[n,t]), f = optional normalise (stats) + clamp.
  * `accumulated_rewards` (:288-319): (sum_{[a,b)} gamma^t r - column mean)/gamma^a.
+ * col_mean: NULL = the column mean over these N rows (the reference's
+ * accumulated_rewards.mean(dim=0)); else P means of the GLOBAL batch supplied
+ * by the caller (env shards: all-reduced column sums / global N).  center = 0
+ * returns the raw sums (first pass of the sharded case).
  */
 int tce_segment_accumulate_f32(const float* adv, const int64_t* pairs, int P,
                                float* out, int64_t N, int T, const double* stats,
@@ -77,9 +81,11 @@ int tce_segment_accumulate_f64(const double* adv, const int64_t* pairs, int P,
                                double* out, int64_t N, int T, const double* stats,
                                double eps, double clip, void* stream);
 int tce_segment_accrew_f32(const float* rewards, const int64_t* pairs, int P,
-                           float* out, int64_t N, int T, float gamma, void* stream);
+                           float* out, int64_t N, int T, float gamma,
+                           const float* col_mean, int center, void* stream);
 int tce_segment_accrew_f64(const double* rewards, const int64_t* pairs, int P,
-                           double* out, int64_t N, int T, double gamma, void* stream);
+                           double* out, int64_t N, int T, double gamma,
+                           const double* col_mean, int center, void* stream);
 
 /* ---- ProDMP trajectory generator ---------------------------------------
  * The arithmetic of mp_pytorch==0.1.4 (third-party, un-vendored; pinned at

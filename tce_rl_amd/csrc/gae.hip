@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void segment_accumulate_kernel(
 template <typename real>
 __global__ __launch_bounds__(256) void segment_accrew_kernel(
     const real* __restrict__ rewards, const int64_t* __restrict__ pairs, int P,
-    real* __restrict__ out, int64_t N, int T, real gamma) {
+    real* __restrict__ out, int64_t N, int T, real gamma,
+    const real* __restrict__ col_mean, int center) {
   __shared__ double s_red[4];
   const int p = blockIdx.x;
   const int a = (int)pairs[2 * p], b = (int)pairs[2 * p + 1];
@@ -411,7 +412,9 @@ __global__ __launch_bounds__(256) void segment_accrew_kernel(
     out[n * P + p] = acc;
     loc += (double)acc;
   }
-  const real mean = (real)(block_sum(loc, s_red) / (double)N);
+  if (!center) return;
+  const real mean = col_mean ? col_mean[p]
+                             : (real)(block_sum(loc, s_red) / (double)N);
   const real d = pow(gamma, real(a));
   for (int64_t n = threadIdx.x; n < N; n += 256)
     out[n * P + p] = (out[n * P + p] - mean) / d;
@@ -529,12 +532,13 @@ int64_t tce_moments_num_partials(void) { return TCE_MOMENTS_BLOCKS; }
   }                                                                            \
   int tce_segment_accrew_##SFX(const REAL* rewards, const int64_t* pairs,      \
                                int P, REAL* out, int64_t N, int T, REAL gamma, \
+                               const REAL* col_mean, int center,               \
                                void* stream) {                                 \
     TCE_CHECK_ARG(rewards && pairs && out && N > 0 && P > 0 && T > 0,          \
                   "segment_accrew: bad arguments");                            \
     hipLaunchKernelGGL(segment_accrew_kernel<REAL>, dim3(P), dim3(256), 0,     \
                        (hipStream_t)stream, rewards, pairs, P, out, N, T,      \
-                       gamma);                                                 \
+                       gamma, col_mean, center);                               \
     TCE_LAUNCH_CHECK();                                                        \
     return 0;                                                                  \
   }

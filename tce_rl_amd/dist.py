@@ -12,8 +12,21 @@ this is the new exchange step of the sharded path:
 Messages are tiny (<= ~300 KB): latency-bound, so exactly one collective per
 step on one flat buffer.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def active(group=None):
+    """True when the sharded code path (collectives included) is to be taken:
+    a process group of more than one rank, or -- TCE_FORCE_DIST=1 -- any
+    initialised process group, so that a ONE-rank RCCL world on a one-GPU box
+    runs exactly the launches and collectives of an N-rank job."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or \
+        os.environ.get("TCE_FORCE_DIST") == "1"
 
 
 class DistContext:
@@ -22,6 +35,7 @@ class DistContext:
         self.enabled = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        self.active = active(group)
         self._flat = {}
         self._aux_group = None
 
@@ -31,19 +45,18 @@ class DistContext:
         the critic's and the policy's gradient all-reduces from two streams;
         on one communicator they would be serialised in host issue order (all
         critic epochs first), on two they proceed independently."""
-        if self.world == 1:
+        if not self.active:
             return self.group
         if self._aux_group is None:
             ranks = dist.get_process_group_ranks(self.group) \
                 if self.group is not None else list(range(self.world))
-            try:
-                self._aux_group = dist.new_group(ranks=ranks)
-            except Exception:            # no second communicator: share one
-                self._aux_group = self.group   # (collectives serialise, still correct)
+            # no fallback: a failure on SOME ranks would leave them on
+            # different communicators (dead-lock), so it has to surface
+            self._aux_group = dist.new_group(ranks=ranks)
         return self._aux_group
 
     def allreduce_grads(self, params):
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in params]
         key = id(params)
@@ -63,7 +76,7 @@ class DistContext:
     def allreduce_flat(self, flat, group=None, average=True):
         """In-place sum (average=False) or mean over ranks of an already-flat
         gradient buffer."""
-        if self.world == 1:
+        if not self.active:
             return
         dist.all_reduce(flat, op=dist.ReduceOp.SUM,
                         group=self.group if group is None else group)
@@ -71,14 +84,14 @@ class DistContext:
             flat.div_(self.world)
 
     def mean_scalar(self, x):
-        if self.world == 1:
+        if not self.active:
             return x
         y = x.clone()
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y / self.world
 
     def broadcast_params(self, params):
-        if self.world == 1:
+        if not self.active:
             return
         for p in params:
             dist.broadcast(p.data, src=0, group=self.group)

@@ -53,7 +53,15 @@ class MPExperiment:
         seed = rep if seed == "auto" else seed
         _resolve_auto(cw_config, seed)
         cfg = cw_config["params"]
-        util.set_global_random_seed(seed)
+        # env sharding (one process per GPU): rank g of `world`
+        # holds num_env_train / world envs and its own env / noise random
+        # streams (seed + g); weights and segment pairs are rank 0's (broadcast
+        # by the agent / sampler), so rank 0 consumes its generators exactly
+        # like a single process
+        from .dist import DistContext
+        dc = DistContext()
+        rank, world = (dc.rank, dc.world) if dc.active else (0, 1)
+        util.set_global_random_seed(seed + rank)
         self.verbose_level = cw_config.get("verbose_level", 1)
         load_model_dir = cw_config.get("load_model_dir", None)
         self.training = load_model_dir is None
@@ -65,6 +73,14 @@ class MPExperiment:
             self.save_model_dir = self.save_model_interval = None
         s_args = dict(cfg["sampler"]["args"])
         s_args.setdefault("mp", cfg.get("mp"))
+        if world > 1:
+            n_train = int(s_args.get("num_env_train", 1))
+            if n_train % world:
+                raise ValueError("num_env_train %d is not divisible by the "
+                                 "%d ranks" % (n_train, world))
+            s_args["num_env_train"] = n_train // world
+        if dc.active and isinstance(s_args.get("seed", 1), int):
+            s_args["seed"] = s_args.get("seed", 1) + rank
         self.sampler = sampler_factory(cfg["sampler"]["type"],
                                        cpu_cores=cw_config.get("cpu_cores"),
                                        **s_args)
@@ -216,6 +232,18 @@ def load_config(path, exp_name=None):
 
 
 def main(argv):
+    # under torch.distributed.run (WORLD_SIZE set): one process per GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(
+            os.environ.get("TCE_BACKEND", "nccl"),
+            **({"device_id": torch.device("cuda", local)}
+               if os.environ.get("TCE_BACKEND", "nccl") == "nccl" else {}))
     cfg = load_config(argv[1])
     if "--iterations" in argv:
         cfg["iterations"] = int(argv[argv.index("--iterations") + 1])
@@ -226,7 +254,8 @@ def main(argv):
         res = exp.iterate(cfg, 0, n)
         keep = {k: v for k, v in res.items() if k.endswith("_time")
                 or k in ("num_global_steps",) or "episode_reward_mean" in k}
-        print(n, keep, flush=True)
+        if world == 1 or int(os.environ.get("RANK", "0")) == 0:
+            print(n, keep, flush=True)
         exp.save_state(cfg, 0, n)
 
 

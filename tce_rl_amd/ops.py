@@ -31,8 +31,8 @@ def merge_stats(stats, group=None):
     (exact pooled-moments identity), so that a sharded batch normalises with
     the statistics of the global batch."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) \
-            or dist.get_world_size(group) == 1:
+    from .dist import active
+    if not active(group):
         return stats
     w = dist.get_world_size(group)
     buf = stats.new_empty(w, 3)
@@ -137,8 +137,24 @@ def segment_advantage(mode, rewards, values, advantages, pred_pairs, gamma,
     if mode == "accumulated_rewards":
         r = _c(rewards)
         out = torch.empty(N, P, dtype=r.dtype, device=r.device)
+        from .dist import active
+        if not active(group):
+            call("tce_segment_accrew_" + s, ptr(r), ptr(pairs), P, ptr(out),
+                 N, T, float(gamma), None, 1, stream())
+            return out
+        # env shards: the reference subtracts the column mean of the WHOLE
+        # batch (temporal_correlated_agent.py:311) -> raw sums, all-reduced
+        # column sums + row count, second pass with the global means
+        import torch.distributed as dist
         call("tce_segment_accrew_" + s, ptr(r), ptr(pairs), P, ptr(out), N, T,
-             float(gamma), stream())
+             float(gamma), None, 0, stream())
+        tot = torch.cat([sum_dim0(out).double(),
+                         torch.full((1,), float(N), dtype=torch.float64,
+                                    device=r.device)])
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        mean = _c((tot[:P] / tot[P]).to(r.dtype))
+        call("tce_segment_accrew_" + s, ptr(r), ptr(pairs), P, ptr(out), N, T,
+             float(gamma), ptr(mean), 1, stream())
         return out
     raise NotImplementedError(mode)
 

@@ -52,7 +52,7 @@ class AbstractAgent(ABC):
         self.num_iterations = 0
         self.num_global_steps = 0
         self._policy_group = None
-        if self.dist.world > 1:
+        if self.dist.active:
             self.dist.broadcast_params(self.policy_net_params +
                                        self.critic_net_params)
             self._policy_group = self.dist.aux_group()
@@ -91,7 +91,10 @@ class AbstractAgent(ABC):
             opt.load_state_dict(torch.load(path, map_location=self.device))
         self.policy_lr_scheduler, self.critic_lr_scheduler = \
             self.get_lr_scheduler()
-        self.num_iterations = epoch
+        # epoch None = the un-suffixed files (util_file.py:293-317); the
+        # reference then leaves num_iterations = None (abstract_agent.py:174),
+        # which only an evaluation run survives -- count from 0 instead
+        self.num_iterations = 0 if epoch is None else epoch
 
     @abstractmethod
     def step(self, *args, **kwargs):
@@ -138,7 +141,7 @@ class AbstractAgent(ABC):
     def _optimizer_step(self, opt, params, clip):
         """grad_norm_clip + Adam step (one flat buffer; one collective when
         the envs are sharded over ranks)."""
-        if self.dist.world > 1:
+        if self.dist.active:
             opt.sync_grads()
             # the policy's exchange has its own communicator (see dist.py)
             self.dist.allreduce_flat(
@@ -171,7 +174,7 @@ class AbstractAgent(ABC):
         """E identical epochs (fixed buffers, no host reads).  graph: the first
         epoch runs eagerly, the second is recorded into a HIP graph and replayed
         -- the ~100 launches of an epoch leave the host."""
-        if graph and E > 2 and self.dist.world == 1:
+        if graph and E > 2 and not self.dist.active:
             epoch()
             g = self._capture(epoch)
             for _ in range(E - 1):
@@ -218,7 +221,7 @@ class _CriticEpochs:
         # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
         self.rows = torch.zeros(self.E, 4, dtype=torch.float32,
                                 device=agent.device)
-        self.fuse_adam = agent.dist.world == 1 and \
+        self.fuse_adam = not agent.dist.active and \
             not agent.clip_grad_norm > 0
         self.done = 0
 
@@ -229,7 +232,7 @@ class _CriticEpochs:
                               ag.clip_critic, max_workgroups, stats=rows[e],
                               adam=opt if self.fuse_adam else None)
             if not self.fuse_adam:
-                if ag.dist.world > 1:
+                if ag.dist.active:
                     ag.dist.allreduce_flat(opt.flat_grad, average=False)
                     opt.step(ag.clip_grad_norm, grad_scale=1.0 / ag.dist.world)
                 else:                   # |g|^2 comes with the reduction
@@ -440,7 +443,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         side_ms = ev[2].elapsed_time(ev[5])
         if self.adaptive_critic_split and cstream is None:
             split = int(min(E, side_ms / first_ms + 2))
-            if self.dist.world > 1:
+            if self.dist.active:
                 # every rank must issue its collectives in the same order (the
                 # critic's first part, the policy's, the critic's rest): agree
                 # on the largest split
@@ -691,7 +694,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), \
             torch.cuda.Event(enable_timing=True)
         ev_a.record()
-        if self.graph_policy_update and self.dist.world == 1 and E > 2 \
+        if self.graph_policy_update and not self.dist.active and E > 2 \
                 and not self.check_policy_balance:
             # The epochs are identical launch sequences on fixed buffers: run
             # the first one eagerly, record the second into a HIP graph and

@@ -35,8 +35,8 @@ class RunningMeanStd:
         the running merge), so every rank keeps the same normalisation and it
         equals the single-process result."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()
-                and dist.get_world_size() > 1):
+        from ..dist import active
+        if not active():
             self.count = ops.rms_update(arr, self.mean, self.var, self.count)
             return
         # local batch moments through the same kernel (merge into an empty state)
@@ -232,8 +232,8 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
         self.pred_pairs = pairs.to(torch.long).to(self.device)
         # env shards of one job use the SAME segments: rank 0's draw
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() \
-                and dist.get_world_size() > 1:
+        from ..dist import active
+        if active():
             dist.broadcast(self.pred_pairs, src=0)
         return self.pred_pairs
 

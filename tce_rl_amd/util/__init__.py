@@ -170,10 +170,15 @@ def rewrite_dict(d, prefix):
 def get_nn_save_paths(log_dir, nn_name, epoch):
     import os
     s_path = os.path.join(log_dir, nn_name + "_parameters.pkl")
-    w_path = os.path.join(log_dir, nn_name + "_weights_{:d}".format(epoch))
+    w_path = os.path.join(log_dir, nn_name + "_weights")
+    if epoch is not None:
+        w_path = w_path + "_{:d}".format(epoch)
     return s_path, w_path
 
 
 def get_training_state_save_path(log_dir, name, epoch):
     import os
-    return os.path.join(log_dir, name + "_state_{:d}".format(epoch))
+    o_path = os.path.join(log_dir, name + "_state")
+    if epoch is not None:
+        o_path = o_path + "_{:d}".format(epoch)
+    return o_path

@@ -22,12 +22,15 @@ def _worker(rank, world, port, overlap, q):
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
     torch.manual_seed(100 + rank)            # different initial weights ...
-    cfg = tce_config("metaworld", num_env=32, num_basis=5, epochs=3,
-                     evaluation_interval=0, seed=rank)
+    # the GLOBAL env count: MPExperiment gives every rank 64 / world envs and
+    # the env / noise seed `seed + rank`
+    cfg = tce_config("metaworld", num_env=64, num_basis=5, epochs=3,
+                     evaluation_interval=0, seed=0)
     cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)             # ... made equal by the broadcast
     agent = exp.agent
+    assert agent.sampler.num_env_train == 32 and agent.sampler.seed == rank
     res = None
     pairs = []
     for _ in range(2):                       # ranks draw differently seeded
@@ -117,3 +120,138 @@ def test_sharded_obs_statistics_equal_the_single_process_ones():
     np.testing.assert_allclose(m0, m_ref, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v0, v_ref, rtol=1e-5, atol=1e-6)
     assert c0[0] == pytest.approx(c_ref[0])
+
+
+# ---------------------------------------------------------------------------
+# sharded == single process (the only contract the new
+# collectives have; reference sites whose global-batch means / stds they
+# reproduce: temporal_correlated_agent.py:213-215,716,736)
+# ---------------------------------------------------------------------------
+N_GLOBAL = 64
+
+
+def _forced(agent, dof, K, lo, hi):
+    """Env state and parameter noise of the global batch rows [lo, hi)."""
+    g = torch.Generator().manual_seed(7)
+    goal = torch.rand(N_GLOBAL, dof, generator=g) * 2 - 1
+    pos0 = 0.1 * (torch.rand(N_GLOBAL, dof, generator=g) * 2 - 1)
+    eps = torch.randn(N_GLOBAL, K, generator=g)
+    goal, pos0, eps = (t[lo:hi].cuda() for t in (goal, pos0, eps))
+    env = agent.sampler.train_envs
+    n = hi - lo
+
+    def reset():
+        env.goal = goal
+        z = torch.zeros(n, dof, device="cuda")
+        return env._obs(torch.zeros(n, device="cuda"), pos0, z)
+    env.reset = reset
+    sample = agent.policy.sample
+    agent.policy.sample = lambda **kw: sample(**kw, eps=eps)
+
+
+def _build_for_equivalence(kind, n_env, overlap):
+    if kind.startswith("tce"):
+        from tce_rl_amd.config import tce_config
+        from tce_rl_amd.mp_exp import MPExperiment
+        cfg = tce_config("metaworld", num_env=n_env, num_basis=5, epochs=3,
+                         evaluation_interval=0, seed=0)
+        cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
+        if kind == "tce_accrew":             # column means over the GLOBAL batch
+            cfg["params"]["agent"]["args"]["segment_advantage"] = \
+                "accumulated_rewards"
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        return exp.agent, 4, 24
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_agent_gpu import build_bbrl
+    agent, _ = build_bbrl(n_env, 3)
+    agent.evaluation_interval = 0
+    return agent, 4, 20
+
+
+def _equiv_run(kind, overlap, world, rank):
+    """Two agent.step()s on the forced global batch (this rank's rows) from
+    seed-0 initial weights -> flat vector {parameters, obs statistics,
+    normalised segment advantages of the last step (this rank's rows)}."""
+    torch.manual_seed(0)                     # identical initial weights
+    n = N_GLOBAL // world
+    # a sharded TCE experiment is configured with the GLOBAL env count
+    agent, dof, K = _build_for_equivalence(
+        kind, N_GLOBAL if kind.startswith("tce") else n, overlap)
+    assert agent.sampler.num_env_train == n
+    _forced(agent, dof, K, rank * n, (rank + 1) * n)
+    captured = {}
+    pd = agent.process_dataset
+
+    def grab(ds):
+        out = pd(ds)
+        captured["adv"] = out["segment_advantage"].detach().cpu().reshape(n, -1)
+        return out
+    agent.process_dataset = grab
+    for it in range(2):
+        torch.manual_seed(20 + it)           # pair offsets (rank 0's are used)
+        res = agent.step()
+    flat = [p.detach().reshape(-1).cpu().double()
+            for p in agent.policy.parameters + agent.critic.parameters]
+    rms = getattr(agent.sampler, "obs_rms", None)
+    if rms is not None:
+        flat += [rms.mean.reshape(-1).cpu().double(),
+                 rms.var.reshape(-1).cpu().double(),
+                 torch.tensor([float(rms.count)], dtype=torch.float64)]
+    return torch.cat(flat).numpy(), captured["adv"].double().numpy(), \
+        int(res["num_global_steps"])
+
+
+def _equiv_worker(rank, world, port, kind, overlap, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo",
+                                init_method="tcp://127.0.0.1:%d" % port,
+                                rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    q.put((world, rank) + _equiv_run(kind, overlap, world, rank))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,overlap", [("tce", True), ("tce", False),
+                                          ("tce_accrew", True),
+                                          ("bbrl", False)])
+def test_sharded_equals_single_process(kind, overlap):
+    """2 ranks x 32 envs == 1 process x the same 64 envs: parameters after two
+    iterations (3 + 3 epochs each), observation statistics and the normalised
+    segment advantages agree to fp32 summation noise (the sharded run sums
+    per-rank partial gradients / moments in a different order).  TCE (C2
+    shape) with the overlapped and the serial update, and the BBRL agent
+    (BASELINE configs[3])."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 200) + (37 if overlap else 0) + \
+        {"tce": 0, "tce_accrew": 53, "bbrl": 71}[kind]
+    procs = [ctx.Process(target=_equiv_worker,
+                         args=(r, 2, port, kind, overlap, q))
+             for r in range(2)]
+    procs.append(ctx.Process(target=_equiv_worker,
+                             args=(0, 1, port, kind, overlap, q)))
+    for p in procs:
+        p.start()
+    out = {(w, r): rest for w, r, *rest in
+           (q.get(timeout=600) for _ in range(3))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (w0, a0, g0), (w1, a1, g1) = out[(2, 0)], out[(2, 1)]
+    ws, as_, gs = out[(1, 0)]
+    assert np.array_equal(w0, w1)                        # lock-step
+    assert g0 == g1 == gs == 2 * N_GLOBAL * 500
+    # normalised advantages: global-batch mean / std on both sides
+    np.testing.assert_allclose(np.concatenate([a0, a1]), as_, rtol=2e-4,
+                               atol=2e-4)
+    # parameters (Adam normalises the gradient: an entry whose gradient is
+    # pure summation noise moves by +-lr either way, hence the absolute term
+    # 2 iterations x 3 epochs x lr 3e-4 would allow; observed: ~1e-6)
+    np.testing.assert_allclose(w0, ws, rtol=2e-3, atol=2e-5)
