@@ -130,6 +130,40 @@ def test_traj_shared_L_and_boundary_conditions(ops):
     assert (end[:, 0, :D] - goal).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_kernel_trajectory_solves_the_dmp_ode(ops, name, dtype):
+    """The trajectory KERNEL (table built by tce_rl_amd/mp/prodmp.py,
+    interpolated and contracted on the GPU) against a scipy integration of the
+    DMP ODE written from the paper (tests/prodmp_ode.py; shares no code with the
+    oracle or the product).  Bounds as in tests/test_prodmp_ode_cpu.py: the
+    tables' own second-order error, u = (alpha dt / tau)^2."""
+    from prodmp_ode import DMPODE
+    from tce_rl_amd.mp import ProDMP
+    cfg = CFGS[name]
+    mp = ProDMP(dtype=dtype, device="cuda", **cfg)
+    ode = DMPODE(**{k: v for k, v in cfg.items() if k != "num_dof"})
+    N, T, dt, dof = 3, HORIZON[name], cfg["dt"], cfg["num_dof"]
+    K = dof * (cfg["num_basis"] + 1)
+    g = np.random.default_rng(5)
+    w = g.normal(size=(N, K))
+    y0 = g.uniform(-1, 1, size=(N, dof))
+    v0 = 0.3 * g.normal(size=(N, dof))
+    times = dt * np.arange(1, T + 1)
+    dev = lambda a: torch.as_tensor(a, dtype=dtype).cuda()
+    t0 = torch.zeros(N, dtype=dtype).cuda()
+    out = ops.prodmp_traj(mp, dev(np.tile(times, (N, 1))), dev(w), t0,
+                          dev(y0), dev(v0)).double().cpu().numpy()
+    u = (cfg["alpha"] * dt / cfg["tau"]) ** 2
+    fp = 0.0 if dtype == torch.float64 else 2e-5
+    for n in range(N):
+        p_ref, v_ref = ode.trajectory(times, w[n], 0.0, y0[n], v0[n])
+        assert np.abs(out[n, :, :dof] - p_ref).max() <= \
+            (0.25 * u + fp) * np.abs(p_ref).max()
+        assert np.abs(out[n, :, dof:] - v_ref).max() <= \
+            (0.5 * u + fp) * np.abs(v_ref).max()
+
+
 def test_pair_logprob_golden_plumbing(ops, golden):
     """Fixture produced by the reference's TemporalCorrelatedPolicy.log_prob."""
     from tce_rl_amd.mp import ProDMP
