@@ -237,3 +237,26 @@ def test_kl_cov_projection_warm_start(ops, K):
         torch.testing.assert_close(warm, cold.detach(), rtol=1e-10, atol=1e-11)
         torch.testing.assert_close(torch.tril(gw), torch.tril(Lr.grad),
                                    rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("K", [4, 12, 24])
+def test_kl_cov_projection_kernel_is_the_constrained_optimum(ops, K):
+    """The projection KERNEL (Jacobi eigen-decomposition + bisection on the
+    GPU) against a direct SLSQP solution of
+        min KL_cov(S~ || S)  s.t.  KL_cov(S~ || S_old) <= eps
+    (tests/test_kl_optimum_cpu.py; nothing of oracle/kl_oracle.py involved)."""
+    import numpy as np
+    from test_kl_optimum_cpu import direct_cov_projection, kl_cov, spd
+    g = np.random.default_rng(K)
+    S_old, S = spd(K, g), spd(K, g, scale=1.7)
+    eps = 5e-3
+    C_ref, f_ref, slack = direct_cov_projection(S, S_old, eps)
+    assert abs(slack) < 1e-9
+    chol = lambda A: torch.linalg.cholesky(torch.as_tensor(A))[None].cuda()
+    pl = ops.kl_cov_projection(chol(S), chol(S_old), eps)[0].cpu()
+    proj = pl @ pl.T
+    f = float(kl_cov(proj, torch.as_tensor(S)))
+    c = float(kl_cov(proj, torch.as_tensor(S_old)))
+    assert abs(c - eps) < 1e-9
+    assert abs(f - f_ref) <= 1e-8 * max(1.0, abs(f_ref))
+    np.testing.assert_allclose(proj.numpy(), C_ref, rtol=5e-5, atol=5e-6)
