@@ -271,6 +271,45 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- GPU-resident synthetic env suite ------------------------
+ * Stands in for the env processes behind SubprocVecEnv.step
+ * (mprl/util/util_mp.py:119-185) and speaks the per-episode protocol the
+ * sampler consumes (mprl/rl/sampler/temporal_correlated_sampler.py:226-303):
+ * ONE launch steps N envs through a whole episode of T steps.
+ *   actions  [N,T,2 dof]  desired pos | vel (the ProDMP trajectory)
+ *   init_obs [N,D]        reset observation, D = d_task + 1 + 2 dof, laid out
+ *                         [q(dof) | qd(dof) | obj(3) | goal(3) | 0.. | time |
+ *                          des_pos(dof) | des_vel(dof)]
+ *   family   0 reach, 1 push / box-push, 2 table-tennis-like (event hit_ball),
+ *            3 hopper-jump-like (event has_left_floor)
+ * Dynamics: unit point mass per dof under PD tracking, semi-implicit Euler:
+ *   a = kp (des_pos - q) + kd (des_vel - qd); qd += dt a; q += dt qd.
+ * Outputs: states [N,T+1,D] (row 0 = init_obs; NULL = not wanted, the
+ * black-box env), rewards [N,T], event_flags [N,T] (1 byte; may be NULL),
+ * metrics [N,2] = {success, final distance} (may be NULL), and -- when
+ * moment_partials (double [N,D,2]) is given -- per-env shifted column sums
+ * {sum(x - shift), sum((x - shift)^2)} over the T+1 rows, which
+ * tce_rms_merge_* folds into the running mean/var exactly like
+ * tce_rms_update_* (RunningMeanStd.update, mprl/util/util_numerical.py:315-337;
+ * `shift` may alias `mean`, batch_count = number of rows summed).
+ */
+int tce_env_rollout_f32(const float* actions, const float* init_obs, int family,
+                        int64_t N, int T, int dof, int d_task, float dt, float kp,
+                        float kd, float* states, float* rewards,
+                        uint8_t* event_flags, float* metrics, const float* shift,
+                        double* moment_partials, void* stream);
+int tce_env_rollout_f64(const double* actions, const double* init_obs, int family,
+                        int64_t N, int T, int dof, int d_task, double dt, double kp,
+                        double kd, double* states, double* rewards,
+                        uint8_t* event_flags, double* metrics, const double* shift,
+                        double* moment_partials, void* stream);
+int tce_rms_merge_f32(const double* moment_partials, int64_t nparts, int D,
+                      const float* shift, double batch_count, double count,
+                      float* mean, float* var, void* stream);
+int tce_rms_merge_f64(const double* moment_partials, int64_t nparts, int D,
+                      const double* shift, double batch_count, double count,
+                      double* mean, double* var, void* stream);
+
 /* ---- streams restricted to a slice of every XCD ---------------------------
  * The critic update and the policy update of one iteration are independent
  * (mprl/rl/agent/temporal_correlated_agent.py:55-70 runs them back to back);

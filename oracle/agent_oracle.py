@@ -11,6 +11,7 @@ TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Used by
 """
 import torch
 
+from . import env_oracle as E
 from . import kl_oracle as KO
 from . import tce_oracle as O
 from .prodmp_oracle import ProDMPOracle, pair_log_prob
@@ -31,7 +32,7 @@ class OracleTCE:
         self.dof, self.K = self.mp.num_dof, self.mp.num_dof * self.mp.num_basis_g
         self.N, self.dt = num_env, self.mp.dt
         self.T = {0.0125: 500, 0.02: 100, 0.008: 350}[self.dt]
-        self.d_task = {500: 39, 100: 20, 350: 19}[self.T]
+        self.task, self.d_task = E.FAMILY[self.T]
         self.D = self.d_task + 1 + 2 * self.dof
         self.a = a
         pa, ca = cfg["policy"]["args"], cfg["critic"]["args"]
@@ -77,17 +78,17 @@ class OracleTCE:
         else:
             self.goal = r(self.N, self.dof) * 2 - 1
             pos = 0.1 * (r(self.N, self.dof) * 2 - 1)
-        task = torch.zeros(self.N, self.d_task, dtype=self.dtype)
-        task[:, :self.dof] = self.goal
-        task[:, self.dof:2 * self.dof] = pos
         z = torch.zeros(self.N, self.dof, dtype=self.dtype)
-        return torch.cat([task, torch.zeros(self.N, 1, dtype=self.dtype), pos,
-                          z], -1)
+        return E.reset_obs(self.task, self.d_task, self.goal, pos, z)
 
-    def step(self):
-        self.it += 1
+    def rollout(self, training=True, deterministic=False):
+        """TemporalCorrelatedSampler.run (temporal_correlated_sampler.py:91-344)
+        on the synthetic env: with ``training`` the observation statistics are
+        updated and applied before the critic (:244-249); an evaluation run
+        (``deterministic``: the mean parameters instead of a sample, :305-315)
+        feeds the critic raw states and leaves the statistics alone.  The pair
+        offsets are drawn in both cases (:136)."""
         N, T, D2 = self.N, self.T, 2 * self.dof
-        a = self.a
         with torch.no_grad():
             s0 = self._reset()
             pairs = O.get_time_pairs(T, dict(num_select=25,
@@ -96,31 +97,57 @@ class OracleTCE:
             y0, v0 = s0[:, -D2:-self.dof], s0[:, -self.dof:]
             mean_old, L_old = self._policy(s0[:, :-D2])
             times = O.get_times(t0, self.dt, T)
-            eps = torch.randn(N, self.K, generator=self.gen, dtype=self.dtype) \
-                if self.forced_eps is None else self.forced_eps
+            if deterministic:
+                eps = torch.zeros(N, self.K, dtype=self.dtype)
+            elif self.forced_eps is not None:
+                eps = self.forced_eps
+            else:
+                eps = torch.randn(N, self.K, generator=self.gen,
+                                  dtype=self.dtype)
             pos, vel = self.mp.sample_trajectories(times, mean_old, L_old, t0,
                                                    y0, v0, eps)
             actions = torch.cat([pos, vel], -1)
             lp_old = pair_log_prob(self.mp, actions, mean_old, L_old, times,
                                    t0, y0, v0, pairs)
-            states = torch.zeros(N, T, self.D, dtype=self.dtype)
-            states[..., :self.dof] = self.goal[:, None]
-            states[..., self.dof:D2] = pos
-            states[..., self.d_task] = self.dt * torch.arange(
-                1, T + 1, dtype=self.dtype)
-            states[..., self.d_task + 1:] = actions
-            rewards = -((pos - self.goal[:, None]) ** 2).sum(-1) \
-                - 1e-3 * (vel ** 2).sum(-1)
-            if T == 350:          # table-tennis family: make_mdp_reward on the
-                # synthetic "hit" event (first step within 0.5 of the goal)
-                near = (pos - self.goal[:, None]).norm(dim=-1) < 0.5
-                flags = torch.cummax(near.to(torch.int8), dim=1).values.bool()
+            states, rewards, flags, metrics = E.rollout(
+                self.task, actions, s0, self.dof, self.d_task, self.dt)
+            episode_reward = rewards.sum(-1)
+            if self.task == "table_tennis":     # make_mdp_reward on hit_ball
                 rewards = O.make_mdp_reward(rewards, flags)
-            states = torch.cat([s0[:, None], states], 1)
-            self.rms.update(states.view(-1, self.D))
-            nstates = self.rms.normalise(states)
+            if training:
+                self.rms.update(states.view(-1, self.D))
+                nstates = self.rms.normalise(states)
+            else:
+                nstates = states
             values = self._mlp(self.cnet, nstates[..., :-D2],
                                self.c_act).squeeze(-1)
+        return dict(step_actions=actions, segment_log_prob_estimate=lp_old,
+                    step_values=values, step_rewards=rewards,
+                    episode_reward=episode_reward,
+                    segment_reward=rewards.sum(-1), pred_pairs=pairs,
+                    segment_params_mean=mean_old, segment_params_L=L_old,
+                    step_states=nstates, segment_state=s0, times=times,
+                    success=metrics[:, 0])
+
+    def evaluate(self):
+        """AbstractAgent.evaluate(evaluate_deterministic=True)
+        (abstract_agent.py:219-255): one deterministic test rollout."""
+        return self.rollout(training=False, deterministic=True)
+
+    def step(self):
+        self.it += 1
+        N, T, D2 = self.N, self.T, 2 * self.dof
+        a = self.a
+        ro = self.rollout(training=True)
+        actions, lp_old, values = ro["step_actions"], \
+            ro["segment_log_prob_estimate"], ro["step_values"]
+        rewards, pairs, nstates = ro["step_rewards"], ro["pred_pairs"], \
+            ro["step_states"]
+        mean_old, L_old, s0, times = ro["segment_params_mean"], \
+            ro["segment_params_L"], ro["segment_state"], ro["times"]
+        t0 = s0[:, -D2 - 1]
+        y0, v0 = s0[:, -D2:-self.dof], s0[:, -self.dof:]
+        with torch.no_grad():
             dones = torch.zeros(N, T, dtype=torch.bool)
             dones[:, -1] = True
             tl = torch.zeros_like(dones)
@@ -187,6 +214,7 @@ class OracleBBRL:
         self.N, self.dt, self.dtype = num_env, self.mp.dt, dtype
         self.T = {0.0125: 500, 0.02: 100, 0.008: 350}[self.dt]
         self.D = dim_obs
+        self.task = "push"              # metaworld push-v2 stand-in (BASELINE C4)
         mk = lambda hid, d_out, gain: torch.nn.ParameterList(
             [torch.nn.Parameter(t) for Wb in O.mlp_init(dim_obs, d_out, hid,
                                                        gain, dtype) for t in Wb])
@@ -221,19 +249,19 @@ class OracleBBRL:
         N, T = self.N, self.T
         goal, pos0 = self.forced_reset
         with torch.no_grad():
-            obs = torch.zeros(N, self.D, dtype=self.dtype)
-            obs[:, :self.dof] = goal
-            obs[:, self.dof:2 * self.dof] = pos0
+            v0 = torch.zeros(N, self.dof, dtype=self.dtype)
+            full0 = E.reset_obs(self.task, self.D, goal, pos0, v0)
+            obs = full0[:, :self.D]
             mean_old, L_old = self._policy(obs)
             action = O.mvn_rsample(mean_old, L_old, self.forced_eps)
             lp_old = O.mvn_log_prob(action, mean_old, L_old)
             values = self._mlp(self.cnet, obs).squeeze(-1)
             t0 = torch.zeros(N, dtype=self.dtype)
-            v0 = torch.zeros(N, self.dof, dtype=self.dtype)
             pos, vel = self.mp.traj(O.get_times(t0, self.dt, T), action, t0,
                                     pos0, v0)
-            reward = (-((pos - goal[:, None]) ** 2).sum(-1)
-                      - 1e-3 * (vel ** 2).sum(-1)).sum(-1)
+            _, rew, _, _ = E.rollout(self.task, torch.cat([pos, vel], -1),
+                                     full0, self.dof, self.D, self.dt)
+            reward = rew.sum(-1)
             adv = O.bbrl_advantage(reward, values, self.norm_advantages,
                                    self.clip_advantages)
         self.last = dict(segment_action=action, segment_log_prob=lp_old,

@@ -577,10 +577,62 @@ def rms_update(x, mean, var, count):
     return count + R
 
 
-def rms_normalize(x, mean, var, eps=1e-8):
+ENV_FAMILIES = {"reach": 0, "push": 1, "table_tennis": 2, "hopper": 3}
+
+
+def env_rollout(actions, init_obs, family, dof, d_task, dt, kp, kd,
+                want_states=True, want_flags=False, shift=None,
+                want_moments=False):
+    """One whole episode of the synthetic env suite (csrc/env.hip) for the N
+    envs of actions [N, T, 2 dof] / init_obs [N, D] -> dict with
+    ``states`` [N, T+1, D] (row 0 = init_obs) or None, ``rewards`` [N, T],
+    ``flags`` [N, T] bool or None, ``metrics`` [N, 2] {success, final
+    distance}, ``partials`` float64 [N, D, 2] (column moments of the T+1 rows,
+    shifted by ``shift``) or None."""
+    check_dev(actions, init_obs, shift)
+    actions, init_obs = _c(actions), _c(init_obs)
+    N, T, A = actions.shape
+    D = init_obs.shape[-1]
+    assert A == 2 * dof and D == d_task + 1 + 2 * dof and init_obs.shape[0] == N
+    dt_, dev = actions.dtype, actions.device
+    states = torch.empty(N, T + 1, D, dtype=dt_, device=dev) \
+        if want_states else None
+    rewards = torch.empty(N, T, dtype=dt_, device=dev)
+    flags = torch.empty(N, T, dtype=torch.uint8, device=dev) \
+        if want_flags else None
+    metrics = torch.empty(N, 2, dtype=dt_, device=dev)
+    partials = torch.empty(N, D, 2, dtype=torch.float64, device=dev) \
+        if want_moments else None
+    if shift is not None:
+        shift = _c(shift.to(dt_))
+    call("tce_env_rollout_" + sfx(dt_), ptr(actions), ptr(init_obs),
+         ENV_FAMILIES[family], N, T, int(dof), int(d_task), float(dt),
+         float(kp), float(kd), ptr(states), ptr(rewards), ptr(flags),
+         ptr(metrics), ptr(shift), ptr(partials), stream())
+    return dict(states=states, rewards=rewards,
+                flags=None if flags is None else flags.view(torch.bool),
+                metrics=metrics, partials=partials)
+
+
+def rms_merge(partials, rows, mean, var, count, shift=None):
+    """Fold the moment partials [nparts, D, 2] of `rows` observation rows
+    (accumulated relative to `shift`, default: the running mean itself) into
+    the running mean / var [D] in place; returns the new count."""
+    check_dev(partials, mean, var, shift)
+    D = mean.numel()
+    assert partials.dtype == torch.float64 and partials.shape[-2:] == (D, 2)
+    partials = _c(partials)
+    sh = mean if shift is None else _c(shift)
+    call("tce_rms_merge_" + sfx(mean.dtype), ptr(partials),
+         partials.numel() // (2 * D), D, ptr(sh), float(rows), float(count),
+         ptr(mean), ptr(var), stream())
+    return count + rows
+
+
+def rms_normalize(x, mean, var, eps=1e-8, inplace=False):
     check_dev(x, mean, var)
     x = _c(x)
-    y = torch.empty_like(x)
+    y = x if inplace else torch.empty_like(x)
     call("tce_rms_normalize_" + sfx(x.dtype), ptr(x), ptr(y), x.numel(),
          x.shape[-1], ptr(mean), ptr(var), float(eps), stream())
     return y

@@ -34,15 +34,30 @@ class RunningMeanStd:
         statistics are those of the GLOBAL batch (pooled over the ranks before
         the running merge), so every rank keeps the same normalisation and it
         equals the single-process result."""
+        self._merge(lambda mean, var, count:
+                    ops.rms_update(arr, mean, var, count))
+
+    def update_from_partials(self, partials, rows):
+        """The same update from column-moment partials [*, D, 2] that were
+        accumulated relative to the current running mean while the batch was
+        being produced (the env rollout kernel): no second pass over it."""
+        shift = self.mean.clone()
+        self._merge(lambda mean, var, count:
+                    ops.rms_merge(partials, rows, mean, var, count,
+                                  shift=shift))
+
+    def _merge(self, fold):
+        """fold(mean, var, count) -> new count merges the local batch into the
+        given running state in place."""
         import torch.distributed as dist
         from ..dist import active
         if not active():
-            self.count = ops.rms_update(arr, self.mean, self.var, self.count)
+            self.count = fold(self.mean, self.var, self.count)
             return
-        # local batch moments through the same kernel (merge into an empty state)
+        # local batch moments through the same kernels (merge into an empty state)
         bm = torch.zeros_like(self.mean)
         bv = torch.zeros_like(self.var)
-        n_loc = ops.rms_update(arr, bm, bv, 0.0)
+        n_loc = fold(bm, bv, 0.0)
         D = bm.numel()
         w = dist.get_world_size()
         mine = torch.cat([bm.double().reshape(-1), bv.double().reshape(-1),
@@ -238,8 +253,8 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
         return self.pred_pairs
 
     @staticmethod
-    def apply_normalization(raw, rms):
-        return ops.rms_normalize(raw, rms.mean, rms.var, 1e-8)
+    def apply_normalization(raw, rms, inplace=False):
+        return ops.rms_normalize(raw, rms.mean, rms.var, 1e-8, inplace=inplace)
 
     @torch.no_grad()
     def run(self, training, policy, critic, deterministic=False, render=False,
@@ -278,15 +293,23 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
                                        init_pos=init_pos, init_vel=init_vel,
                                        pred_pairs=pred_pairs)
             assert_shape(actions, [num_env, num_times, num_dof * 2])
-            next_state, ep_reward, _, infos = envs.step(actions)
-            step_states = torch.cat([init_state[:, None],
-                                     infos["step_states"]], dim=-2)
             # only updated AND applied during training: evaluation feeds the
             # critic raw states (temporal_correlated_sampler.py:244-249)
-            if self.norm_step_obs and training:
-                self.obs_rms.update(step_states.view(-1, dim_obs))
-                norm_states = self.apply_normalization(step_states,
-                                                       self.obs_rms)
+            norm = self.norm_step_obs and training
+            if norm:
+                # the env kernel writes the [N, T+1, D] buffer (initial state
+                # in row 0) once and sums the column moments in the same pass
+                next_state, ep_reward, _, infos = envs.step(
+                    actions, obs_shift=self.obs_rms.mean, want_moments=True)
+            else:
+                next_state, ep_reward, _, infos = envs.step(actions)
+            step_states = infos["step_states_full"]
+            if norm:
+                self.obs_rms.update_from_partials(
+                    infos["obs_moment_partials"],
+                    rows=step_states.shape[0] * step_states.shape[1])
+                norm_states = self.apply_normalization(
+                    step_states, self.obs_rms, inplace=True)
             else:
                 norm_states = step_states
             values = critic.critic(

@@ -62,11 +62,14 @@ def test_direct_epoch_equals_autograd_epoch():
 @pytest.mark.parametrize("env,nb,dtype", [
     ("metaworld", 8, "float32"), ("box_push", 8, "float32"),
     ("box_push", 3, "float32"), ("table_tennis", 3, "float32"),
+    ("table_tennis", 8, "float32"),
     ("box_push", 3, "float64"), ("metaworld", 5, "float64")])
 def test_agent_step_matches_cpu_oracle_other_shapes(env, nb, dtype):
     """K 36 (the reference's Metaworld basis count) and the 7-dof box-pushing
     shapes (K 63 / 28, T 100, 256-wide leaky-relu critic on the library path);
-    table tennis: T 350, phase delay, tanh policy, MDP-reward re-shaping."""
+    table tennis: T 350, phase delay 0.3, tanh policy, MDP-reward re-shaping
+    -- with the reference's 3 basis functions (K 28) and with the 8 that
+    BASELINE.json configs[4] states (K 63)."""
     _agent_vs_oracle(True, True, False, env, nb, dtype)
 
 
@@ -153,6 +156,84 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32", **kw):
     torch.testing.assert_close(agent.policy.variance_net.variable.detach().cpu(),
                                oracle.var.detach(), rtol=5e-3, atol=5e-5)
     assert np.isfinite(res["critic_loss_mean"])
+
+
+@pytest.mark.parametrize("env,nb", [("metaworld", 5), ("table_tennis", 3)])
+def test_deterministic_evaluation_matches_cpu_oracle(env, nb):
+    """f4: AbstractAgent.evaluate (abstract_agent.py:219-255) =
+    one deterministic test rollout (use_mean, temporal_correlated_sampler.py:
+    305-315): the trajectory of the mean parameters, raw (un-normalised) states
+    into the critic, observation statistics untouched, pair offsets drawn --
+    after one training step, against the CPU oracle's evaluate()."""
+    from oracle.agent_oracle import OracleTCE
+    N = 16
+    agent, cfg = build(N, 2, True, env=env, num_basis=nb)
+    oracle = OracleTCE(cfg["params"], N)
+    with torch.no_grad():
+        for po, pg in zip(oracle.pnet, agent.policy.mean_net.parameters()):
+            po.copy_(pg.cpu())
+        for po, pg in zip(oracle.cnet, agent.critic.net.parameters()):
+            po.copy_(pg.cpu())
+        oracle.var.copy_(agent.policy.variance_net.variable.cpu())
+    g = torch.Generator().manual_seed(9)
+    dof = agent.policy.num_dof
+    goal = torch.rand(N, dof, generator=g) * 2 - 1
+    pos0 = 0.1 * (torch.rand(N, dof, generator=g) * 2 - 1)
+    eps = torch.randn(N, agent.policy.dim_out, generator=g)
+    for e in (agent.sampler.train_envs, agent.sampler.test_envs):
+        def reset(e=e):
+            e.goal = goal.cuda()
+            z = torch.zeros(N, dof, device="cuda")
+            return e._obs(torch.zeros(N, device="cuda"), pos0.cuda(), z)
+        e.reset = reset
+    orig_sample = agent.policy.sample
+    agent.policy.sample = lambda **kw: orig_sample(
+        **kw, **({} if kw.get("use_mean") else {"eps": eps.cuda()}))
+    oracle.forced_reset, oracle.forced_eps = (goal, pos0), eps
+    torch.manual_seed(11)
+    agent.step()
+    torch.manual_seed(11)
+    oracle.step()
+    rms_before = (agent.sampler.obs_rms.mean.clone(),
+                  agent.sampler.obs_rms.var.clone(), agent.sampler.obs_rms.count)
+    torch.manual_seed(12)
+    det, sto = agent.evaluate()
+    torch.manual_seed(12)
+    ref = oracle.evaluate()
+    assert sto == {}
+    assert np.array_equal(agent.sampler.pred_pairs.cpu().numpy(),
+                          ref["pred_pairs"].numpy())
+    # the policy / critic differ by one fp32 training step (tolerances of
+    # _agent_vs_oracle: parameters agree to rtol 5e-3 there); the evaluation
+    # rollout itself adds nothing to that
+    c = lambda k: det[k].detach().cpu()
+    torch.testing.assert_close(c("step_actions"), ref["step_actions"],
+                               rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(c("step_rewards"), ref["step_rewards"],
+                               rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(c("episode_reward"), ref["episode_reward"],
+                               rtol=1e-3, atol=5e-2)
+    torch.testing.assert_close(c("step_values"), ref["step_values"],
+                               rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c("segment_log_prob_estimate"),
+                               ref["segment_log_prob_estimate"], rtol=5e-4,
+                               atol=5e-3)
+    assert torch.equal(c("success"), ref["success"])
+    # deterministic: the trajectory is the one of the mean parameters
+    mean = det["segment_params_mean"]
+    from tce_rl_amd import ops
+    t0 = det["segment_init_time"]
+    again = ops.prodmp_traj(agent.policy.mp,
+                            agent.sampler.get_times(t0, agent.sampler.num_times),
+                            mean, t0, det["segment_init_pos"],
+                            det["segment_init_vel"])
+    torch.testing.assert_close(det["step_actions"], again)
+    # raw states went to the critic and the statistics did not move
+    s = det["step_states_full"]
+    assert torch.equal(s[:, 0], det["segment_state"])
+    assert torch.equal(agent.sampler.obs_rms.mean, rms_before[0])
+    assert torch.equal(agent.sampler.obs_rms.var, rms_before[1])
+    assert agent.sampler.obs_rms.count == rms_before[2]
 
 
 def test_checkpoint_round_trip(tmp_path):
