@@ -251,12 +251,14 @@ def test_kl_cov_projection_kernel_is_the_constrained_optimum(ops, K):
     S_old, S = spd(K, g), spd(K, g, scale=1.7)
     eps = 5e-3
     C_ref, f_ref, slack = direct_cov_projection(S, S_old, eps)
-    assert abs(slack) < 1e-9
+    assert abs(slack) < 2e-8           # SLSQP's own feasibility (300 unknowns at K 24)
     chol = lambda A: torch.linalg.cholesky(torch.as_tensor(A))[None].cuda()
     pl = ops.kl_cov_projection(chol(S), chol(S_old), eps)[0].cpu()
     proj = pl @ pl.T
     f = float(kl_cov(proj, torch.as_tensor(S)))
     c = float(kl_cov(proj, torch.as_tensor(S_old)))
     assert abs(c - eps) < 1e-9
-    assert abs(f - f_ref) <= 1e-8 * max(1.0, abs(f_ref))
+    # SLSQP sits `slack` outside / inside the region, worth eta * slack of
+    # objective (eta = O(10) here)
+    assert abs(f - f_ref) <= 1e-8 * max(1.0, abs(f_ref)) + 20 * abs(slack)
     np.testing.assert_allclose(proj.numpy(), C_ref, rtol=5e-5, atol=5e-6)
