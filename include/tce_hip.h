@@ -421,6 +421,43 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        float* adam_state, float lr, float beta1, float beta2, float eps,
                        float weight_decay, float adam_step, void* stream);
 
+/* ---- fused critic epoch for wide / double-precision value networks ---------
+ * The contract of tce_mlp_critic_f32 for  D_in -> hidden -> hidden -> 1  with
+ * hidden = 256 (float32; float64 with D_in <= 24) or hidden = 128 (float64):
+ * the critics of mprl/config/box_push_random_init/tcp/entire/shared.yaml:7,95-96
+ * (float64, 256 x 2) and mprl/config/table_tennis_4d/tcp/entire/shared.yaml:98-103,
+ * on the exact matrix instructions (v_mfma_f32_16x16x4_f32 /
+ * v_mfma_f64_16x16x4_f64).  tce_mlpw_supported(D_in, hidden, element size) tells
+ * whether a combination is built.  workspace: tce_mlpw_workspace_len(R, hidden,
+ * backward) elements (W2 images; backward: H1, dY2, dY1 of all rows, written by
+ * the chain kernel and contracted by the weight-gradient kernel); partials:
+ * [tce_mlpw_grid(), tce_mlpw_num_params(D_in, hidden) + 2]; grad in the order
+ * W1, b1, W2, b2, w3, b3; stats[2] = {mean loss, |grad|^2} zeroed by the caller.
+ * partials == NULL: forward only (values required).
+ */
+int tce_mlpw_supported(int din, int hidden, int elem_size);
+int tce_mlpw_grid(void);
+int64_t tce_mlpw_num_params(int din, int hidden);
+int64_t tce_mlpw_workspace_len(int64_t R, int hidden, int backward);
+int tce_mlpw_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                        int64_t R, int din, int hidden, const float* w1, const float* b1,
+                        const float* w2, const float* b2, const float* w3, const float* b3,
+                        int act, const float* returns, const float* old_values, float clip,
+                        float* values, float* workspace, float* partials, float* grad,
+                        float* stats, int max_workgroups, float* adam_param, float* adam_m,
+                        float* adam_v, float* adam_state, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float adam_step, void* stream);
+int tce_mlpw_critic_f64(const double* x, int64_t env_stride, int64_t row_stride, int T,
+                        int64_t R, int din, int hidden, const double* w1, const double* b1,
+                        const double* w2, const double* b2, const double* w3,
+                        const double* b3, int act, const double* returns,
+                        const double* old_values, double clip, double* values,
+                        double* workspace, double* partials, double* grad, double* stats,
+                        int max_workgroups, double* adam_param, double* adam_m,
+                        double* adam_v, double* adam_state, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, double adam_step,
+                        void* stream);
+
 /* The backward launch of tce_mlp_critic_f32 (same buffers and contract;
  * partials != NULL required) on the f16 matrix cores with SPLIT operands: every
  * fp32 operand is carried as hi = f16(x), lo = f16((x - hi) 2^11) and every

@@ -1,21 +1,44 @@
-"""Fused critic epochs on the exact-fp32 matrix cores (csrc/mlp.hip).
+"""Fused critic epochs on the exact matrix cores.
 
-``supported(mlp)``: the value network D_in -> 128 -> 128 -> 1 in float32 (the
-Metaworld config); anything else stays on the library-GEMM path (mlp_ops).
+``supported(mlp)``: the value network D_in -> H -> H -> 1 with
+* H = 128 in float32 (the Metaworld config): csrc/mlp.hip, one launch per epoch
+  (+ the split-f16 variant csrc/mlp16.hip);
+* H = 256 in float32 / float64 (box pushing, table tennis) and H = 128 in
+  float64: csrc/mlpw_*.hip, chain kernel + weight-gradient kernel per epoch.
+Anything else stays on the library-GEMM path (mlp_ops).
 """
 import torch
 
 from . import _lib
-from ._lib import call, ptr, stream
+from ._lib import call, ptr, sfx, stream
 
 _ACT = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
 
 
-def supported(mlp):
+def narrow_supported(mlp):
+    """D_in -> 128 -> 128 -> 1, float32: csrc/mlp.hip."""
     return (mlp.dtype == torch.float32 and mlp.dim_out == 1
             and list(mlp.hidden_layers) == [128, 128]
             and 1 <= mlp.dim_in <= 40 and mlp.act_func_last_type is None
             and mlp.act_func_hidden_type in _ACT)
+
+
+def wide_supported(mlp):
+    """The shapes csrc/mlpw_*.hip is built for (tce_mlpw_supported)."""
+    hl = list(mlp.hidden_layers)
+    if not (mlp.dim_out == 1 and len(hl) == 2 and hl[0] == hl[1]
+            and mlp.act_func_last_type is None
+            and mlp.act_func_hidden_type in _ACT
+            and mlp.dtype in (torch.float32, torch.float64)):
+        return False
+    if narrow_supported(mlp):
+        return False
+    esize = 4 if mlp.dtype == torch.float32 else 8
+    return bool(_lib.load().tce_mlpw_supported(mlp.dim_in, hl[0], esize))
+
+
+def supported(mlp):
+    return narrow_supported(mlp) or wide_supported(mlp)
 
 
 def _rows(x):
@@ -39,6 +62,8 @@ def _weights(mlp):
 
 def forward(mlp, x):
     """values [..., 1] without autograd (rollout / evaluation)."""
+    if wide_supported(mlp):
+        return _wide_forward(mlp, x)
     xs, es, rs, T, R = _rows(x)
     out = torch.empty(R, dtype=torch.float32, device=x.device)
     call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, mlp.dim_in,
@@ -46,6 +71,95 @@ def forward(mlp, x):
          ptr(out), None, None, None, 0, None, None, None, None, 0.0, 0.0, 0.0,
          0.0, 0.0, 0.0, stream())
     return out.reshape(*x.shape[:-1], 1)
+
+
+def _wide_ws(mlp, R, backward):
+    """Workspace of the wide kernels, cached on the module (W2 images +, for
+    the backward pass, H1 / dY2 / dY1 of all rows)."""
+    H = mlp.hidden_layers[0]
+    n = _lib.load().tce_mlpw_workspace_len(R, H, int(backward))
+    ws = getattr(mlp, "_tce_wide_ws", None)
+    dev = mlp.layers[0].weight.device
+    if ws is None or ws.numel() < n or ws.dtype != mlp.dtype or ws.device != dev:
+        ws = torch.empty(n, dtype=mlp.dtype, device=dev)
+        mlp._tce_wide_ws = ws
+    return ws
+
+
+def _wide_forward(mlp, x):
+    xs, es, rs, T, R = _rows(x)
+    out = torch.empty(R, dtype=mlp.dtype, device=x.device)
+    ws = _wide_ws(mlp, R, False)
+    call("tce_mlpw_critic_" + sfx(mlp.dtype), ptr(xs), es, rs, T, R,
+         mlp.dim_in, mlp.hidden_layers[0], *_weights(mlp),
+         _ACT[mlp.act_func_hidden_type], None, None, 0.0, ptr(out), ptr(ws),
+         None, None, None, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0,
+         0.0, stream())
+    return out.reshape(*x.shape[:-1], 1)
+
+
+class WideEpochRunner:
+    """EpochRunner for the wide / float64 value networks (csrc/mlpw_*.hip):
+    same interface, two launches (+ the slab reduction) per epoch."""
+    arith = "f32"
+
+    def __init__(self, mlp, flat=None, arith="f32"):
+        assert wide_supported(mlp) and arith == "f32"
+        self.mlp = mlp
+        lib = _lib.load()
+        self.H = mlp.hidden_layers[0]
+        self.P = lib.tce_mlpw_num_params(mlp.dim_in, self.H)
+        dev = mlp.layers[0].weight.device
+        if flat is None:
+            flat = torch.zeros(self.P, dtype=mlp.dtype, device=dev)
+        assert flat.numel() == self.P and flat.dtype == mlp.dtype
+        self.flat = flat
+        self.entry = "tce_mlpw_critic_" + sfx(mlp.dtype)
+        self.partials = torch.empty(lib.tce_mlpw_grid(), self.P + 2,
+                                    dtype=mlp.dtype, device=dev)
+        off = 0
+        self.params = list(mlp.parameters())
+        self.views = []
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        assert off == self.P
+
+    def epoch(self, states, returns, old_values, clip, max_workgroups=0,
+              stats=None, adam=None):
+        xs, es, rs, T, R = _rows(states)
+        ret = returns.reshape(-1)
+        ret = ret if ret.is_contiguous() else ret.contiguous()
+        old = old_values.reshape(-1).contiguous() if clip > 0 else None
+        if stats is None:
+            stats = torch.zeros(2, dtype=self.mlp.dtype,
+                                device=self.flat.device)
+        if adam is not None:
+            g = adam.param_groups[0]
+            adam.host_step += 1
+            adam._opt_called = True
+            ad = (ptr(adam.flat_param), ptr(adam.m), ptr(adam.v),
+                  ptr(adam.dev_state), float(g["lr"]), float(g["betas"][0]),
+                  float(g["betas"][1]), float(g["eps"]),
+                  float(g["weight_decay"]), float(adam.host_step))
+        else:
+            ad = (None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+        ws = _wide_ws(self.mlp, R, True)
+        call(self.entry, ptr(xs), es, rs, T, R, self.mlp.dim_in, self.H,
+             *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
+             ptr(ret), ptr(old), float(clip), None, ptr(ws),
+             ptr(self.partials), ptr(self.flat), ptr(stats),
+             int(max_workgroups), *ad, stream())
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return stats
+
+
+def make_runner(mlp, flat=None, arith="f32"):
+    """The epoch runner for a supported value network."""
+    if wide_supported(mlp):
+        return WideEpochRunner(mlp, flat, "f32")
+    return EpochRunner(mlp, flat, arith)
 
 
 class EpochRunner:
@@ -57,7 +171,7 @@ class EpochRunner:
         parameter order W1, b1, W2, b2, w3, b3); allocated if omitted.
         arith: "f32" (exact-fp32 matrix cores, csrc/mlp.hip) or "f16x2" (split
         f16 operands on the f16 matrix cores, csrc/mlp16.hip)."""
-        assert supported(mlp)
+        assert narrow_supported(mlp)
         assert arith in ("f32", "f16x2"), arith
         self.arith = arith
         self.entry = "tce_mlp_critic_" + arith

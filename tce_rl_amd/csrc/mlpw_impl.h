@@ -1,0 +1,872 @@
+// Fused critic epoch for WIDE and fp64 value networks  D_in -> H -> H -> 1
+// (H = 256: the box-pushing / table-tennis critics, fp32 or fp64; H = 128 in
+// fp64) on the exact matrix instructions v_mfma_f32_16x16x4_f32 /
+// v_mfma_f64_16x16x4_f64, templated on the arithmetic type.
+//
+// Replaces, per critic epoch (mprl/rl/agent/temporal_correlated_agent.py:343-366):
+//   values_new = critic(states[..., :-2 dof])       mprl/util/util_nn.py:225-246
+//   loss = value_loss(values_new, returns, old_vs)  :688-716
+//   loss.backward()
+// Configs: mprl/config/box_push_random_init/tcp/entire/shared.yaml:7,95-96
+// (float64, 256 x 2), mprl/config/table_tennis_4d/tcp/entire/shared.yaml:98-103.
+//
+// W2 (H*H*s = 256 KiB .. 512 KiB) does not fit the LDS next to anything else,
+// and the dW2 accumulators (same size) do not fit the registers beside the
+// chains.  Two launches per epoch:
+//
+//  chain kernel (mlpw_chain_kernel): as in mlp.hip everything is computed
+//   TRANSPOSED ([hidden x batch]); a wave owns 16 batch rows and keeps H1 and
+//   H2 / dY2 of those rows in registers as MFMA result tiles, which ARE the B
+//   operands of the next layer (forward X -> H1 -> H2 -> v, backward dY2 ->
+//   dH1 -> dY1 never leave the registers).  The A operands (W2 rows forward,
+//   W2^T rows backward) stream through LDS in panels of PU output units,
+//   double buffered: while the 8 (fp32) / 4 (fp64) waves of the workgroup
+//   contract panel p, panel p + 1 is fetched from L2 into registers and
+//   written to the other buffer; ONE barrier per panel.  W2 stays L2 resident
+//   (every workgroup streams the same 2 x H*H*s bytes per tile).  The kernel
+//   also writes H1, dY2 and dY1 of its rows to HBM ([R][H] each) and sums
+//   db1, db2, dw3, db3 and the loss.
+//  gradient kernel (mlpw_grad_kernel): dW2 = dY2^T H1 and dW1 = dY1^T X as a
+//   split-K product over those arrays: a workgroup takes a contiguous range
+//   of rows, stages KC rows at a time in LDS ([row][unit], double buffered)
+//   and keeps its dW2 / dW1 block in the registers of its 8 waves (fp64,
+//   H = 256: two workgroups per row range, half of dW2 each).
+//  mlpw_finish_kernel reduces the per-workgroup slabs in fixed order (+ Adam).
+//
+// MFMA-bound: per row 2 (D H + H H + H) forward + 2 H H (dH1) + 2 (H H + D H)
+// (weight gradients) flop; the HBM round trip of H1 / dY2 / dY1 (6 R H s bytes
+// per epoch) overlaps with the matrix work of both kernels.
+//
+// Result-tile layouts differ: register i of lane group g holds tile row 4 g + i
+// (f32) but 4 i + g (f64, measured: scripts/probe_mfma_layout.hip).  All
+// activation images (registers, LDS, HBM) are therefore kept in POSITION order:
+// position 16 J + 4 g + i holds unit 16 J + drow(g, i); weights are staged with
+// their input columns permuted to match (mlpw_prep_kernel), the slabs are
+// written back in unit order.
+#pragma once
+#include "common.h"
+
+namespace {
+
+enum { W_TANH = 0, W_RELU = 1, W_LEAKY = 2, W_SOFTPLUS = 3 };
+
+template <typename real> struct WV;
+template <> struct WV<float> {
+  typedef float v4 __attribute__((ext_vector_type(4), aligned(16)));
+  typedef float v2 __attribute__((ext_vector_type(2), aligned(8)));
+  typedef float acc __attribute__((ext_vector_type(4)));
+};
+template <> struct WV<double> {
+  typedef double v4 __attribute__((ext_vector_type(4), aligned(16)));
+  typedef double v2 __attribute__((ext_vector_type(2), aligned(16)));
+  typedef double acc __attribute__((ext_vector_type(4)));
+};
+
+__device__ inline WV<float>::acc wmfma(float a, float b, WV<float>::acc c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ inline WV<double>::acc wmfma(double a, double b, WV<double>::acc c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// tile row held by register i of lane group g
+template <typename real>
+__host__ __device__ inline int drow(int g, int i) {
+  return sizeof(real) == 4 ? 4 * g + i : 4 * i + g;
+}
+// unit held at storage position p (an involution)
+template <typename real>
+__host__ __device__ inline int unit_of_pos(int p) {
+  if (sizeof(real) == 4) return p;
+  return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3);
+}
+
+template <typename real, int ACT>
+__device__ inline real wact(real y) {
+  if (ACT == W_TANH) return tanh(y);
+  if (ACT == W_RELU) return y > real(0) ? y : real(0);
+  if (ACT == W_LEAKY) return y > real(0) ? y : real(0.01) * y;
+  return y > real(20) ? y : log1p(exp(y));
+}
+// derivative expressed with the OUTPUT h = act(y)
+template <typename real, int ACT>
+__device__ inline real wact_d(real h) {
+  if (ACT == W_TANH) return real(1) - h * h;
+  if (ACT == W_RELU) return h > real(0) ? real(1) : real(0);
+  if (ACT == W_LEAKY) return h > real(0) ? real(1) : real(0.01);
+  return real(1) - exp(-h);
+}
+
+// sum over the 16 lanes of a DPP row (all 16 get it)
+__device__ inline double row16_sum(double v) {
+  v = dpp_sum8(v);
+  v += dpp_perm_f64<0x140>(v);
+  return v;
+}
+template <int CTRL>
+__device__ inline float dpp_perm_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float row16_sum(float v) {
+  v += dpp_perm_f32<0x141>(v);          // row_half_mirror
+  v += dpp_perm_f32<0x4E>(v);           // quad_perm [2,3,0,1]
+  v += dpp_perm_f32<0xB1>(v);           // quad_perm [1,0,3,2]
+  v += dpp_perm_f32<0x140>(v);          // row_mirror
+  return v;
+}
+
+template <typename real>
+struct WArgs {
+  const real* x;         // states, row r = (n, t): x + n * env_stride + t * row_stride
+  int64_t env_stride, row_stride;
+  int T;
+  int64_t R;
+  int din, act;
+  const real *w1, *b1, *b2, *w3, *b3;     // torch Linear layout
+  const real *w2p, *w2tp;                 // prepared by mlpw_prep_kernel
+  const real *ret, *old_v;
+  real clip;
+  real* values;                           // [R] (nullable)
+  real *h1s, *dy2s, *dy1s;                // [R][H], position order (backward)
+  real* partials;                         // [grid][P + 2]
+  int P;
+};
+
+template <typename real>
+struct WCfg {
+  static constexpr int WAVES = sizeof(real) == 4 ? 8 : 4;   // chain kernel
+  static constexpr int NT = WAVES * 64;
+  static constexpr int TILE = WAVES * 16;                   // batch rows per tile
+  static constexpr int PU = sizeof(real) == 4 ? 32 : 16;    // output units per panel
+  static constexpr int NTILE = PU / 16;
+  static constexpr int WPAD = sizeof(real) == 4 ? 8 : 2;    // panel pitch = H + WPAD
+  static constexpr int KC = sizeof(real) == 4 ? 16 : 8;     // gradient kernel: rows per stage
+};
+
+__host__ __device__ inline int64_t mlpw_num_params(int din, int H) {
+  return (int64_t)H * din + H + (int64_t)H * H + H + H + 1;
+}
+
+// w2p[u][p] = W2[u][unit(p)];  w2tp[u1][p2] = W2[unit(p2)][u1]
+template <typename real>
+__global__ __launch_bounds__(256) void mlpw_prep_kernel(const real* __restrict__ w2, int H,
+                                                        real* __restrict__ w2p,
+                                                        real* __restrict__ w2tp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= H * H) return;
+  const int r = e / H, p = e - r * H;
+  const int u = unit_of_pos<real>(p);
+  w2p[e] = w2[r * H + u];
+  w2tp[e] = w2[u * H + r];
+}
+
+// ---------------------------------------------------------------------------
+// chain kernel
+// ---------------------------------------------------------------------------
+template <typename real, int H, int KPG>
+struct ChainLds {
+  static constexpr int W1P = 4 * KPG + 4;
+  static constexpr int WP = H + WCfg<real>::WPAD;
+  static constexpr int PANEL = WCfg<real>::PU * WP;
+  static constexpr size_t bytes(bool bwd) {
+    return sizeof(real) * ((size_t)H * W1P + 3 * H + 2 * PANEL +
+                           (bwd ? (size_t)WCfg<real>::WAVES * 3 * H : 0)) + 64;
+  }
+};
+
+// nothing moves across: keeps the compiler from hoisting every LDS read of an
+// unrolled phase to its top (which spills) and the next step's reads ahead of
+// this step's MFMAs
+__device__ inline void wfence() { __builtin_amdgcn_sched_barrier(0); }
+
+// acc[jj] += panel rows (16 jj + m) . B operand tiles (H / 16 of them).  The
+// A fragments of k-block Jk + 1 are read while block Jk is multiplied.
+template <typename real, int H>
+__device__ inline void panel_mma(const real* pan, int m, int g,
+                                 const typename WV<real>::acc* bop,
+                                 typename WV<real>::acc* acc) {
+  typedef typename WV<real>::v4 v4;
+  typedef typename WV<real>::acc vacc;
+  constexpr int WP = H + WCfg<real>::WPAD;
+  constexpr int NTILE = WCfg<real>::NTILE;
+  constexpr int NJ = H / 16;
+  const real* p = pan + m * WP + 4 * g;
+  if (NTILE == 1) {
+    // one output tile: two interleaved accumulation chains over the even / odd
+    // k-blocks (a dependent MFMA needs more than its issue interval)
+    vacc alt = {0, 0, 0, 0};
+    v4 A[2][2];
+    A[0][0] = *reinterpret_cast<const v4*>(p);
+    A[0][1] = *reinterpret_cast<const v4*>(p + 16);
+#pragma unroll
+    for (int Jk = 0; Jk < NJ; Jk += 2) {
+      const int b = (Jk >> 1) & 1;
+      if (Jk + 2 < NJ) {
+        A[b ^ 1][0] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 2));
+        A[b ^ 1][1] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 3));
+      }
+      wfence();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0] = wmfma(A[b][0][i], bop[Jk][i], acc[0]);
+        alt = wmfma(A[b][1][i], bop[Jk + 1][i], alt);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[0][i] += alt[i];
+  } else {
+    v4 A[2][NTILE];
+#pragma unroll
+    for (int jj = 0; jj < NTILE; ++jj)
+      A[0][jj] = *reinterpret_cast<const v4*>(p + 16 * jj * WP);
+#pragma unroll
+    for (int Jk = 0; Jk < NJ; ++Jk) {
+      const int b = Jk & 1;
+      if (Jk + 1 < NJ) {
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj)
+          A[b ^ 1][jj] = *reinterpret_cast<const v4*>(p + 16 * jj * WP + 16 * (Jk + 1));
+      }
+      wfence();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) acc[jj] = wmfma(A[b][jj][i], bop[Jk][i], acc[jj]);
+    }
+  }
+  wfence();
+}
+
+template <typename real, int H, int KPG, int ACT, bool BWD>
+__global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<real> a) {
+  typedef typename WV<real>::v4 v4;
+  typedef typename WV<real>::v2 v2;
+  typedef typename WV<real>::acc vacc;
+  typedef WCfg<real> C;
+  typedef ChainLds<real, H, KPG> LD;
+  constexpr int NJ = H / 16, NP = H / C::PU, NTILE = C::NTILE, NT = C::NT;
+  constexpr int W1P = LD::W1P, WP = LD::WP;
+  constexpr int NSTEP = BWD ? 2 * NP : NP;                   // panels per tile
+  constexpr int CPT = C::PU * H / 4 / NT;                    // 4-element chunks per thread and panel
+  static_assert(C::PU * H % (4 * NT) == 0 && H % (4 * CPT) == 0, "panel copy");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* W1s = reinterpret_cast<real*>(smem_raw);             // [H][W1P] natural rows
+  real* Bs = W1s + H * W1P;                                  // b1 | b2 | w3, position order
+  real* pan = Bs + 3 * H;                                    // [2][PU][WP]
+  real* gacc = pan + 2 * LD::PANEL;                          // [WAVES][3][H] db1 | db2 | dw3 (positions)
+  __shared__ real sred[2 * C::WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;                    // m: A row / batch column
+  const int din = a.din;
+  const int64_t ntiles = (a.R + C::TILE - 1) / C::TILE;
+
+  // ---- resident images
+  for (int e = tid; e < H * 4 * KPG; e += NT) {
+    const int u = e / (4 * KPG), f = e - u * 4 * KPG;
+    W1s[u * W1P + f] = f < din ? a.w1[u * din + f] : real(0);
+  }
+  for (int e = tid; e < H; e += NT) {
+    const int u = unit_of_pos<real>(e);
+    Bs[e] = a.b1[u];
+    Bs[H + e] = a.b2[u];
+    Bs[2 * H + e] = a.w3[u];
+  }
+  if (BWD)
+    for (int e = tid; e < C::WAVES * 3 * H; e += NT) gacc[e] = real(0);
+
+  // ---- panel stream: step s of a tile reads W2p rows (s < NP) or W2Tp rows
+  auto panel_src = [&](int s) -> const real* {
+    return s < NP ? a.w2p + (int64_t)s * C::PU * H : a.w2tp + (int64_t)(s - NP) * C::PU * H;
+  };
+  // thread t moves the 4 CPT consecutive elements [4 CPT t, 4 CPT (t + 1)) of a
+  // panel (one LDS row piece): ONE lane address per panel, the chunks are
+  // immediate offsets of it
+  v4 stg[CPT];
+  const unsigned goff = (unsigned)tid * (4u * CPT);
+  const int soff = (int)(goff / H) * WP + (int)(goff % H);
+  auto fetch = [&](int s) {
+    // uniform (SGPR) base + 32-bit lane offset; the empty asm keeps the
+    // compiler from hoisting one 64-bit lane address per panel out of the tile
+    // loop (32 registers, which then spill)
+    const real* base = panel_src(s);
+    asm volatile("" : "+s"(base));
+    const real* src = base + goff;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) stg[q] = *reinterpret_cast<const v4*>(src + 4 * q);
+  };
+  auto stash = [&](int buf) {
+    real* dst = pan + buf * LD::PANEL + soff;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) *reinterpret_cast<v4*>(dst + 4 * q) = stg[q];
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  // the panel steps of a tile alternate between the two buffers; their number
+  // per tile is even, so step s always reads buffer s & 1 (compile-time
+  // addresses)
+  static_assert(NSTEP % 2 == 0, "panel buffers");
+
+  const real b3 = a.b3[0];
+  const real inv_n = real(1) / (real)a.R;
+  real loss_sum = 0, gb3 = 0;
+  real* my_acc = gacc + wave * 3 * H;
+
+  // x fragment: lane group g holds features KPG g + s of the lane's row (zeros
+  // past D_in); one lane address, the features are immediate offsets of it
+  auto load_x = [&](int64_t tile, real* dst) {
+    int64_t r = tile * C::TILE + wave * 16 + m;
+    if (r >= a.R) r = a.R - 1;
+    const int64_t ne = r / a.T;
+    const int t = (int)(r - ne * a.T);
+    const real* xp = a.x + ne * a.env_stride + t * a.row_stride + KPG * g;
+    const int nk = din - KPG * g;                            // features of this lane group
+#pragma unroll
+    for (int s = 0; s < KPG; ++s) dst[s] = s < nk ? xp[s] : real(0);
+  };
+  real xn[KPG];
+  load_x(blockIdx.x, xn);
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r = tile * C::TILE + wave * 16 + m;
+    const bool rok = r < a.R;
+    const bool more = tile + gridDim.x < ntiles;
+    real xb[KPG];
+#pragma unroll
+    for (int s = 0; s < KPG; ++s) xb[s] = rok ? xn[s] : real(0);
+    real rt = 0, ov = 0;
+    if (BWD) {
+      rt = a.ret[rok ? r : a.R - 1];
+      if (a.clip > real(0)) ov = a.old_v[rok ? r : a.R - 1];
+    }
+    if (more) load_x(tile + gridDim.x, xn);
+
+    // ---- layer 1: H1^T = act(W1 X^T + b1), two row blocks at a time
+    vacc h1[NJ];
+#pragma unroll
+    for (int J = 0; J < NJ; J += 2) {
+      vacc c0 = *reinterpret_cast<const v4*>(Bs + 16 * J + 4 * g);
+      vacc c1 = *reinterpret_cast<const v4*>(Bs + 16 * J + 16 + 4 * g);
+      const real* p0 = W1s + (16 * J + m) * W1P + KPG * g;
+      const real* p1 = p0 + 16 * W1P;
+#pragma unroll
+      for (int s = 0; s < KPG; s += 2) {
+        const v2 a0 = *reinterpret_cast<const v2*>(p0 + s);
+        const v2 a1 = *reinterpret_cast<const v2*>(p1 + s);
+        c0 = wmfma(a0[0], xb[s], c0);
+        c1 = wmfma(a1[0], xb[s], c1);
+        c0 = wmfma(a0[1], xb[s + 1], c0);
+        c1 = wmfma(a1[1], xb[s + 1], c1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c0[i] = wact<real, ACT>(c0[i]);
+        c1[i] = wact<real, ACT>(c1[i]);
+      }
+      h1[J] = c0;
+      h1[J + 1] = c1;
+      wfence();
+    }
+    // rows of this lane in the [R][H] workspaces (position order)
+    real* ph = a.h1s + r * H + 4 * g;
+    real* pd = a.dy2s + r * H + 4 * g;
+    real* p1s = a.dy1s + r * H + 4 * g;
+    if (BWD && rok) {
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) *reinterpret_cast<v4*>(ph + 16 * J) = h1[J];
+    }
+
+    // ---- layer 2 through the W2 panels: H2^T = act(W2 H1^T + b2).  The H2
+    // tiles are not kept: their share of v = w3 . H2 is taken at once and
+    // (backward) the tile is parked in the dY2 rows of the workspace.
+    real v = 0;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const bool last = !BWD && s == NP - 1;
+      const bool pre = !last || more;                       // another panel follows
+      if (pre) fetch(last ? 0 : s + 1);
+      vacc acc[NTILE];
+#pragma unroll
+      for (int jj = 0; jj < NTILE; ++jj)
+        acc[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + 4 * g);
+      panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc);
+#pragma unroll
+      for (int jj = 0; jj < NTILE; ++jj) {
+        const int J = s * NTILE + jj;
+        const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[jj][i] = wact<real, ACT>(acc[jj][i]);
+          v += w3v[i] * acc[jj][i];
+        }
+        if (BWD && rok) *reinterpret_cast<v4*>(pd + 16 * J) = acc[jj];
+      }
+      if (pre) stash((s & 1) ^ 1);
+      __syncthreads();
+    }
+
+    // ---- value head, loss, dL/dv
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    v += b3;
+    if (a.values && rok && g == 0) a.values[r] = v;
+
+    if (BWD) {
+      real dv;
+      {
+        const real e = v - rt;
+        real l = e * e, d = real(2) * e;
+        if (a.clip > real(0)) {
+          const real dlt = v - ov;
+          const real cl = dlt < -a.clip ? -a.clip : (dlt > a.clip ? a.clip : dlt);
+          const real e2 = ov + cl - rt;
+          if (e2 * e2 > l) {
+            l = e2 * e2;
+            d = (dlt > -a.clip && dlt < a.clip) ? real(2) * e2 : real(0);
+          }
+        }
+        if (!rok) { l = 0; d = 0; }
+        dv = d * inv_n;
+        if (g == 0) { loss_sum += l; gb3 += dv; }
+      }
+      // dY2 = dv w3 act'(H2): the parked H2 tiles come back (this lane reads
+      // what it wrote), dY2 replaces them in the workspace and stays in
+      // registers as the B operand of the backward panels; dw3, db2 = sums
+      // over the 16 batch lanes of a row
+      vacc dy2[NJ];
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const v4 z = {0, 0, 0, 0};
+        dy2[J] = rok ? *reinterpret_cast<const v4*>(pd + 16 * J) : z;
+      }
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
+        vacc t3, t2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const real hv = dy2[J][i];
+          t3[i] = dv * hv;
+          const real dy = dv * w3v[i] * wact_d<real, ACT>(hv);
+          dy2[J][i] = dy;
+          t2[i] = dy;
+        }
+        if (rok) *reinterpret_cast<v4*>(pd + 16 * J) = dy2[J];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          t3[i] = row16_sum(t3[i]);
+          t2[i] = row16_sum(t2[i]);
+        }
+        if (m == 0) {
+          real* q2 = my_acc + H + 16 * J + 4 * g;
+          real* q3 = my_acc + 2 * H + 16 * J + 4 * g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { q2[i] += t2[i]; q3[i] += t3[i]; }
+        }
+        wfence();
+      }
+      // ---- dH1^T = W2^T dY2^T through the W2^T panels; dY1 = dH1 act'(H1)
+      // (the H1 tile of the panel is read back from the workspace)
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const bool last = s == NP - 1;
+        const bool pre = !last || more;
+        if (pre) fetch(last ? 0 : NP + s + 1);
+        vacc hb[NTILE];
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) {
+          const v4 z = {0, 0, 0, 0};
+          hb[jj] = rok ? *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj)) : z;
+        }
+        vacc acc[NTILE];
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
+        panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc);
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) {
+          const int J = s * NTILE + jj;
+          vacc t1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[jj][i] *= wact_d<real, ACT>(hb[jj][i]);
+            t1[i] = row16_sum(acc[jj][i]);
+          }
+          if (rok) *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
+          if (m == 0) {
+            real* q1 = my_acc + 16 * J + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q1[i] += t1[i];
+          }
+        }
+        if (pre) stash(((NP + s) & 1) ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  if (BWD) {
+    // ---- slab: b1, b2, w3 (unit order), b3, loss
+    loss_sum = wave_sum(loss_sum);
+    gb3 = wave_sum(gb3);
+    if (lane == 0) { sred[wave] = gb3; sred[C::WAVES + wave] = loss_sum; }
+    __syncthreads();
+    real* out = a.partials + (int64_t)blockIdx.x * (a.P + 2);
+    real* ob1 = out + (int64_t)H * din;
+    real* ob2 = ob1 + H + (int64_t)H * H;
+    real* ow3 = ob2 + H;
+    for (int e = tid; e < 3 * H; e += NT) {
+      const int which = e / H, p = e - which * H;
+      real s = 0;
+#pragma unroll
+      for (int w = 0; w < C::WAVES; ++w) s += gacc[w * 3 * H + e];
+      const int u = unit_of_pos<real>(p);
+      (which == 0 ? ob1 : (which == 1 ? ob2 : ow3))[u] = s;
+    }
+    if (tid == 0) {
+      real s3 = 0, sl = 0;
+#pragma unroll
+      for (int w = 0; w < C::WAVES; ++w) { s3 += sred[w]; sl += sred[C::WAVES + w]; }
+      ow3[H] = s3;                                            // b3
+      ow3[H + 1] = sl;                                        // sum of the losses of this workgroup's rows
+      ow3[H + 2] = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gradient kernel: dW2 = dY2^T H1, dW1 = dY1^T X over a range of rows
+// ---------------------------------------------------------------------------
+template <typename real, int H>
+struct GradCfg {
+  static constexpr int NSPLIT = (sizeof(real) == 8 && H > 128) ? 2 : 1;
+  static constexpr int UR = H / NSPLIT;          // dY2 / dY1 units per workgroup
+  static constexpr int UW = UR / 8;              // per wave
+  static constexpr int NAT = UW / 16;
+  static_assert(UW % 16 == 0, "wave slice");
+};
+
+template <typename real, int H, int KPG>
+struct GradLds {
+  static constexpr int XW = KPG == 6 ? 32 : 48;  // X columns (>= D_in), multiple of 16
+  static constexpr int PX = XW == 32 ? 48 : 80;  // pitches = 16 mod 32 (conflict-free column reads)
+  static constexpr int PA = GradCfg<real, H>::UR + 16;
+  static constexpr int PB = H + 16;
+  static constexpr int ROW = 2 * PA + PB + PX;
+  static constexpr int BUF = WCfg<real>::KC * ROW;
+  static constexpr size_t bytes() { return sizeof(real) * 2 * (size_t)BUF + 64; }
+};
+
+template <typename real, int H, int KPG>
+__global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
+  typedef typename WV<real>::v4 v4;
+  typedef typename WV<real>::acc vacc;
+  typedef GradCfg<real, H> G;
+  typedef GradLds<real, H, KPG> LD;
+  constexpr int KC = WCfg<real>::KC, NJ = H / 16, NAT = G::NAT, NXT = LD::XW / 16;
+  constexpr int NT = 512;
+  constexpr int NVA = (KC * G::UR / 4 + NT - 1) / NT;        // staged 4-chunks per thread
+  constexpr int NVB = (KC * H / 4 + NT - 1) / NT;
+  constexpr int NVX = (KC * LD::XW + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* lds = reinterpret_cast<real*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int din = a.din;
+  const int ubase = blockIdx.y * G::UR;
+  // rows of this workgroup: a multiple of KC per workgroup
+  int64_t per = (a.R + gridDim.x - 1) / gridDim.x;
+  per = (per + KC - 1) / KC * KC;
+  const int64_t r_lo = blockIdx.x * per;
+  const int64_t r_hi = tmin<int64_t>(a.R, r_lo + per);
+
+  vacc acc2[NAT][NJ], acc1[NAT][NXT];
+#pragma unroll
+  for (int at = 0; at < NAT; ++at) {
+#pragma unroll
+    for (int bt = 0; bt < NJ; ++bt) acc2[at][bt] = (vacc){0, 0, 0, 0};
+#pragma unroll
+    for (int xt = 0; xt < NXT; ++xt) acc1[at][xt] = (vacc){0, 0, 0, 0};
+  }
+
+  v4 sa2[NVA], sa1[NVA], sb[NVB];
+  real sx[NVX];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int q = 0; q < NVA; ++q) {
+      const int idx = q * NT + tid;
+      const int row = idx / (G::UR / 4), c4 = idx - row * (G::UR / 4);
+      const int64_t r = r0 + row;
+      const bool ok = idx < KC * G::UR / 4 && r < r_hi;
+      const int64_t off = (ok ? r : r_lo) * H + ubase + 4 * c4;
+      const v4 z = {0, 0, 0, 0};
+      sa2[q] = ok ? *reinterpret_cast<const v4*>(a.dy2s + off) : z;
+      sa1[q] = ok ? *reinterpret_cast<const v4*>(a.dy1s + off) : z;
+    }
+#pragma unroll
+    for (int q = 0; q < NVB; ++q) {
+      const int idx = q * NT + tid;
+      const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+      const int64_t r = r0 + row;
+      const bool ok = idx < KC * H / 4 && r < r_hi;
+      const v4 z = {0, 0, 0, 0};
+      sb[q] = ok ? *reinterpret_cast<const v4*>(a.h1s + (ok ? r : r_lo) * H + 4 * c4) : z;
+    }
+#pragma unroll
+    for (int q = 0; q < NVX; ++q) {
+      const int idx = q * NT + tid;
+      const int row = idx / LD::XW, f = idx - row * LD::XW;
+      const int64_t r = r0 + row;
+      real val = 0;
+      if (idx < KC * LD::XW && r < r_hi && f < din) {
+        const int64_t ne = r / a.T;
+        const int t = (int)(r - ne * a.T);
+        val = a.x[ne * a.env_stride + t * a.row_stride + f];
+      }
+      sx[q] = val;
+    }
+  };
+  auto stash = [&](int buf) {
+    real* A2 = lds + buf * LD::BUF;
+    real* A1 = A2 + KC * LD::PA;
+    real* B2 = A1 + KC * LD::PA;
+    real* BX = B2 + KC * LD::PB;
+#pragma unroll
+    for (int q = 0; q < NVA; ++q) {
+      const int idx = q * NT + tid;
+      if (idx < KC * G::UR / 4) {
+        const int row = idx / (G::UR / 4), c4 = idx - row * (G::UR / 4);
+        *reinterpret_cast<v4*>(A2 + row * LD::PA + 4 * c4) = sa2[q];
+        *reinterpret_cast<v4*>(A1 + row * LD::PA + 4 * c4) = sa1[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NVB; ++q) {
+      const int idx = q * NT + tid;
+      if (idx < KC * H / 4) {
+        const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+        *reinterpret_cast<v4*>(B2 + row * LD::PB + 4 * c4) = sb[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NVX; ++q) {
+      const int idx = q * NT + tid;
+      if (idx < KC * LD::XW) {
+        const int row = idx / LD::XW, f = idx - row * LD::XW;
+        BX[row * LD::PX + f] = sx[q];
+      }
+    }
+  };
+
+  int cur = 0;
+  if (r_lo < r_hi) {
+    fetch(r_lo);
+    stash(0);
+  }
+  __syncthreads();
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += KC) {
+    const bool more = r0 + KC < r_hi;
+    if (more) fetch(r0 + KC);
+    const real* A2 = lds + cur * LD::BUF;
+    const real* A1 = A2 + KC * LD::PA;
+    const real* B2 = A1 + KC * LD::PA;
+    const real* BX = B2 + KC * LD::PB;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int row = 4 * ks + g;
+      real a2[NAT], a1[NAT];
+#pragma unroll
+      for (int at = 0; at < NAT; ++at) {
+        a2[at] = A2[row * LD::PA + wave * G::UW + 16 * at + m];
+        a1[at] = A1[row * LD::PA + wave * G::UW + 16 * at + m];
+      }
+#pragma unroll
+      for (int bt = 0; bt < NJ; ++bt) {
+        const real b = B2[row * LD::PB + 16 * bt + m];
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) acc2[at][bt] = wmfma(a2[at], b, acc2[at][bt]);
+      }
+#pragma unroll
+      for (int xt = 0; xt < NXT; ++xt) {
+        const real b = BX[row * LD::PX + 16 * xt + m];
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) acc1[at][xt] = wmfma(a1[at], b, acc1[at][xt]);
+      }
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- slab sections W1 and W2 (unit order) of this workgroup's units
+  real* out = a.partials + (int64_t)blockIdx.x * (a.P + 2);
+  real* oW1 = out;
+  real* oW2 = out + (int64_t)H * din + H;
+#pragma unroll
+  for (int at = 0; at < NAT; ++at)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pa = ubase + wave * G::UW + 16 * at + drow<real>(g, i);
+      const int ua = unit_of_pos<real>(pa);
+#pragma unroll
+      for (int bt = 0; bt < NJ; ++bt)
+        oW2[(int64_t)ua * H + unit_of_pos<real>(16 * bt + m)] = acc2[at][bt][i];
+#pragma unroll
+      for (int xt = 0; xt < NXT; ++xt) {
+        const int f = 16 * xt + m;
+        if (f < din) oW1[(int64_t)ua * din + f] = acc1[at][xt][i];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// slab reduction (+ Adam), the arithmetic of mlp_finish_kernel for either type
+// ---------------------------------------------------------------------------
+template <typename real>
+struct WAdam {
+  real *param, *m, *v, *state;
+  real lr, b1, b2, eps, wd, step;
+};
+
+constexpr int WFIN_GROUPS = 16;
+
+template <typename real>
+__global__ __launch_bounds__(64 * WFIN_GROUPS) void mlpw_finish_kernel(
+    const real* __restrict__ partials, int nparts, int P, int64_t R, real* __restrict__ grad,
+    real* __restrict__ stats, WAdam<real> ad) {
+  __shared__ real part[WFIN_GROUPS][64];
+  __shared__ real red[WFIN_GROUPS];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + col;
+  real s = 0;
+  if (p < P + 1) {
+    const real* src = partials + p;
+#pragma unroll 4
+    for (int i = grp; i < nparts; i += WFIN_GROUPS) s += src[(int64_t)i * (P + 2)];
+  }
+  part[grp][col] = s;
+  __syncthreads();
+  real sq = 0;
+  if (grp == 0 && p < P + 1) {
+    real g0 = 0;
+#pragma unroll
+    for (int k = 0; k < WFIN_GROUPS; ++k) g0 += part[k][col];
+    if (p < P) {
+      grad[p] = g0;
+      sq = g0 * g0;
+      if (ad.param) {
+        const real w = ad.param[p];
+        const real gg = ad.wd != real(0) ? g0 + ad.wd * w : g0;
+        const real mi = ad.b1 * ad.m[p] + (real(1) - ad.b1) * gg;
+        const real vi = ad.b2 * ad.v[p] + (real(1) - ad.b2) * gg * gg;
+        ad.m[p] = mi;
+        ad.v[p] = vi;
+        const real bc1 = real(1) - pow(ad.b1, ad.step);
+        const real bc2s = sqrt(real(1) - pow(ad.b2, ad.step));
+        ad.param[p] = w - (ad.lr / bc1) * mi / (sqrt(vi) / bc2s + ad.eps);
+      }
+    } else {
+      stats[0] = g0 / (real)R;
+    }
+  }
+  const real tot = block_sum(sq, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[1], tot);
+    if (ad.param && blockIdx.x == 0) ad.state[0] = ad.step;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+inline int mlpw_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename real, int H, int KPG, int ACT>
+int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int max_wg,
+                    const real* w2, WAdam<real> ad, hipStream_t st) {
+  typedef WCfg<real> C;
+  const bool bwd = a.partials != nullptr;
+  const int64_t ntiles = (a.R + C::TILE - 1) / C::TILE;
+  int grid = mlpw_cu_count();
+  if (max_wg > 0 && max_wg < grid) grid = max_wg;
+  if (ntiles < grid) grid = (int)ntiles;
+  // workspace: w2p | w2tp | h1s | dy2s | dy1s
+  real* w2p = workspace;
+  real* w2tp = w2p + (int64_t)H * H;
+  a.w2p = w2p;
+  a.w2tp = w2tp;
+  a.h1s = w2tp + (int64_t)H * H;
+  a.dy2s = a.h1s + a.R * H;
+  a.dy1s = a.dy2s + a.R * H;
+  hipLaunchKernelGGL(mlpw_prep_kernel<real>, dim3((H * H + 255) / 256), dim3(256), 0, st, w2,
+                     H, w2p, w2tp);
+  TCE_LAUNCH_CHECK();
+  const size_t lds = ChainLds<real, H, KPG>::bytes(bwd);
+  if (bwd) {
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int glds0 = (int)GradLds<real, H, KPG>::bytes();
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpw_grad_kernel<real, H, KPG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, glds0);
+      set = true;
+    }
+    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, true>), dim3(grid), dim3(C::NT), lds,
+                       st, a);
+    TCE_LAUNCH_CHECK();
+    const dim3 ggrid(grid, GradCfg<real, H>::NSPLIT);
+    const size_t glds = GradLds<real, H, KPG>::bytes();
+    hipLaunchKernelGGL((mlpw_grad_kernel<real, H, KPG>), ggrid, dim3(512), glds, st, a);
+    TCE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlpw_finish_kernel<real>, dim3((a.P + 1 + 63) / 64),
+                       dim3(64 * WFIN_GROUPS), 0, st, a.partials, grid, a.P, a.R, grad, stats,
+                       ad);
+    TCE_LAUNCH_CHECK();
+  } else {
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, false>), dim3(grid), dim3(C::NT), lds,
+                       st, a);
+    TCE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <typename real, int H, int KPG>
+int mlpw_launch(WArgs<real> a, real* workspace, real* grad, real* stats, int max_wg,
+                const real* w2, WAdam<real> ad, hipStream_t st) {
+  switch (a.act) {
+#ifndef MLPW_ONLY_RELU
+    case W_TANH:
+      return mlpw_launch_act<real, H, KPG, W_TANH>(a, workspace, grad, stats, max_wg, w2, ad, st);
+    case W_LEAKY:
+      return mlpw_launch_act<real, H, KPG, W_LEAKY>(a, workspace, grad, stats, max_wg, w2, ad, st);
+    case W_SOFTPLUS:
+      return mlpw_launch_act<real, H, KPG, W_SOFTPLUS>(a, workspace, grad, stats, max_wg, w2, ad,
+                                                       st);
+#endif
+    case W_RELU:
+      return mlpw_launch_act<real, H, KPG, W_RELU>(a, workspace, grad, stats, max_wg, w2, ad, st);
+  }
+  tce_set_error("mlpw_critic: activation not built");
+  return 1;
+}
+
+}  // namespace

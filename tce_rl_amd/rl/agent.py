@@ -211,15 +211,17 @@ class _CriticEpochs:
         opt = self.opt = agent.critic_optimizer
         run = getattr(agent, "_critic_runner", None)
         arith = getattr(agent, "critic_arith", "f32")
+        if critic_ops.wide_supported(agent.critic.net):
+            arith = "f32"            # exact matrix cores of the net's own dtype
         if run is None or run.mlp is not agent.critic.net or \
                 run.flat is not opt.flat_grad or run.arith != arith:
-            run = agent._critic_runner = critic_ops.EpochRunner(
+            run = agent._critic_runner = critic_ops.make_runner(
                 agent.critic.net, opt.flat_grad, arith=arith)
         self.runner = run
         opt.bind_grads()
         self.E = agent.epochs_critic
         # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
-        self.rows = torch.zeros(self.E, 4, dtype=torch.float32,
+        self.rows = torch.zeros(self.E, 4, dtype=agent.critic.net.dtype,
                                 device=agent.device)
         self.fuse_adam = not agent.dist.active and \
             not agent.clip_grad_norm > 0
