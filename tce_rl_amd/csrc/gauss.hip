@@ -178,7 +178,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_part_kernel(
     const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gL, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* A = reinterpret_cast<double*>(smem_raw);
-  const int KP = K + 1;
+  const int KP = sm_pitch(K);
   double* Los = A + K * KP;
   __shared__ double red[4];
   const int64_t b = blockIdx.x;
@@ -213,7 +213,16 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_part_kernel(
 // KL covariance projection.  ctx (double) per matrix: [Vt K*K | lam K | eta,
 // active, alpha, pad].
 // ---------------------------------------------------------------------------
+#ifdef KLP_STAMP
+// diagnostic build (scripts/klproj_stamps.py): cycle stamps per section behind the ctx
+__host__ __device__ inline int64_t klp_ctx_len(int K) { return (int64_t)K * K + K + 4 + 16; }
+#define KLP_T(k) { __syncthreads(); if (threadIdx.x == 0) { const long long tn_ = __builtin_readcyclecounter(); stamp_[k] = (double)(tn_ - t0_); t0_ = tn_; } }
+#define KLP_T0() long long t0_ = __builtin_readcyclecounter(); double* stamp_ = cb + (int64_t)K * K + K + 4;
+#else
 __host__ __device__ inline int64_t klp_ctx_len(int K) { return (int64_t)K * K + K + 4; }
+#define KLP_T(k)
+#define KLP_T0()
+#endif
 
 // h(eta) = 1/2 sum (mu - 1 - log mu), mu = (eta+1) lam / (eta lam + 1); one wave.
 __device__ inline double klp_h(double eta, double lam, bool live) {
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     const real* __restrict__ beta, int entropy_eq, real* __restrict__ projL,
     double* __restrict__ ctx, int K, int warm_start) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int KP = K + 1;
+  const int KP = sm_pitch(K);
   double* A = reinterpret_cast<double*>(smem_raw);   // A -> rotated -> Y
   double* Vt = A + K * KP;
   double* Los = Vt + K * KP;                          // Lo -> S -> Lp
@@ -244,9 +253,12 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
   const real* Lb = L + b * (int64_t)K * K;
   double* cb = ctx + b * klp_ctx_len(K);
 
+  KLP_T0()
   sm_load(A, Lb, K, KP, true);
   sm_load(Los, Lo + b * sLo, K, KP, true);
+  KLP_T(0)
   sm_trsm_l(A, Los, K, KP);                           // A = Lo^-1 L (lower)
+  KLP_T(1)
   double loc = 0;
   for (int e = threadIdx.x; e < K * K; e += SM_BT) {
     const int i = e / K, j = e - i * K;
@@ -261,7 +273,9 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     // warm start: ctx still holds the eigenvectors of the previous call (its
     // "active" slot says whether it wrote any)
     const bool warm = warm_start && cb[(int64_t)K * K + K + 1] == 1.0;
+    KLP_T(2)
     sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP, warm ? cb : nullptr, Tmp);
+    KLP_T(3)
     if (threadIdx.x < 64) {
       const bool live = threadIdx.x < K;
       const double lm = live ? lam[threadIdx.x] : 1.0;
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     }
     __syncthreads();
     eta = s_eta;
+    KLP_T(4)
     // ctx: Vt, lam
     for (int e = threadIdx.x; e < K * K; e += SM_BT) cb[e] = Vt[(e / K) * KP + (e % K)];
     if (threadIdx.x < K) cb[(int64_t)K * K + threadIdx.x] = lam[threadIdx.x];
@@ -302,8 +317,11 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
       A[r * KP + k] = acc * sqrt(mu);
     }
     __syncthreads();
+    KLP_T(5)
     sm_mm_nt(Los, A, A, K, KP);                       // S = Y Y^T
+    KLP_T(6)
     sm_cholesky(Los, K, KP);                          // Lp
+    KLP_T(7)
   } else {
     sm_load(Los, Lb, K, KP, true);                    // Lp = L
   }
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     if (entropy_eq || H < bt) alpha = exp((bt - H) / (double)K);
   }
   sm_store(projL + b * (int64_t)K * K, Los, K, KP, true, alpha);
+  KLP_T(8)
   if (threadIdx.x == 0) {
     double* tail = cb + (int64_t)K * K + K;
     tail[0] = eta;
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_bwd_kernel(
     const real* __restrict__ projL, const double* __restrict__ ctx,
     const real* __restrict__ gproj, real* __restrict__ gL, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int KP = K + 1;
+  const int KP = sm_pitch(K);
   double* M0 = reinterpret_cast<double*>(smem_raw);
   double* M1 = M0 + K * KP;
   double* M2 = M1 + K * KP;
@@ -531,7 +550,7 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
                             void* stream) {                                       \
     TCE_CHECK_ARG(L && L_old && B > 0 && K > 0 && K <= 64,                        \
                   "kl_cov_part: bad arguments (K <= 64)");                        \
-    const size_t lds = 2 * (size_t)K * (K + 1) * sizeof(double);                  \
+    const size_t lds = 2 * (size_t)K * sm_pitch(K) * sizeof(double);                  \
     if (bwd) {                                                                    \
       TCE_CHECK_ARG(grad_out && grad_L, "kl_cov_part: null gradient buffers");    \
       set_lds(kl_cov_part_kernel<REAL, true>, lds);                               \
@@ -555,7 +574,7 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
                                 void* stream) {                                   \
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && B > 0 && K > 0 && K <= 64,       \
                   "kl_cov_proj: bad arguments (K <= 64)");                        \
-    const size_t lds = 4 * (size_t)K * (K + 1) * sizeof(double);                  \
+    const size_t lds = 4 * (size_t)K * sm_pitch(K) * sizeof(double);                  \
     set_lds(kl_cov_proj_fwd_kernel<REAL>, lds);                                   \
     hipLaunchKernelGGL(kl_cov_proj_fwd_kernel<REAL>, dim3((unsigned)B),           \
                        dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,           \
@@ -571,7 +590,7 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && grad_proj && grad_L && B > 0 &&  \
                       K > 0 && K <= 64,                                           \
                   "kl_cov_proj_bwd: bad arguments (K <= 64)");                    \
-    const size_t lds = 4 * (size_t)K * (K + 1) * sizeof(double);                  \
+    const size_t lds = 4 * (size_t)K * sm_pitch(K) * sizeof(double);                  \
     set_lds(kl_cov_proj_bwd_kernel<REAL>, lds);                                   \
     hipLaunchKernelGGL(kl_cov_proj_bwd_kernel<REAL>, dim3((unsigned)B),           \
                        dim3(SM_BT), lds, (hipStream_t)stream, L, L_old,           \

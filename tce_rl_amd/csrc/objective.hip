@@ -73,7 +73,7 @@ __global__ __launch_bounds__(KE_BT) void kl_shared_env_kernel(
     real* __restrict__ gmean, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Los = reinterpret_cast<real*>(smem_raw);     // [K][KP]
-  const int KP = K + 1;
+  const int KP = sm_pitch(K);
   real* Lps = Los + K * KP;
   real* vs = Lps + K * KP;                            // [KE_BT][KP]
   __shared__ double red[4];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
     int64_t N, int K, real coeff, int include_cov, const double* __restrict__ partials,
     int nparts, real* __restrict__ out, real* __restrict__ gL, int par) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int KP = K + 1;
+  const int KP = sm_pitch(K);
   double* A = reinterpret_cast<double*>(smem_raw);   // Ln
   double* B = A + K * KP;                             // Lo
   double* C = B + K * KP;                             // Lp
@@ -154,40 +154,23 @@ __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
     f = sm_block_sum(lf, red);
     ld = sm_block_sum(ll, red);
   };
-  // X = Lq^-1 Ls by forward substitution, thread `col` per column
-  auto solve_cols = [&](double* Xw, const double* Lq, const double* Ls, int col) {
-    for (int r = 0; r < K; ++r) {
-      double v = Ls[r * KP + col];
-      for (int k = 0; k < r; ++k) v -= Lq[r * KP + k] * Xw[k * KP + col];
-      Xw[r * KP + col] = v / Lq[r * KP + r];
+  // X = Lq^-1 Ls (quad-parallel forward substitution, smallmat.h)
+  auto solve = [&](double* Xw, const double* Lq, const double* Ls) {
+    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+      const int i = e / K, j = e - i * K;
+      Xw[i * KP + j] = Ls[i * KP + j];
     }
+    __syncthreads();
+    sm_trsm_l(Xw, Lq, K, KP);
   };
   double f1, l1, f2, l2, f3, l3;
-  const int w = threadIdx.x >> 6, col = threadIdx.x & 63;
-  if (par) {
-    // the three solves on three waves: X0 = Lo^-1 Ln, X (kept) = Lp^-1 Ln, X2 = Lo^-1 Lp
-    double* X0 = X + K * KP;
-    double* X2 = X0 + K * KP;
-    if (col < K) {
-      if (w == 0) solve_cols(X0, B, A, col);
-      else if (w == 1) solve_cols(X, C, A, col);
-      else if (w == 2) solve_cols(X2, B, C, col);
-    }
-    __syncthreads();
-    frob_ld(X0, f1, l1);                                // new || old
-    frob_ld(X2, f3, l3);                                // proj || old
-    frob_ld(X, f2, l2);                                 // new || proj
-  } else {
-    if (w == 0 && col < K) solve_cols(X, B, A, col);
-    __syncthreads();
-    frob_ld(X, f1, l1);
-    if (w == 0 && col < K) solve_cols(X, B, C, col);
-    __syncthreads();
-    frob_ld(X, f3, l3);
-    if (w == 0 && col < K) solve_cols(X, C, A, col);
-    __syncthreads();
-    frob_ld(X, f2, l2);                                 // X = Lp^-1 Ln stays
-  }
+  (void)par;
+  solve(X, B, A);                                       // new || old
+  frob_ld(X, f1, l1);
+  solve(X, B, C);                                       // proj || old
+  frob_ld(X, f3, l3);
+  solve(X, C, A);                                       // new || proj; X = Lp^-1 Ln stays
+  frob_ld(X, f2, l2);
   if (gL) {
     sm_trsm_lt(X, C, K, KP);                          // Sigma_proj^-1 Ln
     for (int e = threadIdx.x; e < K * K; e += SM_BT) {
@@ -241,15 +224,15 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
   TCE_CHECK_ARG(mn && mo && mp && Ln && Lo && Lp && out && ws && N > 0 && K > 0 && K <= 64,
                 "kl_shared: bad arguments (K <= 64)");
   const int nblk = (int)ceil_div(N, KE_BT);
-  const size_t lds_e = ((size_t)2 * K * (K + 1) + (size_t)KE_BT * (K + 1)) * sizeof(real);
+  const size_t lds_e = ((size_t)2 * K * sm_pitch(K) + (size_t)KE_BT * sm_pitch(K)) * sizeof(real);
   if (lds_e > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_env_kernel<real>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e);
   hipLaunchKernelGGL(kl_shared_env_kernel<real>, dim3(nblk), dim3(KE_BT), lds_e, st, mn, mo, mp,
                      Lo, Lp, N, K, coeff / (real)N, gmean, ws);
   TCE_LAUNCH_CHECK();
-  const int par = (size_t)6 * K * (K + 1) * sizeof(double) <= 150 * 1024;   // K <= 55
-  const size_t lds_m = (size_t)(par ? 6 : 4) * K * (K + 1) * sizeof(double);
+  const int par = (size_t)6 * K * sm_pitch(K) * sizeof(double) <= 150 * 1024;   // K <= 55
+  const size_t lds_m = (size_t)(par ? 6 : 4) * K * sm_pitch(K) * sizeof(double);
   if (lds_m > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_mat_kernel<real>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);

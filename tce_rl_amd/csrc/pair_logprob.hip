@@ -23,6 +23,9 @@ namespace {
 constexpr int PL_BT = 256;
 constexpr int PL_MAXR = 16;   // 2 * dof <= 16
 
+// odd row pitch: K + 1 is even for odd K (K = 63 -> 64: a whole column in one bank)
+__host__ __device__ inline int pl_pitch(int K) { return (K + 1) | 1; }
+
 struct PLShape {
   int K, R, P, PC, nbg, dof;
 };
@@ -30,8 +33,8 @@ struct PLShape {
 // LDS carve (in reals): Ls[K][K+1] | ms[K] | Hs[P][2][nbg] | cs[P][2][2] |
 // Ms[PC][R][K+1] | Cs[PC][R][R+1] | dv[PC][R] | Li[PC][R][R+1] | al[PC][R] | gs[PC]
 __host__ __device__ inline size_t pl_lds_reals(const PLShape& s, bool bwd) {
-  size_t n = (size_t)s.K * (s.K + 1) + s.K + (size_t)s.P * 2 * s.nbg + (size_t)s.P * 4;
-  n += (size_t)s.PC * s.R * (s.K + 1) + (size_t)s.PC * s.R * (s.R + 1) + (size_t)s.PC * s.R;
+  size_t n = (size_t)s.K * pl_pitch(s.K) + s.K + (size_t)s.P * 2 * s.nbg + (size_t)s.P * 4;
+  n += (size_t)s.PC * s.R * pl_pitch(s.K) + (size_t)s.PC * s.R * (s.R + 1) + (size_t)s.PC * s.R;
   if (bwd) n += (size_t)s.PC * s.R * (s.R + 1) + (size_t)s.PC * s.R + s.PC;
   return n;
 }
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int K = s.K, R = s.R, P = s.P, PC = s.PC, nbg = s.nbg, dof = s.dof;
-  const int KP = K + 1, RP = R + 1;
+  const int KP = pl_pitch(K), RP = R + 1;
   real* Ls = smem;
   real* ms = Ls + K * KP;
   real* Hs = ms + K;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int K = s.K, R = s.R, P = s.P, nbg = s.nbg, dof = s.dof;
-  const int KP = K + 1, RP = R + 1;
+  const int KP = pl_pitch(K), RP = R + 1;
   const int wsp = pf_ws_pair(s);
   real* Ws = smem;                               // [P][2 nbg + 4 + R*R + 1] compact
   const int cw = 2 * nbg + 4 + R * R + 1;
@@ -593,7 +596,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   // envs per block of the fast path: as many as the LDS budget allows
   const int cw = 2 * nbg + 4 + f.R * f.R + 1;
   auto env_lds = [&](int eb) {
-    return ((size_t)P * cw + (size_t)eb * (K + 1) * (bwd ? 5 : 1) +
+    return ((size_t)P * cw + (size_t)eb * pl_pitch(K) * (bwd ? 5 : 1) +
             (bwd ? 4 * ((size_t)eb * (f.R + 1) + eb) : 0)) * sizeof(real);
   };
   // up to 64 envs (one lane each) per block of 4 waves; fewer when the four

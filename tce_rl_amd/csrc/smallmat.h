@@ -1,10 +1,15 @@
 // K x K (K <= 64) dense helpers on LDS-resident double matrices, executed by
-// one 256-thread workgroup.  Row pitch KP = K + 1 (bank-conflict free column
-// walks).  Every helper ends with a barrier unless noted.
+// one 256-thread workgroup.  Row pitch KP = sm_pitch(K): the next ODD number
+// above K, so that column walks (stride KP doubles) touch all 32 eight-byte
+// bank pairs -- K + 1 is even for odd K, and K = 63 (7 dof x 9) made it 64: every
+// element of a column in ONE bank (measured: 5 100 cycles per Jacobi round
+// instead of 900).  Every helper ends with a barrier unless noted.
 #pragma once
 #include "common.h"
 
 #define SM_BT 256
+
+__host__ __device__ inline int sm_pitch(int K) { return (K + 1) | 1; }
 
 // C[i][j] = sum_k A[i][k] * B[j][k]        (C = A B^T)
 __device__ inline void sm_mm_nt(double* C, const double* A, const double* B, int K, int KP) {
@@ -112,6 +117,25 @@ __device__ inline void sm_store(real* __restrict__ dst, const double* D, int K, 
   __syncthreads();
 }
 
+// 1 / x and 1 / sqrt(x) from the hardware estimates (2^-23 relative) and two
+// Newton steps each: ~1e-16 relative in ~8 dependent FMAs instead of the ~30
+// instruction IEEE sequences.  Used where the result only has to be accurate,
+// not correctly rounded (Jacobi rotations: c^2 + s^2 = 1 to rounding is what
+// keeps the eigenvectors orthogonal).
+__device__ inline double sm_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ inline double sm_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  return y;
+}
+
 // Block-wide sum of a double (all threads get it); scratch >= 4 doubles.
 __device__ inline double sm_block_sum(double v, double* scratch) { return block_sum(v, scratch); }
 
@@ -177,10 +201,13 @@ __device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* f
       ga = dpp_sum8(ga);
       // relative off-diagonal tolerance: eigenvalues to ~1e-13 relative (the
       // bound is 5e-4 .. 5e-2; a tighter test only chases rounding noise)
-      if (p >= 0 && fabs(ga) > 1e-13 * sqrt(al * be) && ga != 0.0) {
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+      if (p >= 0 && ga * ga > 1e-26 * (al * be) && ga != 0.0) {
+        // the rotation sits on the critical path of every round (K - 1 rounds
+        // per sweep, one barrier each): Newton-refined hardware reciprocals
+        const double zeta = (be - al) * sm_rcp(2.0 * ga);
+        const double w = fma(zeta, zeta, 1.0);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) * sm_rcp(fabs(zeta) + w * sm_rsq(w));
+        const double c = sm_rsq(fma(t, t, 1.0)), s = c * t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = l8 + 8 * i;
