@@ -28,6 +28,7 @@ NUM_ENV, NUM_BASIS, EPOCHS = 4096, 5, 50
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix (dense, = vector peak)
 F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 matrix, dense (no sparsity)
+F64_MFMA_PEAK_TF = 78.6        # FP64 matrix = FP64 vector rate (v_mfma_f64_16x16x4_f64: 64 cycles per SIMD)
 
 
 def build_agent(num_env, seed):
@@ -82,9 +83,9 @@ def kernel_time_cold_us(fn, launches=5):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r01e_pmc.json, else r01c: rocprofv3 --pmc FETCH_SIZE /
+    (profiles/r02_pmc.json, else r01e / r01c: rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, FETCH x2 correction); None if absent."""
-    for tag in ("r01e", "r01c"):
+    for tag in ("r02", "r01e", "r01c"):
         try:
             with open(os.path.join(REPO, "profiles", tag + "_pmc.json")) as f:
                 return json.load(f)["kernels"][kernel]["traffic_bytes"]
@@ -93,14 +94,50 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline(agent):
+def profiled_us(kernel_substr):
+    """Average duration (us) of a kernel in the committed rocprofv3
+    --kernel-trace --stats summary of this same command
+    (profiles/r02_bench_kernel_stats.csv); None if absent."""
+    import csv
+    try:
+        with open(os.path.join(REPO, "profiles",
+                               "r02_bench_kernel_stats.csv")) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row["Name"]:
+                    return round(float(row["AverageNs"]) / 1e3, 1)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def hbm_entry(name, alg, us, us_cold=None, note=None, traffic=None):
+    d = {"kernel": name, "bound": "hbm", "achieved": round(alg / us / 1e3, 1),
+         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "us_per_launch": round(us, 2), "algorithmic_bytes": alg}
+    if us_cold is not None:
+        d["cold"] = {"us_per_launch": round(us_cold, 2),
+                     "achieved": round(alg / us_cold / 1e3, 1),
+                     "frac": round(alg / us_cold / 1e3 / HBM_PEAK_GBS, 4)}
+    if note:
+        d["note"] = note
+    return d
+
+
+def roofline(agent, critic_ms_in_step):
     """Rooflines measured live with HIP events on the launch stream.
 
-    dominant kernel = mlp_critic_bwd_kernel (the 50 critic epochs are ~90 % of
-    the device time of a step): MFMA-bound, algorithmic flops per launch =
-    6 * (D_in*H + H*H + H) per row (forward 2x, backward 4x) * N*T rows
-    against the dense FP32 matrix peak.  GAE scan and trajectory generator:
-    HBM-bound, algorithmic bytes per SURVEY 8(d)."""
+    dominant kernel = mlp_critic_bwd_kernel (+ mlp_finish_kernel: the 50 critic
+    epochs are ~90 % of the device time of a step): MFMA-bound, algorithmic
+    flops per launch = 6 * (D_in*H + H*H + H) per row (forward 2x, backward
+    4x) * N*T rows against the dense FP32 matrix peak.  `achieved` uses the
+    average launch duration INSIDE the timed steps (HIP events on the critic's
+    stream around its 50 epochs, policy stream running beside it -- what
+    rocprofv3 sees for the same command); the isolated back-to-back figure is
+    reported beside it.  GAE scan, trajectory generator and env rollout:
+    HBM-bound, algorithmic bytes per SURVEY 8(d), at the C2 working set (which
+    stays in the 256 MB Infinity Cache between launches) AND at 8x the envs
+    (295 / 529 MB per launch: past the cache)."""
     from tce_rl_amd import ops, critic_ops
     N, T = NUM_ENV, agent.sampler.num_times
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -117,13 +154,23 @@ def roofline(agent):
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
+    us_step = critic_ms_in_step * 1e3 / EPOCHS
     critic = {"kernel": "mlp_critic_bwd_kernel<relu,10> (+ mlp_finish_kernel)",
-              "bound": "mfma", "achieved": round(flops / us_c / 1e6, 2),
+              "bound": "mfma", "achieved": round(flops / us_step / 1e6, 2),
               "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-              "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4),
+              "frac": round(flops / us_step / 1e6 / F32_MFMA_PEAK_TF, 4),
               "traffic": pmc_traffic("mlp_critic_bwd_kernel"),
-              "us_per_launch": round(us_c, 1),
-              "algorithmic_flops": flops, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+              "us_per_launch": round(us_step, 1),
+              "measured": "HIP events on the critic stream around the 50 "
+                          "epochs of every timed step (launch + slab "
+                          "reduction / Adam), policy epochs on a second stream",
+              "isolated_back_to_back": {
+                  "us_per_launch": round(us_c, 1),
+                  "achieved": round(flops / us_c / 1e6, 2),
+                  "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4)},
+              "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel"),
+              "algorithmic_flops": flops,
+              "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     critic16 = {
         "kernel": "mlp_critic_bwd16_kernel<relu,2> (+ mlp_finish_kernel)",
         "bound": "mfma", "achieved": round(flops / us_c16 / 1e6, 2),
@@ -137,60 +184,118 @@ def roofline(agent):
         "dtype": "f16x2 split operands, fp32 accumulate "
                  "(v_mfma_f32_16x16x32_f16; 3 MFMAs per product)"}
     del full, xs
-    r = torch.randn(N, T, device="cuda", generator=g)
-    v = torch.randn(N, T + 1, device="cuda", generator=g)
-    d = torch.zeros(N, T, dtype=torch.bool, device="cuda")
-    d[:, -1] = True
-    tl = torch.zeros_like(d)
-    us = kernel_time_us(lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True))
-    us_cold = kernel_time_cold_us(lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True))
-    alg = N * T * 18 + N * 4
-    gae = {"kernel": "gae_dpp_kernel<float,true,true,8>", "bound": "hbm",
-           "achieved": round(alg / us / 1e3, 1), "peak": HBM_PEAK_GBS,
-           "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
-           "traffic": pmc_traffic("gae_dpp_kernel"),
-           "us_per_launch": round(us, 2), "algorithmic_bytes": alg,
-           "cold": {"us_per_launch": round(us_cold, 2),
-                    "achieved": round(alg / us_cold / 1e3, 1),
-                    "frac": round(alg / us_cold / 1e3 / HBM_PEAK_GBS, 4),
-                    "note": "inputs evicted by a 1 GiB fill before the launch; "
-                            "the back-to-back figure above re-reads its 37 MB "
-                            "from the 256 MB Infinity Cache, as the step does "
-                            "(values and rewards were just produced)"}}
+    extra = {"critic_split_f16": critic16}
+
+    def gae_case(n):
+        r = torch.randn(n, T, device="cuda", generator=g)
+        v = torch.randn(n, T + 1, device="cuda", generator=g)
+        d = torch.zeros(n, T, dtype=torch.bool, device="cuda")
+        d[:, -1] = True
+        tl = torch.zeros_like(d)
+        f = lambda: ops.gae(r, v, d, tl, 1.0, 0.95, True)
+        return n * T * 18 + n * 4, kernel_time_us(f), kernel_time_cold_us(f)
+    alg, us, us_cold = gae_case(N)
+    extra["gae_scan"] = hbm_entry(
+        "gae_dpp_kernel<float,true,true,8>", alg, us, us_cold,
+        "C2 size: the 37 MB working set stays in the 256 MB Infinity Cache "
+        "between back-to-back launches (as in the step, where values and "
+        "rewards were just produced); `cold` = after a 1 GiB fill",
+        pmc_traffic("gae_dpp_kernel"))
+    alg, us, us_cold = gae_case(8 * N)
+    extra["gae_scan_32768_envs"] = hbm_entry(
+        "gae_dpp_kernel<float,true,true,8>", alg, us, us_cold,
+        "295 MB per launch: past the Infinity Cache")
+
     # trajectory generator (write-bound): T*2*dof*4 B written per env
+    def traj_case(mp, n, t_len):
+        K = mp.num_dof * mp.num_basis_g
+        t0 = torch.zeros(n, device="cuda")
+        times = ops.times(t0, mp.dt, t_len)
+        w = 0.1 * torch.randn(n, K, device="cuda", generator=g)
+        y0 = torch.rand(n, mp.num_dof, device="cuda", generator=g)
+        v0 = torch.zeros(n, mp.num_dof, device="cuda")
+        f = lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0)
+        alg = n * (t_len * 2 * mp.num_dof * 4 + 4 * (K + 2 * mp.num_dof + 1))
+        return alg, kernel_time_us(f), kernel_time_cold_us(f)
     mp = agent.policy.mp
-    K = mp.num_dof * mp.num_basis_g
-    t0 = torch.zeros(N, device="cuda")
-    times = ops.times(t0, mp.dt, T)
-    w = 0.1 * torch.randn(N, K, device="cuda", generator=g)
-    y0 = torch.rand(N, mp.num_dof, device="cuda", generator=g)
-    v0 = torch.zeros(N, mp.num_dof, device="cuda")
-    us2 = kernel_time_us(lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0))
-    us2_cold = kernel_time_cold_us(
-        lambda: ops.prodmp_traj(mp, times, w, t0, y0, v0))
-    alg2 = N * (T * 2 * mp.num_dof * 4 + 4 * (K + 2 * mp.num_dof + 1))
-    extra = {"prodmp_traj": {
-        "bound": "hbm", "achieved": round(alg2 / us2 / 1e3, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(alg2 / us2 / 1e3 / HBM_PEAK_GBS, 4),
-        "traffic": pmc_traffic("prodmp_traj_kernel"),
-        "us_per_launch": round(us2, 2), "algorithmic_bytes": alg2,
-        "cold_us_per_launch": round(us2_cold, 2),
-        "note": "trajectory kernel; the [T, 4+2(nb+1)] basis table "
-                "(one 10 us kernel) is built once per time grid and reused by "
-                "the ~100 trajectory / log-prob evaluations of a rollout + "
-                "update (ops._times_flags)"}}
-    extra["gae_scan"] = gae
-    extra["critic_split_f16"] = critic16
+    alg, us, us_cold = traj_case(mp, N, T)
+    extra["prodmp_traj"] = hbm_entry(
+        "prodmp_traj_kernel<float,4,6,true>", alg, us, us_cold,
+        "trajectory kernel; the [T, 4+2(nb+1)] basis table (one 10 us kernel) "
+        "is built once per time grid and reused by the ~100 trajectory / "
+        "log-prob evaluations of a rollout + update (ops._times_flags)",
+        pmc_traffic("prodmp_traj_kernel"))
+    alg, us, us_cold = traj_case(mp, 8 * N, T)
+    extra["prodmp_traj_32768_envs"] = hbm_entry(
+        "prodmp_traj_kernel<float,4,6,true>", alg, us, us_cold,
+        "529 MB per launch: past the Infinity Cache")
+    from tce_rl_amd.mp import ProDMP
+    mp7 = ProDMP(num_dof=7, num_basis=8, tau=2.0, alpha_phase=3, alpha=10,
+                 dt=0.02, basis_bandwidth_factor=3, weights_scale=0.3,
+                 goal_scale=0.3, dtype=torch.float32, device="cuda")
+    alg, us, us_cold = traj_case(mp7, 16 * N, 100)
+    extra["prodmp_traj_dof7"] = hbm_entry(
+        "prodmp_traj_kernel<float,7,9,false>", alg, us, us_cold,
+        "BASELINE configs[2] rows (dof 7: 56-byte rows, stored through a "
+        "wave-private LDS slab as contiguous 8-byte chunks), 65536 envs x T "
+        "100 = 367 MB")
+
+    # env rollout kernel: writes the [N, T+1, D] state buffer once, reads the
+    # desired trajectory; column moments in the same pass
+    env = agent.sampler.train_envs
+    D = env.dim_obs
+    acts = torch.randn(N, T, 2 * env.num_dof, device="cuda", generator=g)
+    obs0 = env.reset()
+    shift = torch.zeros(D, device="cuda")
+    f = lambda: ops.env_rollout(acts, obs0, env.task, env.num_dof,
+                                env.dim_task_obs, env.dt, 400.0, 40.0,
+                                want_states=True, shift=shift,
+                                want_moments=True)
+    alg = N * ((T + 1) * D * 4 + T * 2 * env.num_dof * 4 + T * 4)
+    extra["env_rollout"] = hbm_entry(
+        "env_rollout_kernel<float>", alg, kernel_time_us(f, launches=5),
+        kernel_time_cold_us(f),
+        "one launch = one whole episode of the %d synthetic envs: state "
+        "buffer written once (%d MB), observation moments accumulated in the "
+        "same pass" % (N, N * (T + 1) * D * 4 // 1000000))
+    del acts
+
+    # wide / fp64 critics of BASELINE configs[2] (box pushing): one epoch =
+    # chain kernel + weight-gradient kernel (+ slab reduction)
+    from tce_rl_amd.nn import MLP
+    for tag, dtype, peak in (("f32", torch.float32, F32_MFMA_PEAK_TF),
+                             ("f64", torch.float64, F64_MFMA_PEAK_TF)):
+        wide = MLP("ValueFunction", 21, 1, [256, 256], "orthogonal", 1.0,
+                   "leaky_relu", None, dtype, torch.device("cuda"))
+        n3, t3 = 8192, 100
+        st = torch.randn(n3, t3 + 1, 35, device="cuda", generator=g,
+                         dtype=dtype)[:, :-1, :21]
+        rt = torch.randn(n3, t3, device="cuda", generator=g, dtype=dtype)
+        runw = critic_ops.make_runner(wide)
+        us_w = kernel_time_us(lambda: runw.epoch(st, rt, rt, 0.0), launches=3)
+        fl = 6.0 * (21 * 256 + 256 * 256 + 256) * n3 * t3
+        extra["critic_256x2_" + tag] = {
+            "kernel": "mlpw_chain_kernel + mlpw_grad_kernel + "
+                      "mlpw_finish_kernel (<%s, 256>)" % tag,
+            "bound": "mfma", "achieved": round(fl / us_w / 1e6, 2),
+            "peak": peak, "unit": "TFLOP/s",
+            "frac": round(fl / us_w / 1e6 / peak, 4), "traffic": None,
+            "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
+            "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
+                        "D_in 21 -> 256 -> 256 -> 1, leaky_relu",
+            "dtype": tag + (" (v_mfma_f32_16x16x4_f32)" if tag == "f32"
+                            else " (v_mfma_f64_16x16x4_f64)")}
+        del st, rt, runw, wide
     return critic, extra
 
 
 def cpu_baseline():
     """The CPU oracle (torch-CPU restatement of the reference path, kind
-    'port') on a bounded sample: 256 envs, full 50 + 50 epochs."""
+    'port') on a bounded sample: 128 envs, full 50 + 50 epochs; one untimed
+    warm-up step, then the median of three timed steps."""
     from tce_rl_amd.config import tce_config
     from oracle.agent_oracle import OracleTCE      # checker / baseline only
-    n = 256
+    n = 128
     # host cores this process may use (the GPU box gives 16 per GPU); torch
     # with more threads than cores thrashes on the small ops
     try:
@@ -204,13 +309,18 @@ def cpu_baseline():
     cfg = tce_config("metaworld", num_env=n, num_basis=NUM_BASIS,
                      epochs=EPOCHS, device="cpu")
     o = OracleTCE(cfg["params"], n)
-    t = time.perf_counter()
-    steps = o.step()
-    dt = time.perf_counter() - t
+    steps = o.step()                                # warm-up
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter()
+        steps = o.step()
+        ts.append(time.perf_counter() - t)
+    dt = sorted(ts)[1]
     return {"value": round(steps / dt, 1), "unit": "env-steps/s",
             "cores": threads, "kind": "port",
-            "sample": "1 agent.step() of the torch-CPU oracle at %d envs "
-                      "(T 500, 50 critic + 50 policy epochs), %.1f s" % (n, dt)}
+            "sample": "torch-CPU oracle agent.step() at %d envs (T 500, 50 "
+                      "critic + 50 policy epochs): 1 warm-up step, median of "
+                      "3 timed steps = %.2f s" % (n, dt)}
 
 
 def self_launch(args):
@@ -329,10 +439,11 @@ def main():
     if rank == 0:
         print("[bench] warmup done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    pol_time = 0.0
+    pol_time = crit_time = 0.0
     for _ in range(args.steps):
         res = agent.step()
         pol_time += res["update_policy_time"]
+        crit_time += res["update_critic_time"]      # device time (HIP events)
     barrier()
     elapsed = time.perf_counter() - t0
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
@@ -361,7 +472,7 @@ def main():
         env_steps = world * NUM_ENV * T * args.steps
         print("[bench] timed region: %.3f s" % elapsed, file=sys.stderr,
               flush=True)
-        roof, extra = roofline(agent)
+        roof, extra = roofline(agent, crit_time / args.steps * 1e3)
         print("[bench] roofline done", file=sys.stderr, flush=True)
         out = {
             "metric": "env-steps/sec (TCE rollout + update, Metaworld-reach-"

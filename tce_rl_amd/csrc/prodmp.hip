@@ -51,6 +51,16 @@ __device__ inline void store_vec(real* dst, const real* src) {
   *reinterpret_cast<vec*>(dst) = v;
 }
 
+// the same with NV * sizeof(real) alignment guaranteed by the caller (one store)
+template <typename real, int NV>
+__device__ inline void store_vec_aligned(real* dst, const real* src) {
+  typedef real vec __attribute__((ext_vector_type(NV), aligned(NV * sizeof(real))));
+  vec v;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = src[i];
+  *reinterpret_cast<vec*>(dst) = v;
+}
+
 // NBG > 0: num_basis + 1 known at compile time (the loops over the basis
 // become straight-line FMAs with SGPR parameter operands); NBG == 0: runtime.
 // HALF (DOF == 4 only): a lane owns (t, pos | vel) and writes ONE 16-byte
@@ -118,15 +128,42 @@ __global__ __launch_bounds__(256) void prodmp_traj_kernel(
         o[d] = pos;
         o[DOF + d] = vel;
       }
+      constexpr int C = 2 * DOF;
+      if (C % 4 != 0 && C % 2 == 0) {
+        // rows of C = 14 (dof 7) values: a lane's row is not a multiple of 16 B,
+        // so row-per-lane stores are 8-byte pieces at a C*s-byte stride (25 % of
+        // the HBM rate).  The wave's 64 rows are contiguous in memory: stage
+        // them in a wave-private LDS slab and store them as consecutive
+        // 2-element chunks, lane = chunk (512 B / 1 KiB contiguous per store).
+        __shared__ real slab[4][64 * C];
+        real* sl = slab[threadIdx.x >> 6];
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < C; ++k) sl[lane * C + k] = o[k];
+        // the slab is private to this wave and LDS operations of one wave
+        // execute in order: only the COMPILER must not reorder across here.  (A
+        // release fence also waits for the wave's outstanding global stores --
+        // one HBM round trip per env.)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int t_w = t - lane;                              // first step of the wave
+        real* wbase = out + (n * T + t_w) * (int64_t)C;
+        const int nvalid = (T - t_w < 64 ? T - t_w : 64) * C;  // elements of live rows
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) {
+          const int e = 2 * (q * 64 + lane);
+          if (e < nvalid) store_vec_aligned<real, 2>(wbase + e, sl + e);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
       if (t < T) {
         real* dst = out + (n * T + t) * (int64_t)(2 * DOF);
-        constexpr int C = 2 * DOF;
         if (C % 4 == 0) {
 #pragma unroll
           for (int k = 0; k < C / 4; ++k) store_vec<real, 4>(dst + 4 * k, o + 4 * k);
         } else if (C % 2 == 0) {
-#pragma unroll
-          for (int k = 0; k < C / 2; ++k) store_vec<real, 2>(dst + 2 * k, o + 2 * k);
+          // handled below (all lanes of the wave take part)
         } else {
 #pragma unroll
           for (int k = 0; k < C; ++k) dst[k] = o[k];

@@ -77,8 +77,8 @@ class SyntheticTCEEnv:
         self.dim_task_obs = int(dim_task_obs or max(d_task, 2 * num_dof + 6))
         self.dtype, self.device = dtype, torch.device(device)
         self.dim_obs = self.dim_task_obs + 1 + 2 * num_dof
-        if not 3 <= num_dof <= 16 or self.dim_obs > 64:
-            raise NotImplementedError("synthetic env suite: 3 <= num_dof <= 16 "
+        if not 3 <= num_dof <= 8 or self.dim_obs > 64:
+            raise NotImplementedError("synthetic env suite: 3 <= num_dof <= 8 "
                                       "and obs dim <= 64")
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.observation_space = types.SimpleNamespace(shape=(self.dim_obs,))

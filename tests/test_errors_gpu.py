@@ -65,7 +65,15 @@ def test_limits_fall_back_or_raise_cleanly():
     assert y.shape == (5000, 1) and torch.isfinite(y).all()
     f64 = MLP("ValueFunction", 20, 1, [128, 128], "orthogonal", 1.0, "relu",
               None, torch.float64, torch.device("cuda"))
-    assert not critic_ops.supported(f64)                   # fused kernel: fp32
+    assert critic_ops.supported(f64) and not critic_ops.narrow_supported(f64)
+    odd = MLP("ValueFunction", 20, 1, [192, 192], "orthogonal", 1.0, "relu",
+              None, torch.float32, torch.device("cuda"))
+    assert not critic_ops.supported(odd)                   # widths 128 / 256 only
+    y = odd(torch.randn(5000, 20, device="cuda"))          # library path
+    assert y.shape == (5000, 1) and torch.isfinite(y).all()
+    big64 = MLP("ValueFunction", 40, 1, [256, 256], "orthogonal", 1.0, "relu",
+                None, torch.float64, torch.device("cuda"))
+    assert not critic_ops.supported(big64)                 # fp64 x 256: D_in <= 24
     K = 65                                                  # K <= 64 everywhere
     L = torch.eye(K, device="cuda").expand(3, K, K).contiguous()
     with pytest.raises(RuntimeError):
