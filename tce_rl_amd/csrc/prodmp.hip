@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void prodmp_traj_kernel(
     MPParams<real> mp, const real* __restrict__ times, int times_general,
     const real* __restrict__ w, const real* __restrict__ t0,
     const real* __restrict__ y0, const real* __restrict__ v0,
-    real* __restrict__ out, int64_t N, int T, int epb) {
+    real* __restrict__ out, int64_t N, int T, int epb, int only_if_general) {
+  // only_if_general: the uniform-grid case was done by prodmp_traj_rows_kernel
+  if (only_if_general && !times_general && *nonuniform == 0) return;
   const int nbg = NBG > 0 ? NBG : mp.nbg;
   constexpr int MAXB = NBG > 0 ? NBG : TCE_MAXB;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -173,6 +175,97 @@ __global__ __launch_bounds__(256) void prodmp_traj_kernel(
   }
 }
 
+// Rows of 2 DOF values that are not a multiple of 16 bytes (odd DOF: 7-dof box
+// pushing / table tennis, 56-byte rows) on the shared (uniform init time) basis
+// table.  Three things differ from prodmp_traj_kernel:
+//  * the per-env parameters (w, y0, v0) of a chunk of envs are staged in LDS
+//    first, so the env loop issues NO global loads: loads and stores share one
+//    in-order counter on gfx950, and a load behind a store waits for the store
+//    to reach memory -- one HBM round trip per env (measured: 5.6 us per env and
+//    wave, 26 % of the HBM rate);
+//  * short horizons (T <= 128, box pushing: 100) put 256 / T consecutive envs
+//    side by side in a workgroup (their rows are consecutive in memory), so
+//    200 of 256 lanes work instead of 100;
+//  * the 64 rows of a wave are contiguous: they go through a wave-private LDS
+//    slab and leave as consecutive 2-element chunks, lane = chunk.
+template <typename real, int DOF, int NBG>
+__global__ __launch_bounds__(256) void prodmp_traj_rows_kernel(
+    const real* __restrict__ B, const int* __restrict__ nonuniform, MPParams<real> mp,
+    int times_general, const real* __restrict__ w, const real* __restrict__ y0,
+    const real* __restrict__ v0, real* __restrict__ out, int64_t N, int T, int spb, int epb) {
+  if (times_general || *nonuniform != 0) return;      // prodmp_traj_kernel takes it
+  const int nbg = NBG > 0 ? NBG : mp.nbg;
+  constexpr int MAXB = NBG > 0 ? NBG : TCE_MAXB;
+  constexpr int C = 2 * DOF;
+  constexpr int EC = 32;                               // envs per staged chunk
+  const int K = DOF * nbg, NPAR = K + 2 * DOF;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* par = reinterpret_cast<real*>(smem_raw);       // [EC][NPAR]
+  real* slab = par + EC * NPAR;                         // [4 waves][64 * C]
+  const int i = threadIdx.x, lane = i & 63;
+  int sub = 0, t = blockIdx.x * 256 + i;
+  if (spb > 1) { sub = i / T; t = i - sub * T; }
+  const bool live = spb > 1 ? sub < spb : t < T;
+  const int tc = t < T ? t : T - 1;
+  real row[TCE_ROWLEN];
+  mp_row_load(B + (int64_t)tc * (4 + 2 * nbg), nbg, row);
+  real* sl = slab + (i >> 6) * 64 * C;
+  const int64_t n_begin = (int64_t)blockIdx.y * epb;
+  const int64_t n_end = tmin<int64_t>(N, n_begin + epb);
+  // first global row of this wave relative to the first env of an iteration
+  const int r_w = spb > 1 ? (i & ~63) : blockIdx.x * 256 + (i & ~63);
+  const int rows_it = spb > 1 ? spb * T : T;            // rows per iteration beyond which nothing lives
+  for (int64_t c0 = n_begin; c0 < n_end; c0 += EC) {
+    const int ne = (int)tmin<int64_t>(EC, n_end - c0);
+    __syncthreads();                                    // the previous chunk is consumed
+    for (int idx = i; idx < ne * NPAR; idx += 256) {
+      const int e = idx / NPAR, j = idx - e * NPAR;
+      const int64_t n = c0 + e;
+      par[idx] = j < K ? w[n * K + j] : (j < K + DOF ? y0[n * DOF + j - K] : v0[n * DOF + j - K - DOF]);
+    }
+    __syncthreads();
+    for (int e = 0; e < ne; e += spb) {
+      const int slot = e + sub < ne ? e + sub : ne - 1; // dead lanes shadow a live env
+      const real* p = par + slot * NPAR;
+      real o[C];
+#pragma unroll
+      for (int d = 0; d < DOF; ++d) {
+        const real yd = p[K + d], vd = p[K + DOF + d];
+        real pos = row[0] * yd + row[1] * vd;
+        real vel = row[2] * yd + row[3] * vd;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+          if (b < nbg) {
+            const real th = p[d * nbg + b];
+            pos += row[4 + b] * th;
+            vel += row[4 + TCE_MAXB + b] * th;
+          }
+        }
+        o[d] = pos;
+        o[DOF + d] = vel;
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) sl[lane * C + k] = o[k];
+      asm volatile("" ::: "memory");                    // wave-private slab: compiler order only
+      __builtin_amdgcn_wave_barrier();
+      const int live_rows = (ne - e < spb ? ne - e : spb) * (spb > 1 ? T : 1);
+      const int lim = spb > 1 ? live_rows : (live_rows ? rows_it : 0);
+      int nrow = lim - r_w;                             // live rows of this wave
+      nrow = nrow < 0 ? 0 : (nrow > 64 ? 64 : nrow);
+      real* wbase = out + ((c0 + e) * T + r_w) * (int64_t)C;
+      const int nvalid = nrow * C;
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) {
+        const int el = 2 * (q * 64 + lane);
+        if (el < nvalid) store_vec_aligned<real, 2>(wbase + el, sl + el);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  (void)live;
+}
+
 template <typename real>
 int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scaled_dt,
                 real inv_scale_g, int rel_goal, const real* times, int times_flags,
@@ -193,6 +286,35 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
                        stream, mp, times, t0, N, T, B, flag);
     TCE_LAUNCH_CHECK();
   }
+  // odd dof (rows not a multiple of 16 B) on the shared basis table: the rows
+  // kernel; the kernel below then only runs if the time grid turns out general
+  int only_general = 0;
+  if (dof == 3 || dof == 5 || dof == 7) {
+    const int spb = T <= 128 ? 256 / T : 1;
+    const int txr = spb > 1 ? 1 : (int)ceil_div(T, 256);
+    int64_t epr = tmax<int64_t>(spb, (N * txr) / 2048);
+    epr = ceil_div(epr, spb) * spb;
+    const int64_t gyr = ceil_div(N, epr);
+    TCE_CHECK_ARG(gyr <= 65535, "prodmp_traj: too many envs");
+    const size_t lds = ((size_t)32 * (dof * nbg + 2 * dof) + (size_t)4 * 64 * 2 * dof) * sizeof(real);
+    dim3 gr(txr, (unsigned)gyr);
+#define ROWS_GO(D, NB)                                                            \
+    hipLaunchKernelGGL((prodmp_traj_rows_kernel<real, D, NB>), gr, dim3(256), lds, \
+                       stream, B, flag, mp, times_general, w, y0, v0, out, N, T,   \
+                       spb, (int)epr)
+    if (dof == 7) {
+      if (nbg == 9) ROWS_GO(7, 9);
+      else if (nbg == 4) ROWS_GO(7, 4);
+      else ROWS_GO(7, 0);
+    } else if (dof == 5) {
+      ROWS_GO(5, 0);
+    } else {
+      ROWS_GO(3, 0);
+    }
+#undef ROWS_GO
+    TCE_LAUNCH_CHECK();
+    only_general = 1;
+  }
   // ~2048 workgroups: each keeps its basis rows for `epb` envs
   const bool half = (dof == 4);
   const int txb = (int)ceil_div((int64_t)T * (half ? 2 : 1), 256);
@@ -203,7 +325,7 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
 #define TRAJ_GO(D, NB, H)                                                         \
   hipLaunchKernelGGL((prodmp_traj_kernel<real, D, NB, H>), grid, dim3(256), 0,    \
                      stream, B, flag, mp, times, times_general, w, t0, y0, v0,    \
-                     out, N, T, epb)
+                     out, N, T, epb, only_general)
 #define TRAJ_NB(D, H)                                                             \
   switch (nbg) {                                                                  \
     case 4: TRAJ_GO(D, 4, H); break;                                              \
