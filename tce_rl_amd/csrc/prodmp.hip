@@ -254,10 +254,11 @@ __global__ __launch_bounds__(256) void prodmp_traj_rows_kernel(
       nrow = nrow < 0 ? 0 : (nrow > 64 ? 64 : nrow);
       real* wbase = out + ((c0 + e) * T + r_w) * (int64_t)C;
       const int nvalid = nrow * C;
+      constexpr int CH = C % 4 == 0 ? 4 : 2;            // elements per store (16 B when rows allow)
 #pragma unroll
-      for (int q = 0; q < C / 2; ++q) {
-        const int el = 2 * (q * 64 + lane);
-        if (el < nvalid) store_vec_aligned<real, 2>(wbase + el, sl + el);
+      for (int q = 0; q < C / CH; ++q) {
+        const int el = CH * (q * 64 + lane);
+        if (el < nvalid) store_vec_aligned<real, CH>(wbase + el, sl + el);
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -289,7 +290,7 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
   // odd dof (rows not a multiple of 16 B) on the shared basis table: the rows
   // kernel; the kernel below then only runs if the time grid turns out general
   int only_general = 0;
-  if (dof == 3 || dof == 5 || dof == 7) {
+  if (dof == 3 || dof == 4 || dof == 5 || dof == 7) {
     const int spb = T <= 128 ? 256 / T : 1;
     const int txr = spb > 1 ? 1 : (int)ceil_div(T, 256);
     int64_t epr = tmax<int64_t>(spb, (N * txr) / 2048);
@@ -306,6 +307,11 @@ int traj_launch(const real* tab, int M, int nbg, real tau, real delay, real scal
       if (nbg == 9) ROWS_GO(7, 9);
       else if (nbg == 4) ROWS_GO(7, 4);
       else ROWS_GO(7, 0);
+    } else if (dof == 4) {
+      if (nbg == 6) ROWS_GO(4, 6);
+      else if (nbg == 9) ROWS_GO(4, 9);
+      else if (nbg == 5) ROWS_GO(4, 5);
+      else ROWS_GO(4, 0);
     } else if (dof == 5) {
       ROWS_GO(5, 0);
     } else {
