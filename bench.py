@@ -220,14 +220,14 @@ def roofline(agent, critic_ms_in_step):
     mp = agent.policy.mp
     alg, us, us_cold = traj_case(mp, N, T)
     extra["prodmp_traj"] = hbm_entry(
-        "prodmp_traj_kernel<float,4,6,true>", alg, us, us_cold,
+        "prodmp_traj_rows_kernel<float,4,6>", alg, us, us_cold,
         "trajectory kernel; the [T, 4+2(nb+1)] basis table (one 10 us kernel) "
         "is built once per time grid and reused by the ~100 trajectory / "
         "log-prob evaluations of a rollout + update (ops._times_flags)",
-        pmc_traffic("prodmp_traj_kernel"))
+        pmc_traffic("prodmp_traj_rows_kernel<float, 4"))
     alg, us, us_cold = traj_case(mp, 8 * N, T)
     extra["prodmp_traj_32768_envs"] = hbm_entry(
-        "prodmp_traj_kernel<float,4,6,true>", alg, us, us_cold,
+        "prodmp_traj_rows_kernel<float,4,6>", alg, us, us_cold,
         "529 MB per launch: past the Infinity Cache")
     from tce_rl_amd.mp import ProDMP
     mp7 = ProDMP(num_dof=7, num_basis=8, tau=2.0, alpha_phase=3, alpha=10,
@@ -235,10 +235,10 @@ def roofline(agent, critic_ms_in_step):
                  goal_scale=0.3, dtype=torch.float32, device="cuda")
     alg, us, us_cold = traj_case(mp7, 16 * N, 100)
     extra["prodmp_traj_dof7"] = hbm_entry(
-        "prodmp_traj_kernel<float,7,9,false>", alg, us, us_cold,
+        "prodmp_traj_rows_kernel<float,7,9>", alg, us, us_cold,
         "BASELINE configs[2] rows (dof 7: 56-byte rows, stored through a "
         "wave-private LDS slab as contiguous 8-byte chunks), 65536 envs x T "
-        "100 = 367 MB")
+        "100 = 367 MB", pmc_traffic("prodmp_traj_rows_kernel<float, 7"))
 
     # env rollout kernel: writes the [N, T+1, D] state buffer once, reads the
     # desired trajectory; column moments in the same pass
@@ -257,7 +257,9 @@ def roofline(agent, critic_ms_in_step):
         kernel_time_cold_us(f),
         "one launch = one whole episode of the %d synthetic envs: state "
         "buffer written once (%d MB), observation moments accumulated in the "
-        "same pass" % (N, N * (T + 1) * D * 4 // 1000000))
+        "same pass; instruction-bound (one wave per env, ~200 instructions "
+        "per step)" % (N, N * (T + 1) * D * 4 // 1000000),
+        pmc_traffic("env_rollout_kernel"))
     del acts
 
     # wide / fp64 critics of BASELINE configs[2] (box pushing): one epoch =
@@ -279,7 +281,10 @@ def roofline(agent, critic_ms_in_step):
                       "mlpw_finish_kernel (<%s, 256>)" % tag,
             "bound": "mfma", "achieved": round(fl / us_w / 1e6, 2),
             "peak": peak, "unit": "TFLOP/s",
-            "frac": round(fl / us_w / 1e6 / peak, 4), "traffic": None,
+            "frac": round(fl / us_w / 1e6 / peak, 4),
+            "traffic": (None if tag != "f32" or pmc_traffic("mlpw_chain_kernel")
+                        is None else pmc_traffic("mlpw_chain_kernel") +
+                        pmc_traffic("mlpw_grad_kernel")),
             "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
             "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
                         "D_in 21 -> 256 -> 256 -> 1, leaky_relu",

@@ -32,4 +32,21 @@ w = 0.1 * torch.randn(N, 24, device="cuda", generator=g); y0 = torch.rand(N, 4, 
 for _ in range(3):
     big.fill_(1.0)
     ops.prodmp_traj(mp, times, w, t0, y0, v0)
+# round 2: wide critic (C3 rows, fp32), env rollout kernel, dof-7 trajectories
+wide = MLP("ValueFunction", 21, 1, [256, 256], "orthogonal", 1.0, "leaky_relu", None, torch.float32, torch.device("cuda"))
+xw = torch.randn(8192, 101, 35, device="cuda", generator=g)[:, :-1, :21]; rw = torch.randn(8192, 100, device="cuda", generator=g)
+runw = critic_ops.make_runner(wide)
+for _ in range(3):
+    big.fill_(1.0)
+    runw.epoch(xw, rw, rw, 0.0)
+acts = torch.randn(N, T, 8, device="cuda", generator=g); obs0 = torch.randn(N, 48, device="cuda", generator=g); shift = torch.zeros(48, device="cuda")
+for _ in range(3):
+    big.fill_(1.0)
+    ops.env_rollout(acts, obs0, "reach", 4, 39, 0.0125, 400.0, 40.0, want_states=True, shift=shift, want_moments=True)
+mp7 = ProDMP(dtype=torch.float32, device="cuda", num_dof=7, num_basis=8, tau=2.0, alpha_phase=3, alpha=10, dt=0.02, basis_bandwidth_factor=3, weights_scale=0.3, goal_scale=0.3)
+n7 = 65536; t07 = torch.zeros(n7, device="cuda"); times7 = ops.times(t07, mp7.dt, 100)
+w7 = 0.1 * torch.randn(n7, 63, device="cuda", generator=g); y07 = torch.rand(n7, 7, device="cuda", generator=g); v07 = torch.zeros(n7, 7, device="cuda")
+for _ in range(3):
+    big.fill_(1.0)
+    ops.prodmp_traj(mp7, times7, w7, t07, y07, v07)
 torch.cuda.synchronize()

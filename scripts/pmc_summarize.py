@@ -10,7 +10,8 @@ Both counters are reported in KiB."""
 import csv, json, os, sys, collections
 
 KERNELS = ("gae_dpp_kernel", "mlp_critic_bwd_kernel", "mlp_critic_bwd16_kernel",
-           "mlp_critic_fwd_kernel", "prodmp_traj_kernel")
+           "mlp_critic_fwd_kernel", "prodmp_traj_rows_kernel<float, 4", "prodmp_traj_rows_kernel<float, 7",
+           "mlpw_chain_kernel", "mlpw_grad_kernel", "env_rollout_kernel")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
