@@ -134,7 +134,14 @@ struct WArgs {
 
 template <typename real>
 struct WCfg {
-  static constexpr int WAVES = sizeof(real) == 4 ? 8 : 4;   // chain kernel
+  // chain kernel: two waves per SIMD in fp32; fp64 keeps its B operands in 128
+  // registers per lane and spills at the 256 of a two-wave kernel (tried: 279
+  // spilled registers), so it runs one wave per SIMD
+  static constexpr int WAVES = sizeof(real) == 4 ? 8 : 4;
+  // copies of the db1 / db2 / dw3 accumulators in LDS: one per wave (plain
+  // read-modify-write, fixed summation order); fewer copies than waves would
+  // go through LDS atomics
+  static constexpr int NACC = WAVES;
   static constexpr int NT = WAVES * 64;
   static constexpr int TILE = WAVES * 16;                   // batch rows per tile
   static constexpr int PU = sizeof(real) == 4 ? 32 : 16;    // output units per panel
@@ -170,9 +177,17 @@ struct ChainLds {
   static constexpr int PANEL = WCfg<real>::PU * WP;
   static constexpr size_t bytes(bool bwd) {
     return sizeof(real) * ((size_t)H * W1P + 3 * H + 2 * PANEL +
-                           (bwd ? (size_t)WCfg<real>::WAVES * 3 * H : 0)) + 64;
+                           (bwd ? (size_t)WCfg<real>::NACC * 3 * H : 0)) + 64;
   }
 };
+
+#ifdef MLPW_STAMP
+// diagnostic build (scripts/mlpw_stamps.py): cycles per phase of the chain
+// kernel (wave 0 of workgroup 0), left in the first elements of the dY1 rows
+#define WSTAMP(k) { const long long tn_ = __builtin_readcyclecounter(); stt_[k] += tn_ - tp_; tp_ = tn_; }
+#else
+#define WSTAMP(k)
+#endif
 
 // nothing moves across: keeps the compiler from hoisting every LDS read of an
 // unrolled phase to its top (which spills) and the next step's reads ahead of
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   real* W1s = reinterpret_cast<real*>(smem_raw);             // [H][W1P] natural rows
   real* Bs = W1s + H * W1P;                                  // b1 | b2 | w3, position order
   real* pan = Bs + 3 * H;                                    // [2][PU][WP]
-  real* gacc = pan + 2 * LD::PANEL;                          // [WAVES][3][H] db1 | db2 | dw3 (positions)
+  real* gacc = pan + 2 * LD::PANEL;                          // [NACC][3][H] db1 | db2 | dw3 (positions)
   __shared__ real sred[2 * C::WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     Bs[2 * H + e] = a.w3[u];
   }
   if (BWD)
-    for (int e = tid; e < C::WAVES * 3 * H; e += NT) gacc[e] = real(0);
+    for (int e = tid; e < C::NACC * 3 * H; e += NT) gacc[e] = real(0);
 
   // ---- panel stream: step s of a tile reads W2p rows (s < NP) or W2Tp rows
   auto panel_src = [&](int s) -> const real* {
@@ -311,7 +326,8 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   const real b3 = a.b3[0];
   const real inv_n = real(1) / (real)a.R;
   real loss_sum = 0, gb3 = 0;
-  real* my_acc = gacc + wave * 3 * H;
+  real* my_acc = gacc + (wave % C::NACC) * 3 * H;
+  constexpr bool ACC_ATOMIC = C::NACC < C::WAVES;
 
   // x fragment: lane group g holds features KPG g + s of the lane's row (zeros
   // past D_in); one lane address, the features are immediate offsets of it
@@ -328,7 +344,12 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   real xn[KPG];
   load_x(blockIdx.x, xn);
 
+#ifdef MLPW_STAMP
+  long long stt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tp_ = __builtin_readcyclecounter();
+#endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    WSTAMP(7)
     const int64_t r = tile * C::TILE + wave * 16 + m;
     const bool rok = r < a.R;
     const bool more = tile + gridDim.x < ntiles;
@@ -377,6 +398,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       for (int J = 0; J < NJ; ++J) *reinterpret_cast<v4*>(ph + 16 * J) = h1[J];
     }
 
+    WSTAMP(0)
     // ---- layer 2 through the W2 panels: H2^T = act(W2 H1^T + b2).  The H2
     // tiles are not kept: their share of v = w3 . H2 is taken at once and
     // (backward) the tile is parked in the dY2 rows of the workspace.
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       __syncthreads();
     }
 
+    WSTAMP(1)
     // ---- value head, loss, dL/dv
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -462,10 +485,14 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           real* q2 = my_acc + H + 16 * J + 4 * g;
           real* q3 = my_acc + 2 * H + 16 * J + 4 * g;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { q2[i] += t2[i]; q3[i] += t3[i]; }
+          for (int i = 0; i < 4; ++i) {
+            if (ACC_ATOMIC) { unsafeAtomicAdd(q2 + i, t2[i]); unsafeAtomicAdd(q3 + i, t3[i]); }
+            else { q2[i] += t2[i]; q3[i] += t3[i]; }
+          }
         }
         wfence();
       }
+      WSTAMP(2)
       // ---- dH1^T = W2^T dY2^T through the W2^T panels; dY1 = dH1 act'(H1)
       // (the H1 tile of the panel is read back from the workspace)
 #pragma unroll
@@ -496,14 +523,22 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           if (m == 0) {
             real* q1 = my_acc + 16 * J + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q1[i] += t1[i];
+            for (int i = 0; i < 4; ++i) {
+              if (ACC_ATOMIC) unsafeAtomicAdd(q1 + i, t1[i]);
+              else q1[i] += t1[i];
+            }
           }
         }
         if (pre) stash(((NP + s) & 1) ^ 1);
         __syncthreads();
       }
+      WSTAMP(3)
     }
   }
+#ifdef MLPW_STAMP
+  if (BWD && blockIdx.x == 0 && tid == 0)
+    for (int k = 0; k < 8; ++k) a.dy1s[k] = (real)stt_[k];
+#endif
 
   if (BWD) {
     // ---- slab: b1, b2, w3 (unit order), b3, loss
@@ -519,7 +554,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       const int which = e / H, p = e - which * H;
       real s = 0;
 #pragma unroll
-      for (int w = 0; w < C::WAVES; ++w) s += gacc[w * 3 * H + e];
+      for (int w = 0; w < C::NACC; ++w) s += gacc[w * 3 * H + e];
       const int u = unit_of_pos<real>(p);
       (which == 0 ? ob1 : (which == 1 ? ob2 : ow3))[u] = s;
     }
