@@ -8,7 +8,7 @@ so = os.path.join(ROOT, "scripts", "variants", "libklp_stamp.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 if "--build" in sys.argv or not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC",
-                           "-std=c++17", "-shared", "-DKLP_STAMP", os.path.join(CS, "gauss.hip"),
+                           "-std=c++17", "-shared", "-DKLP_STAMP", "-DSMJ_STAMP", os.path.join(CS, "gauss.hip"),
                            os.path.join(CS, "capi.hip"), "-o", so])
     if "--build" in sys.argv:
         sys.exit(0)
@@ -42,3 +42,5 @@ for warm in (0, 1):
             acc += ctx[0, -16:].cpu()
     acc /= 18
     print("K %d warm %d cycles:" % (K, warm), {k: int(v) for k, v in zip(names, acc[:9].tolist())}, "total", int(acc[:9].sum()))
+    jn = ["pairs", "loads+dots", "dpp", "rotate+store", "barrier", "sweeps"]
+    print("   jacobi (thread 0):", {k: round(v, 1) for k, v in zip(jn, acc[9:15].tolist())})

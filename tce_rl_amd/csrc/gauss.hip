@@ -274,7 +274,9 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
     // "active" slot says whether it wrote any)
     const bool warm = warm_start && cb[(int64_t)K * K + K + 1] == 1.0;
     KLP_T(2)
-    sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP, warm ? cb : nullptr, Tmp);
+    // float32 results do not need the decomposition beyond their own rounding
+    sm_jacobi_rows(A, Vt, lam, &s_flag, K, KP, warm ? cb : nullptr, Tmp,
+                   sizeof(real) == 4 ? 1e-18 : 1e-26, sizeof(real) == 4 ? 1e-10 : 1e-16);
     KLP_T(3)
     if (threadIdx.x < 64) {
       const bool live = threadIdx.x < K;
@@ -336,6 +338,10 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_fwd_kernel(
   }
   sm_store(projL + b * (int64_t)K * K, Los, K, KP, true, alpha);
   KLP_T(8)
+#ifdef SMJ_STAMP
+  if (threadIdx.x == 0 && active)
+    for (int k = 0; k < 6; ++k) cb[(int64_t)K * K + K + 4 + 9 + k] = (double)smj_acc[k == 5 ? 7 : k];
+#endif
   if (threadIdx.x == 0) {
     double* tail = cb + (int64_t)K * K + K;
     tail[0] = eta;

@@ -139,36 +139,55 @@ __device__ inline double sm_rsq(double x) {
 // Block-wide sum of a double (all threads get it); scratch >= 4 doubles.
 __device__ inline double sm_block_sum(double v, double* scratch) { return block_sum(v, scratch); }
 
-// One-sided (Hestenes) Jacobi on the ROWS of A (K x K, LDS): rotations J^T are
-// applied on the left of A and of Vt (Vt starts as I) until the rows of A are
-// mutually orthogonal.  Then A A^T(original) = Q diag(lam) Q^T with
-// Q[i][k] = Vt[k][i], lam[k] = |row k of A|^2.  8 lanes per row pair, K/2
+// One-sided (Hestenes) Jacobi on the ROWS of the LOWER-TRIANGULAR matrix A
+// (K x K, LDS): plane rotations are applied on the left of A until its rows are
+// mutually orthogonal, A' = Vt A.  Then A A^T = Q diag(lam) Q^T with
+// Q[i][k] = Vt[k][i], lam[k] = |row k of A'|^2.  8 lanes per row pair, K/2
 // independent pairs per round (round-robin tournament), one barrier per round.
-// warm (nullable, with scratch T [K][KP]): an orthogonal K x K matrix (row-major,
-// global memory) that nearly diagonalises A A^T already -- the Vt of a previous
-// call for a nearby A.  The iteration then starts from Vt = warm, A = warm A and
-// needs 2-3 sweeps instead of 8-10.
+// Every round re-reads and re-writes all of A, and the LDS bandwidth of that is
+// what a round costs -- so Vt is NOT rotated along (it would double the
+// traffic): it is recovered at the end as Vt = A' A0^-1 with one triangular
+// solve against the original A (kept in the Vt slot meanwhile).
+// A sweep in which every pair was already orthogonal to 1e-8 relative is the
+// last one: cyclic Jacobi converges quadratically, the rotations of that sweep
+// leave 1e-16, so the confirming sweep is skipped.
+// warm (nullable): an orthogonal K x K matrix (row-major, global memory) that
+// nearly diagonalises A A^T already -- the Vt of a previous call for a nearby
+// A.  The iteration then starts from A <- warm A and needs 1-2 sweeps instead of
+// 8-10.  T: scratch [K][KP].
+#ifdef SMJ_STAMP
+__device__ long long smj_acc[8];
+#define SMJ_T(k) { if (threadIdx.x == 0) { const long long tn_ = __builtin_readcyclecounter(); smj_acc[k] += tn_ - smj_t0; smj_t0 = tn_; } }
+#else
+#define SMJ_T(k)
+#endif
+// rot2 / done2: squared relative off-diagonal |<p,q>|^2 / (|p|^2 |q|^2) above
+// which a pair is rotated / above which another sweep follows.  Results that
+// leave in float32 do not need the eigen-decomposition to 1e-13: (1e-18, 1e-10)
+// ends one or two sweeps earlier than the float64 setting (1e-26, 1e-16).
 __device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* flag, int K, int KP,
-                                      const double* warm = nullptr, double* T = nullptr) {
-  if (warm != nullptr) {
-    for (int e = threadIdx.x; e < K * K; e += SM_BT) Vt[(e / K) * KP + (e % K)] = warm[e];
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
-      const int i = e / K, j = e - i * K;
-      double acc = 0;
-      for (int k = 0; k < K; ++k) acc += Vt[i * KP + k] * A[k * KP + j];
-      T[i * KP + j] = acc;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
-      const int i = e / K, j = e - i * K;
-      A[i * KP + j] = T[i * KP + j];
-    }
-  } else {
-    for (int e = threadIdx.x; e < K * K; e += SM_BT) {
-      const int i = e / K, j = e - i * K;
-      Vt[i * KP + j] = (i == j) ? 1.0 : 0.0;
-    }
+                                      const double* warm, double* T, double rot2 = 1e-26,
+                                      double done2 = 1e-16) {
+#ifdef SMJ_STAMP
+  long long smj_t0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) { for (int k = 0; k < 8; ++k) smj_acc[k] = 0; smj_acc[7] = 0; }
+#endif
+  double* A0 = Vt;                       // the original A lives in the Vt slot until the end
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    A0[i * KP + j] = A[i * KP + j];
+    if (warm != nullptr) T[i * KP + j] = warm[e];
+  }
+  __syncthreads();
+  if (warm != nullptr) sm_mm_nn(A, T, A0, K, KP);          // A <- warm A0
+  // squared row norms, kept up to date by the rotations (alpha' = alpha - t
+  // gamma, beta' = beta + t gamma): a round then needs ONE dot product and one
+  // cross-lane reduction instead of three
+  __shared__ double nrm[64];
+  if (threadIdx.x < K) {
+    double s2 = 0;
+    for (int k = 0; k < K; ++k) s2 += A[threadIdx.x * KP + k] * A[threadIdx.x * KP + k];
+    nrm[threadIdx.x] = s2;
   }
   __syncthreads();
   const int KE = (K + 1) & ~1;          // even player count (K odd: one bye)
@@ -178,59 +197,93 @@ __device__ inline void sm_jacobi_rows(double* A, double* Vt, double* lam, int* f
     if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
     for (int r = 0; r < KE - 1; ++r) {
-      int p = -1, q = -1;
+      int p = 0, q = 0;
+      bool on = false;
       if (pair < npairs) {
         if (pair == 0) { p = KE - 1; q = r; }
-        else { p = (r + pair) % (KE - 1); q = (r - pair + KE - 1) % (KE - 1); }
-        if (p >= K || q >= K) { p = -1; q = -1; }   // bye
+        else {
+          p = r + pair; if (p >= KE - 1) p -= KE - 1;
+          q = r - pair; if (q < 0) q += KE - 1;
+        }
+        on = p < K && q < K;                       // else: bye
+        if (!on) { p = 0; q = 0; }
       }
       // this lane's elements k = l8, l8 + 8, ... of both rows stay in registers
-      // for the dot products and the rotation (K <= 64: at most 8 each)
+      // for the dot products and the rotation (K <= 64: at most 8 each); loads
+      // are clamped instead of predicated (no branches on the critical path)
+      SMJ_T(0)
       double xa[8], ya[8];
-      double al = 0, be = 0, ga = 0;
+      double ga = 0;
+      const double al = nrm[p], be = nrm[q];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = l8 + 8 * i;
-        const bool ok = p >= 0 && k < K;
-        xa[i] = ok ? A[p * KP + k] : 0.0;
-        ya[i] = ok ? A[q * KP + k] : 0.0;
-        al += xa[i] * xa[i]; be += ya[i] * ya[i]; ga += xa[i] * ya[i];
+        const int kc = k < K ? k : K - 1;
+        const double xv = A[p * KP + kc], yv = A[q * KP + kc];
+        xa[i] = k < K ? xv : 0.0;
+        ya[i] = k < K ? yv : 0.0;
+        ga += xa[i] * ya[i];
       }
-      al = dpp_sum8(al);
-      be = dpp_sum8(be);
+      SMJ_T(1)
       ga = dpp_sum8(ga);
-      // relative off-diagonal tolerance: eigenvalues to ~1e-13 relative (the
-      // bound is 5e-4 .. 5e-2; a tighter test only chases rounding noise)
-      if (p >= 0 && ga * ga > 1e-26 * (al * be) && ga != 0.0) {
-        // the rotation sits on the critical path of every round (K - 1 rounds
-        // per sweep, one barrier each): Newton-refined hardware reciprocals
-        const double zeta = (be - al) * sm_rcp(2.0 * ga);
-        const double w = fma(zeta, zeta, 1.0);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) * sm_rcp(fabs(zeta) + w * sm_rsq(w));
-        const double c = sm_rsq(fma(t, t, 1.0)), s = c * t;
+      SMJ_T(2)
+      const double g2 = ga * ga, ab = al * be;
+      if (on && g2 > rot2 * ab && ga != 0.0) {
+        // t = gamma / (d + sign(d) sqrt(d^2 + gamma^2)), d = (beta - alpha) / 2:
+        // the smaller root, |t| <= 1.  The rotation sits on the critical path
+        // of every round and float64 operations are slow to depend on here
+        // (~20 cycles each): t only steers the convergence, so its square root
+        // and reciprocal take ONE Newton step (1e-14); c = 1 / sqrt(1 + t^2)
+        // takes two -- c^2 + s^2 = 1 to rounding is what keeps Vt orthogonal.
+        const double d = 0.5 * (be - al);
+        const double h = fma(d, d, g2);
+        double rs = __builtin_amdgcn_rsq(h);
+        rs = fma(fma(-0.5 * h * rs, rs, 0.5), rs, rs);
+        const double den = fabs(d) + h * rs;
+        double it = __builtin_amdgcn_rcp(den);
+        it = fma(fma(-den, it, 1.0), it, it);
+        const double t = (d >= 0 ? ga : -ga) * it;
+        const double c = sm_rsq(fma(t, t, 1.0)), sn = c * t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = l8 + 8 * i;
           if (k < K) {
-            A[p * KP + k] = c * xa[i] - s * ya[i];
-            A[q * KP + k] = s * xa[i] + c * ya[i];
-            const double u = Vt[p * KP + k], v = Vt[q * KP + k];
-            Vt[p * KP + k] = c * u - s * v;
-            Vt[q * KP + k] = s * u + c * v;
+            A[p * KP + k] = c * xa[i] - sn * ya[i];
+            A[q * KP + k] = sn * xa[i] + c * ya[i];
           }
         }
-        if (l8 == 0) *flag = 1;
+        if (l8 == 0) {
+          nrm[p] = al - t * ga;
+          nrm[q] = be + t * ga;
+          atomicMax(flag, g2 > done2 * ab ? 2 : 1);
+        }
       }
+      SMJ_T(3)
       __syncthreads();
+      SMJ_T(4)
     }
-    const int any = *flag;
+    const int lvl = *flag;
     __syncthreads();
-    if (!any) break;
+#ifdef SMJ_STAMP
+    if (threadIdx.x == 0) smj_acc[7] += 1;
+#endif
+    if (lvl < 2) break;
   }
   if (threadIdx.x < K) {
     double s = 0;
     for (int k = 0; k < K; ++k) s += A[threadIdx.x * KP + k] * A[threadIdx.x * KP + k];
     lam[threadIdx.x] = s;
+  }
+  // Vt = A' A0^-1  (Z A0 = A': one solve per row of A')
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    T[i * KP + j] = A[i * KP + j];
+  }
+  __syncthreads();
+  sm_trsm_r(T, A0, K, KP);
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    Vt[i * KP + j] = T[i * KP + j];
   }
   __syncthreads();
 }
