@@ -41,41 +41,71 @@ __device__ inline void sm_mm_tn(double* C, const double* A, const double* B, int
   }
   __syncthreads();
 }
-// X <- L^-1 X   (L lower triangular), one thread per column of X
-__device__ inline void sm_trsm_l(double* X, const double* L, int K, int KP) {
-  if (threadIdx.x < K) {
-    const int c = threadIdx.x;
-    for (int r = 0; r < K; ++r) {
-      double v = X[r * KP + c];
-      for (int k = 0; k < r; ++k) v -= L[r * KP + k] * X[k * KP + c];
-      X[r * KP + c] = v / L[r * KP + r];
+// ---- triangular solves: 4 consecutive lanes (a "quad") per column (or row)
+// of X.  Row by row: each lane of the quad sums every fourth term of
+// sum_k L[r][k] x_k, two quad-permute adds give all four the total, lane 0
+// writes x_r back to LDS where the quad reads it in the next rows (the LDS
+// executes a wave's operations in order: no barrier inside the solve).  The
+// dependent chain per row is one LDS round trip + <= K / 8 FMAs per
+// accumulator instead of the K / 2 of a thread-per-column solve.
+__device__ inline double sm_quad_sum(double v) {
+  v += dpp_perm_f64<0xB1>(v);           // quad_perm [1,0,3,2]
+  v += dpp_perm_f64<0x4E>(v);           // quad_perm [2,3,0,1]
+  return v;
+}
+// UPPER = false: X <- L^-1 X (forward);  UPPER = true: X <- L^-T X (backward).
+// ROWS = false: the systems are the columns of X;  ROWS = true: its rows
+// (UPPER: X <- X L^-1).
+template <bool UPPER, bool ROWS>
+__device__ inline void sm_tri_solve(double* X, const double* L, int K, int KP) {
+  __shared__ double invd[64];
+  __syncthreads();                                       // earlier readers of invd are done
+  if (threadIdx.x < K) invd[threadIdx.x] = 1.0 / L[threadIdx.x * KP + threadIdx.x];
+  __syncthreads();
+  const int c = threadIdx.x >> 2, t = threadIdx.x & 3;
+  const bool live = c < K;
+  const int cc = live ? c : 0;                           // dead quads shadow system 0, never write
+  const int xs = ROWS ? 1 : KP;                          // stride between unknowns of a system
+  double* xb = X + (ROWS ? cc * KP : cc);
+  for (int rr = 0; rr < K; ++rr) {
+    const int r = UPPER ? K - 1 - rr : rr;
+    double a0 = 0, a1 = 0;
+    if (!UPPER) {
+      const double* lr = L + r * KP;
+      int k = t;
+      for (; k + 4 < r; k += 8) {
+        a0 += lr[k] * xb[k * xs];
+        a1 += lr[k + 4] * xb[(k + 4) * xs];
+      }
+      if (k < r) a0 += lr[k] * xb[k * xs];
+    } else {
+      const double* lc = L + r;
+      int k = r + 1 + t;
+      for (; k + 4 < K; k += 8) {
+        a0 += lc[k * KP] * xb[k * xs];
+        a1 += lc[(k + 4) * KP] * xb[(k + 4) * xs];
+      }
+      if (k < K) a0 += lc[k * KP] * xb[k * xs];
     }
+    const double acc = sm_quad_sum(a0 + a1);
+    const double xr = (xb[r * xs] - acc) * invd[r];
+    if (live && t == 0) xb[r * xs] = xr;
+    asm volatile("" ::: "memory");                       // program order of the LDS accesses
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+}
+// X <- L^-1 X   (L lower triangular)
+__device__ inline void sm_trsm_l(double* X, const double* L, int K, int KP) {
+  sm_tri_solve<false, false>(X, L, K, KP);
 }
 // X <- L^-T X
 __device__ inline void sm_trsm_lt(double* X, const double* L, int K, int KP) {
-  if (threadIdx.x < K) {
-    const int c = threadIdx.x;
-    for (int r = K - 1; r >= 0; --r) {
-      double v = X[r * KP + c];
-      for (int k = r + 1; k < K; ++k) v -= L[k * KP + r] * X[k * KP + c];
-      X[r * KP + c] = v / L[r * KP + r];
-    }
-  }
-  __syncthreads();
+  sm_tri_solve<true, false>(X, L, K, KP);
 }
-// X <- X L^-1   (solve Z L = X), one thread per row of X
+// X <- X L^-1   (solve Z L = X: L^T z^T = x^T for every row)
 __device__ inline void sm_trsm_r(double* X, const double* L, int K, int KP) {
-  if (threadIdx.x < K) {
-    const int r = threadIdx.x;
-    for (int j = K - 1; j >= 0; --j) {
-      double v = X[r * KP + j];
-      for (int k = j + 1; k < K; ++k) v -= X[r * KP + k] * L[k * KP + j];
-      X[r * KP + j] = v / L[j * KP + j];
-    }
-  }
-  __syncthreads();
+  sm_tri_solve<true, true>(X, L, K, KP);
 }
 // In-place Cholesky of the lower triangle of S (right-looking); upper part zeroed.
 __device__ inline void sm_cholesky(double* S, int K, int KP) {
