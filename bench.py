@@ -267,15 +267,15 @@ def roofline(agent, critic_ms_in_step):
     from tce_rl_amd.nn import MLP
     for tag, dtype, peak in (("f32", torch.float32, F32_MFMA_PEAK_TF),
                              ("f64", torch.float64, F64_MFMA_PEAK_TF)):
-        wide = MLP("ValueFunction", 21, 1, [256, 256], "orthogonal", 1.0,
+        wide = MLP("ValueFunction", 22, 1, [256, 256], "orthogonal", 1.0,
                    "leaky_relu", None, dtype, torch.device("cuda"))
         n3, t3 = 8192, 100
-        st = torch.randn(n3, t3 + 1, 35, device="cuda", generator=g,
-                         dtype=dtype)[:, :-1, :21]
+        st = torch.randn(n3, t3 + 1, 36, device="cuda", generator=g,
+                         dtype=dtype)[:, :-1, :22]
         rt = torch.randn(n3, t3, device="cuda", generator=g, dtype=dtype)
         runw = critic_ops.make_runner(wide)
         us_w = kernel_time_us(lambda: runw.epoch(st, rt, rt, 0.0), launches=3)
-        fl = 6.0 * (21 * 256 + 256 * 256 + 256) * n3 * t3
+        fl = 6.0 * (22 * 256 + 256 * 256 + 256) * n3 * t3
         extra["critic_256x2_" + tag] = {
             "kernel": "mlpw_chain_kernel + mlpw_grad_kernel + "
                       "mlpw_finish_kernel (<%s, 256>)" % tag,
@@ -287,7 +287,7 @@ def roofline(agent, critic_ms_in_step):
                         pmc_traffic("mlpw_grad_kernel")),
             "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
             "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
-                        "D_in 21 -> 256 -> 256 -> 1, leaky_relu",
+                        "D_in 22 -> 256 -> 256 -> 1, leaky_relu",
             "dtype": tag + (" (v_mfma_f32_16x16x4_f32)" if tag == "f32"
                             else " (v_mfma_f64_16x16x4_f64)")}
         del st, rt, runw, wide

@@ -12,8 +12,8 @@ restatement.
 import torch
 
 KP, KD = 400.0, 40.0
-FAMILY = {500: ("reach", 39), 100: ("push", 20), 350: ("table_tennis", 20),
-          250: ("hopper", 15)}
+FAMILY = {500: ("reach", 39), 100: ("push", 21), 350: ("table_tennis", 21),
+          250: ("hopper", 17)}
 
 
 def initial_object(task, goal3, hand):

@@ -33,8 +33,8 @@ for _ in range(3):
     big.fill_(1.0)
     ops.prodmp_traj(mp, times, w, t0, y0, v0)
 # round 2: wide critic (C3 rows, fp32), env rollout kernel, dof-7 trajectories
-wide = MLP("ValueFunction", 21, 1, [256, 256], "orthogonal", 1.0, "leaky_relu", None, torch.float32, torch.device("cuda"))
-xw = torch.randn(8192, 101, 35, device="cuda", generator=g)[:, :-1, :21]; rw = torch.randn(8192, 100, device="cuda", generator=g)
+wide = MLP("ValueFunction", 22, 1, [256, 256], "orthogonal", 1.0, "leaky_relu", None, torch.float32, torch.device("cuda"))
+xw = torch.randn(8192, 101, 36, device="cuda", generator=g)[:, :-1, :22]; rw = torch.randn(8192, 100, device="cuda", generator=g)
 runw = critic_ops.make_runner(wide)
 for _ in range(3):
     big.fill_(1.0)

@@ -10,14 +10,18 @@
 // the buffer is written once and never re-read for its statistics.
 //
 // HBM-bound: writes (T+1)*D*s B and reads T*2*dof*s B per env (C2: 394 + 66 MB).
-// Mapping: one wave per env, lane = observation column (coalesced D*s-byte row
-// stores); lanes < dof integrate one degree of freedom each; the T steps of an
-// env are a serial recurrence whose per-step latency IS the kernel time (all
-// 4096 waves are resident at once): the hand position and |qd|^2 reach the
-// other lanes by v_readlane / DPP (an LDS round trip per step cost 2 300 cycles
-// of dependent latency, 474 us per episode whatever was stored), the desired
-// trajectory is staged in LDS a block of 16 steps ahead and read one step
-// ahead; 16 waves per CU keep the stores in flight.
+// Mapping: 16 lanes (one DPP row) per env, 4 envs per wave; lanes < dof
+// integrate one degree of freedom each; the other columns that change with the
+// step (object, time, desired row) are packed one per lane, the goal / padding
+// columns are written into the LDS staging rows once (closed-form moments);
+// rows leave in 16-step blocks as a fixed number of 16-byte stores.  The T steps of an env are a serial
+// recurrence whose per-step latency IS the kernel time (every wave is resident):
+// the hand position and |qd|^2 reach the row's lanes by ds_bpermute / DPP (an
+// LDS memory round trip per step cost 2 300 cycles of dependent latency), the
+// desired trajectory is staged in LDS a block of 16 steps ahead and read one
+// step ahead.  (One wave per env -- round-2's first version -- was
+// instruction-bound: 200 instructions per step and env, 17 % of the HBM rate;
+// this one reaches 24 %, 139 of its 243 us being the bare recurrence.)
 //
 // Observation row: [q(dof) | qd(dof) | obj(3) | goal(3) | 0 ... | time |
 //                   des_pos(dof) | des_vel(dof)],   D = d_task + 1 + 2 dof.
@@ -31,44 +35,50 @@ namespace {
 
 enum { FAM_REACH = 0, FAM_PUSH = 1, FAM_TABLE_TENNIS = 2, FAM_HOPPER = 3 };
 
-// value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS
-__device__ inline float lane_bcast(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ inline double lane_bcast(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-// sum over lanes 0..7 of the wave (valid in lanes 0..7)
-__device__ inline float sum8_lo(float v) {
+// sum over the 16 lanes of a DPP row (all 16 get it)
+__device__ inline float row_sum16(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
   return v;
 }
-__device__ inline double sum8_lo(double v) { return dpp_sum8(v); }
+__device__ inline double row_sum16(double v) {
+  v = dpp_sum8(v);
+  v += dpp_perm_f64<0x140>(v);
+  return v;
+}
+// value of lane `src` of my 16-lane row
+__device__ inline float row_get(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ inline double row_get(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-template <typename real>
+constexpr int ENV_LPE = 16;            // lanes per env (one DPP row)
+constexpr int ENV_EPW = 64 / ENV_LPE;  // envs per wave
+
+// NQ: 16-byte pieces per lane and block of the staged rows (>= BS * D / 64);
+// NQ = 0: D is not a multiple of 4, per-step 4-byte column stores instead
+template <typename real, int NQ>
 __global__ __launch_bounds__(64) void env_rollout_kernel(
-    const real* __restrict__ actions, const real* __restrict__ init_obs, int family,
+    const real* __restrict__ actions, const real* __restrict__ init_obs, int family, int64_t N,
     int T, int dof, int d_task, real dt, real kp, real kd,
     real* __restrict__ states, real* __restrict__ rewards,
     uint8_t* __restrict__ flags, real* __restrict__ metrics,
     const real* __restrict__ shift, double* __restrict__ partials) {
-  const int64_t n = blockIdx.x;
   const int c = threadIdx.x;
+  const int g = c & (ENV_LPE - 1), e = c / ENV_LPE;  // lane in the env's row, env of the wave
+  const int64_t n_raw = (int64_t)blockIdx.x * ENV_EPW + e;
+  const bool live = n_raw < N;
+  const int64_t n = live ? n_raw : N - 1;            // dead rows shadow the last env, never store
+  const int rowbase = c & ~(ENV_LPE - 1);
   const int D = d_task + 1 + 2 * dof;
+  const int A = 2 * dof;
   const real* o0 = init_obs + n * D;
-  const real* act = actions + n * (int64_t)T * 2 * dof;
-  // lane roles: c < dof integrates degree of freedom c and owns the columns c
-  // (q) and dof + c (qd) of the row; lanes 2 dof .. D - 1 own one column each
-  // (object, goal, padding, time, desired pos / vel); the rest idles
-  const bool dyn = c < dof;
-  const bool own = c >= 2 * dof && c < D;
-  const int acol = c - d_task - 1;                  // my column inside the action
-  const bool has_a = acol >= 0 && c < D;
-  real q = dyn ? o0[c] : real(0), qd = dyn ? o0[dof + c] : real(0);
+  const real* act = actions + n * (int64_t)T * A;
+  // lane roles inside an env's row: g < dof integrates degree of freedom g and
+  // owns the columns g (q) and dof + g (qd); every lane also owns the columns
+  // 2 dof + g + 16 m < D (object, goal, padding, time, desired pos / vel)
+  const bool dyn = g < dof;
+  real q = dyn ? o0[g] : real(0), qd = dyn ? o0[dof + g] : real(0);
   real obj[3], goal[3], ov[3], hp[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -78,97 +88,151 @@ __global__ __launch_bounds__(64) void env_rollout_kernel(
     ov[j] = family == FAM_TABLE_TENNIS ? -obj[j] / (real(T) * dt) : real(0);
   }
   bool event = false;
-  // moments of my column(s) (shifted by the running mean), row 0 = initial obs
-  const int cb = dyn ? dof + c : c;                 // second column of a dyn lane
-  const double k = (shift && (dyn || own)) ? (double)shift[c] : 0.0;
-  const double kb = (shift && dyn) ? (double)shift[cb] : 0.0;
-  double m1 = 0, m2 = 0, m1b = 0, m2b = 0;
+  // Columns that change with the step besides q / qd: object (3), time, desired
+  // [pos | vel] (2 dof) -- lane g owns number g + 16 md of that list (kind 0..2
+  // obj, 7 time, 8 + k element k of the desired row; -1 none).  The goal and
+  // padding columns never change: they are written into the staging rows once
+  // and their moments are a closed form at the end.
+  constexpr int ENV_MD = 2, ENV_MC = 4;
+  int dcol[ENV_MD], dkind[ENV_MD];
+  double dk_[ENV_MD];
+#pragma unroll
+  for (int md = 0; md < ENV_MD; ++md) {
+    const int j = g + ENV_LPE * md;
+    int col = -1, kind = -1;
+    if (j < 3) { col = 2 * dof + j; kind = j; }
+    else if (j == 3) { col = d_task; kind = 7; }
+    else if (j - 4 < A) { col = d_task + 1 + (j - 4); kind = 8 + (j - 4); }
+    dcol[md] = col;
+    dkind[md] = kind;
+    dk_[md] = (shift && col >= 0) ? (double)shift[col] : 0.0;
+  }
+  int ccol[ENV_MC];
+#pragma unroll
+  for (int m = 0; m < ENV_MC; ++m) {
+    const int col = 2 * dof + 3 + g + ENV_LPE * m;
+    ccol[m] = col < d_task ? col : -1;
+  }
+  const double kq = (shift && dyn) ? (double)shift[g] : 0.0;
+  const double kv = (shift && dyn) ? (double)shift[dof + g] : 0.0;
+  double mq1 = 0, mq2 = 0, mv1 = 0, mv2 = 0, md1[ENV_MD], md2[ENV_MD];
   real* srow = states ? states + n * (int64_t)(T + 1) * D : nullptr;
-  if (dyn || own) {
-    const real x0 = o0[c];
-    if (srow) srow[c] = x0;
-    const double d0 = (double)x0 - k;
-    m1 = d0;
-    m2 = d0 * d0;
-  }
+  // row 0 = the reset observation
   if (dyn) {
-    const real x0 = o0[cb];
-    if (srow) srow[cb] = x0;
-    const double d0 = (double)x0 - kb;
-    m1b = d0;
-    m2b = d0 * d0;
+    const real x0 = o0[g], x1 = o0[dof + g];
+    if (srow && live) { srow[g] = x0; srow[dof + g] = x1; }
+    mq1 = (double)x0 - kq; mq2 = mq1 * mq1;
+    mv1 = (double)x1 - kv; mv2 = mv1 * mv1;
   }
-  // desired trajectory: blocks of BS steps (BS * 2 dof <= 256 floats) come in
-  // with ONE coalesced load per wave, issued a whole block ahead, and are
-  // parked in a wave-private LDS slab; a step's values are read from it one
-  // step ahead of their use.  (Per-step global loads put an L2 round trip,
-  // ~750 ns under load, on every step's critical path.)
+#pragma unroll
+  for (int md = 0; md < ENV_MD; ++md) {
+    md1[md] = 0; md2[md] = 0;
+    if (dcol[md] >= 0) {
+      const real x0 = o0[dcol[md]];
+      if (srow && live) srow[dcol[md]] = x0;
+      md1[md] = (double)x0 - dk_[md]; md2[md] = md1[md] * md1[md];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < ENV_MC; ++m)
+    if (ccol[m] >= 0 && srow && live) srow[ccol[m]] = o0[ccol[m]];
+  // desired trajectory: blocks of BS steps, one coalesced load per env block,
+  // parked in an LDS slab (per wave: 4 envs x BS x 2 dof), read one step ahead
   constexpr int BS = 16;
-  const int A = 2 * dof;
-  __shared__ real slab[2][BS * 16];
+  __shared__ real slab[2][ENV_EPW][BS * 16];
+  // the rows of a block of BS steps are staged here and leave as consecutive
+  // 16-byte pieces once per block (lane = piece: BS * D * s contiguous bytes per
+  // env) -- per-step 4-byte column stores were bound by the number of store
+  // instructions (8 per step and wave), not by bytes
+  __shared__ real stage[ENV_EPW][BS * 64];
+  __shared__ real rstage[ENV_EPW][BS];
+  __shared__ uint8_t fstage[ENV_EPW][BS];
+  constexpr bool wide = NQ > 0;                      // D % 4 == 0: rows start on 16-byte boundaries
+  if (wide) {
+#pragma unroll
+    for (int m = 0; m < ENV_MC; ++m)
+      if (ccol[m] >= 0) {
+        const real xc = o0[ccol[m]];
+        for (int u = 0; u < BS; ++u) stage[e][u * D + ccol[m]] = xc;
+      }
+  }
   typedef real ld4 __attribute__((ext_vector_type(4), aligned(sizeof(real))));
   const int64_t total = (int64_t)T * A;
-  auto fetch_block = [&](int blk) -> ld4 {
-    ld4 v = {0, 0, 0, 0};
-    const int64_t e0 = (int64_t)blk * BS * A + 4 * c;
-    if (4 * c < BS * A) {
-      if (e0 + 3 < total) v = *reinterpret_cast<const ld4*>(act + e0);
-      else
-        for (int j = 0; j < 4; ++j)
-          if (e0 + j < total) v[j] = act[e0 + j];
+  // the env's block = BS * A <= 256 contiguous elements: 16 lanes x 4 x 4
+  struct Blk { ld4 v[4]; };
+  // (pieces past BS * A are never parked, so they stay unwritten; elements past
+  // the episode's end repeat its last one -- clamped, unconditional loads: a
+  // register written on some paths only makes the compiler wait for every
+  // outstanding memory operation at the top of the block loop)
+  auto fetch_block = [&](int blk, Blk& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int el = 4 * (g + ENV_LPE * j);
+      int64_t e0 = (int64_t)blk * BS * A + (el < BS * A ? el : 0);
+      e0 = e0 + 3 < total ? e0 : total - 4;
+      b.v[j] = *reinterpret_cast<const ld4*>(act + e0);
     }
-    return v;
   };
-  auto park_block = [&](int buf, ld4 v) {
-    if (4 * c < BS * A) *reinterpret_cast<ld4*>(&slab[buf][4 * c]) = v;
+  auto park_block = [&](int buf, const Blk& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int el = 4 * (g + ENV_LPE * j);
+      if (el < BS * A) *reinterpret_cast<ld4*>(&slab[buf][e][el]) = b.v[j];
+    }
   };
   const int nblk = (T + BS - 1) / BS;
-  park_block(0, fetch_block(0));
+  Blk nextb;
+  fetch_block(0, nextb);
+  park_block(0, nextb);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   real dist2 = 0;
-  // values of step 0
-  real dp_n = dyn ? slab[0][c] : real(0), dv_n = dyn ? slab[0][dof + c] : real(0);
-  real ac_n = has_a ? slab[0][acol] : real(0);
+  // values of step 0: dp / dv for the dof lanes, the action elements of owned columns
+  real dp_n = dyn ? slab[0][e][g] : real(0), dv_n = dyn ? slab[0][e][dof + g] : real(0);
+  real oa_n[ENV_MD];
+#pragma unroll
+  for (int md = 0; md < ENV_MD; ++md) oa_n[md] = dkind[md] >= 8 ? slab[0][e][dkind[md] - 8] : real(0);
   for (int blk = 0; blk < nblk; ++blk) {
    const int buf = blk & 1;
    const int steps = T - blk * BS < BS ? T - blk * BS : BS;
-   // the next block: loaded and parked here, in one piece (the wait for it
-   // also drains this wave's outstanding stores -- loads and stores share one
-   // in-order counter -- but only once per BS steps; a load result kept in
-   // registers across the steps makes the compiler wait at every step)
-   if (blk + 1 < nblk) park_block(buf ^ 1, fetch_block(blk + 1));
-   asm volatile("" ::: "memory");
-   __builtin_amdgcn_wave_barrier();
+   // the next block's loads are issued here and waited for after the BS steps,
+   // BEFORE this block's rows are flushed: loads and stores share one in-order
+   // counter, a load issued behind the flush would wait for the stores to
+   // reach memory (several us under load, once per block); the steps in
+   // between touch no global memory
+   if (blk + 1 < nblk) fetch_block(blk + 1, nextb);
    for (int u = 0; u < steps; ++u) {
     const int i = blk * BS + u;
-    const real dp_i = dp_n, dv_i = dv_n, ac_i = ac_n;
-    {                                                // read step i + 1 from the slab
-      const int un = u + 1 < steps ? u + 1 : 0;
-      const real* sb = slab[u + 1 < steps ? buf : buf ^ 1] + un * A;
-      if (dyn) { dp_n = sb[c]; dv_n = sb[dof + c]; }
-      if (has_a) ac_n = sb[acol];
+    const real dp_i = dp_n, dv_i = dv_n;
+    real oa_i[ENV_MD];
+#pragma unroll
+    for (int md = 0; md < ENV_MD; ++md) oa_i[md] = oa_n[md];
+    if (u + 1 < steps) {                             // read step i + 1 from the slab
+      const real* sb = slab[buf][e] + (u + 1) * A;
+      if (dyn) { dp_n = sb[g]; dv_n = sb[dof + g]; }
+#pragma unroll
+      for (int md = 0; md < ENV_MD; ++md)
+        if (dkind[md] >= 8) oa_n[md] = sb[dkind[md] - 8];
     }
     if (dyn) {                                       // PD-tracked point mass
       const real a = kp * (dp_i - q) + kd * (dv_i - qd);
       qd = qd + dt * a;
       q = q + dt * qd;
     }
-    // hand = q[:3] and |qd|^2 to every lane: lane broadcasts / DPP, no LDS
+    // hand = q[:3] and |qd|^2 to every lane of the env's row
     real h[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) h[j] = lane_bcast(q, j);
-    const real v2 = lane_bcast(sum8_lo(dyn ? qd * qd : real(0)), 0);
+    for (int j = 0; j < 3; ++j) h[j] = row_get(q, rowbase + j);
+    const real v2 = row_sum16(dyn ? qd * qd : real(0));
     const real t = real(i + 1) * dt;
     real rew;
     if (family == FAM_PUSH) {
       real c2 = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) c2 += (hp[j] - obj[j]) * (hp[j] - obj[j]);
-      if (c2 < real(0.01)) {                         // in contact: carried along
+      const bool touch = c2 < real(0.01);            // in contact: carried along
 #pragma unroll
-        for (int j = 0; j < 3; ++j) obj[j] += h[j] - hp[j];
-      }
+      for (int j = 0; j < 3; ++j) obj[j] += touch ? h[j] - hp[j] : real(0);
       real g2 = 0, o2 = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -183,11 +247,13 @@ __global__ __launch_bounds__(64) void env_rollout_kernel(
       real b2 = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) b2 += (h[j] - obj[j]) * (h[j] - obj[j]);
-      if (!event && b2 < real(0.04)) {               // racket meets the ball
-        event = true;
+      const bool hit = !event && b2 < real(0.04);    // racket meets the ball
+      real qv[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ov[j] = lane_bcast(qd, j);
-      }
+      for (int j = 0; j < 3; ++j) qv[j] = row_get(qd, rowbase + j);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ov[j] = hit ? qv[j] : ov[j];
+      event = event || hit;
       real g2 = 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) g2 += (obj[j] - goal[j]) * (obj[j] - goal[j]);
@@ -203,61 +269,121 @@ __global__ __launch_bounds__(64) void env_rollout_kernel(
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) hp[j] = h[j];
-    real* orow = srow ? srow + (int64_t)(i + 1) * D : nullptr;
-    if (dyn || own) {
-      real x;
-      if (dyn) x = q;
-      else if (c < 2 * dof + 3) x = c == 2 * dof ? obj[0] : (c == 2 * dof + 1 ? obj[1] : obj[2]);
-      else if (c < 2 * dof + 6) x = c == 2 * dof + 3 ? goal[0] : (c == 2 * dof + 4 ? goal[1] : goal[2]);
-      else if (c < d_task) x = 0;
-      else if (c == d_task) x = t;
-      else x = ac_i;
-#if !(ENV_SKIP & 1)
-      if (orow) orow[c] = x;
-#endif
-#if !(ENV_SKIP & 2)
-      const double d = (double)x - k;
-      m1 += d;
-      m2 += d * d;
-#else
-      m1 += (double)x;
-#endif
-    }
+    real* orow = (srow && live) ? srow + (int64_t)(i + 1) * D : nullptr;
     if (dyn) {
 #if !(ENV_SKIP & 1)
-      if (orow) orow[cb] = qd;
+      if (wide) { stage[e][u * D + g] = q; stage[e][u * D + dof + g] = qd; }
+      else if (orow) { orow[g] = q; orow[dof + g] = qd; }
 #endif
 #if !(ENV_SKIP & 2)
-      const double d = (double)qd - kb;
-      m1b += d;
-      m2b += d * d;
+      const double d1 = (double)q - kq, d2 = (double)qd - kv;
+      mq1 += d1; mq2 += d1 * d1;
+      mv1 += d2; mv2 += d2 * d2;
 #endif
+    }
+#pragma unroll
+    for (int md = 0; md < ENV_MD; ++md) {
+      if (dkind[md] >= 0) {
+        const int kd_ = dkind[md];
+        real x;
+        if (kd_ < 3) x = kd_ == 0 ? obj[0] : (kd_ == 1 ? obj[1] : obj[2]);
+        else if (kd_ == 7) x = t;
+        else x = oa_i[md];
+#if !(ENV_SKIP & 1)
+        if (wide) stage[e][u * D + dcol[md]] = x;
+        else if (orow) orow[dcol[md]] = x;
+#endif
+#if !(ENV_SKIP & 2)
+        const double d = (double)x - dk_[md];
+        md1[md] += d; md2[md] += d * d;
+#endif
+      }
+    }
+    if (!wide && orow) {                             // the never-changing columns
+#pragma unroll
+      for (int m = 0; m < ENV_MC; ++m)
+        if (ccol[m] >= 0) orow[ccol[m]] = o0[ccol[m]];
     }
 #if !(ENV_SKIP & 4)
-    if (c == 0) {
-      rewards[n * (int64_t)T + i] = rew;
-      if (flags) flags[n * (int64_t)T + i] = event ? 1 : 0;
+    if (g == 0) {
+      rstage[e][u] = rew;
+      fstage[e][u] = event ? 1 : 0;
     }
 #else
-    if (c == 0 && i == T - 1) rewards[n * (int64_t)T + i] = rew;
+    if (g == 0 && live && i == T - 1) rewards[n * (int64_t)T + i] = rew;
 #endif
    }
+   // ---- park the next block and take its first step's values
+   if (blk + 1 < nblk) {
+     park_block(buf ^ 1, nextb);
+     asm volatile("" ::: "memory");
+     __builtin_amdgcn_wave_barrier();
+     const real* sb = slab[buf ^ 1][e];
+     if (dyn) { dp_n = sb[g]; dv_n = sb[dof + g]; }
+#pragma unroll
+     for (int md = 0; md < ENV_MD; ++md)
+       if (dkind[md] >= 8) oa_n[md] = sb[dkind[md] - 8];
+   }
+   // ---- flush the block: rows i0 + 1 .. i0 + steps of the state buffer,
+   // rewards and flags of steps i0 .. i0 + steps - 1
+   asm volatile("" ::: "memory");
+   __builtin_amdgcn_wave_barrier();
+   {
+     // a FIXED number of unconditional stores per block (pieces past the end
+     // repeat the last one; rows of dead envs repeat env N - 1's, same values):
+     // the compiler can then count them (s_waitcnt vmcnt(n)) and the next
+     // block's loads do not wait for these stores to reach memory
+     const int i0 = blk * BS;
+#if !(ENV_SKIP & 1)
+     if (wide && srow) {
+       real* dst = srow + (int64_t)(i0 + 1) * D;
+       const int n4 = steps * D / 4;
+       typedef real st4 __attribute__((ext_vector_type(4), aligned(4 * sizeof(real))));
+#pragma unroll
+       for (int qq = 0; qq < (NQ > 0 ? NQ : 1); ++qq) {
+         int p4 = g + ENV_LPE * qq;
+         p4 = p4 < n4 ? p4 : n4 - 1;
+         *reinterpret_cast<st4*>(dst + 4 * p4) = *reinterpret_cast<const st4*>(&stage[e][4 * p4]);
+       }
+     }
+#endif
+#if !(ENV_SKIP & 4)
+     {
+       const int gg = g < steps ? g : steps - 1;
+       rewards[n * (int64_t)T + i0 + gg] = rstage[e][gg];
+       if (flags) flags[n * (int64_t)T + i0 + gg] = fstage[e][gg];
+     }
+#endif
+   }
+   asm volatile("" ::: "memory");
+   __builtin_amdgcn_wave_barrier();
   }
-  if (c == 0 && metrics) {
+  if (g == 0 && live && metrics) {
     const real lim = family == FAM_TABLE_TENNIS ? real(0.09) : real(0.0025);
     const bool ok = dist2 < lim && (family != FAM_TABLE_TENNIS || event);
     metrics[2 * n] = ok ? real(1) : real(0);
     metrics[2 * n + 1] = sqrt(dist2);
   }
-  if (partials) {
-    if (dyn || own) {
-      partials[(n * D + c) * 2 + 0] = m1;
-      partials[(n * D + c) * 2 + 1] = m2;
-    }
+  if (partials && live) {
     if (dyn) {
-      partials[(n * D + cb) * 2 + 0] = m1b;
-      partials[(n * D + cb) * 2 + 1] = m2b;
+      partials[(n * D + g) * 2 + 0] = mq1;
+      partials[(n * D + g) * 2 + 1] = mq2;
+      partials[(n * D + dof + g) * 2 + 0] = mv1;
+      partials[(n * D + dof + g) * 2 + 1] = mv2;
     }
+#pragma unroll
+    for (int md = 0; md < ENV_MD; ++md)
+      if (dcol[md] >= 0) {
+        partials[(n * D + dcol[md]) * 2 + 0] = md1[md];
+        partials[(n * D + dcol[md]) * 2 + 1] = md2[md];
+      }
+#pragma unroll
+    for (int m = 0; m < ENV_MC; ++m)
+      if (ccol[m] >= 0) {                              // T + 1 equal rows
+        const double d = (double)o0[ccol[m]] - (shift ? (double)shift[ccol[m]] : 0.0);
+        partials[(n * D + ccol[m]) * 2 + 0] = (double)(T + 1) * d;
+        partials[(n * D + ccol[m]) * 2 + 1] = (double)(T + 1) * d * d;
+      }
   }
 }
 
@@ -308,10 +434,34 @@ extern "C" {
     TCE_CHECK_ARG(d_task >= 2 * dof + 6 && d_task + 1 + 2 * dof <= 64,             \
                   "env_rollout: 2 dof + 6 <= d_task and D <= 64");                 \
     TCE_CHECK_ARG(N < (1ll << 31), "env_rollout: too many envs");                  \
-    hipLaunchKernelGGL(env_rollout_kernel<REAL>, dim3((unsigned)N), dim3(64), 0,   \
-                       (hipStream_t)stream, actions, init_obs, family, T, dof,     \
-                       d_task, dt, kp, kd, states, rewards, event_flags, metrics,  \
-                       shift, moment_partials);                                    \
+    const int need = (16 * (d_task + 1 + 2 * dof) + 63) / 64;                      \
+    const dim3 grid((unsigned)((N + ENV_EPW - 1) / ENV_EPW));                      \
+    hipStream_t st = (hipStream_t)stream;                                          \
+    if ((d_task + 1 + 2 * dof) % 4 != 0)                                           \
+      hipLaunchKernelGGL((env_rollout_kernel<REAL, 0>), grid, dim3(64), 0, st,     \
+                         actions, init_obs, family, N, T, dof, d_task, dt, kp, kd, \
+                         states, rewards, event_flags, metrics, shift,             \
+                         moment_partials);                                         \
+    else if (need <= 6)                                                            \
+      hipLaunchKernelGGL((env_rollout_kernel<REAL, 6>), grid, dim3(64), 0, st,     \
+                         actions, init_obs, family, N, T, dof, d_task, dt, kp, kd, \
+                         states, rewards, event_flags, metrics, shift,             \
+                         moment_partials);                                         \
+    else if (need <= 9)                                                            \
+      hipLaunchKernelGGL((env_rollout_kernel<REAL, 9>), grid, dim3(64), 0, st,     \
+                         actions, init_obs, family, N, T, dof, d_task, dt, kp, kd, \
+                         states, rewards, event_flags, metrics, shift,             \
+                         moment_partials);                                         \
+    else if (need <= 12)                                                           \
+      hipLaunchKernelGGL((env_rollout_kernel<REAL, 12>), grid, dim3(64), 0, st,    \
+                         actions, init_obs, family, N, T, dof, d_task, dt, kp, kd, \
+                         states, rewards, event_flags, metrics, shift,             \
+                         moment_partials);                                         \
+    else                                                                           \
+      hipLaunchKernelGGL((env_rollout_kernel<REAL, 16>), grid, dim3(64), 0, st,    \
+                         actions, init_obs, family, N, T, dof, d_task, dt, kp, kd, \
+                         states, rewards, event_flags, metrics, shift,             \
+                         moment_partials);                                         \
     TCE_LAUNCH_CHECK();                                                            \
     return 0;                                                                      \
   }                                                                                \

@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 # task, dof, d_task, T, dt  (the stand-in dimensions of tce_rl_amd/envs)
 CASES = {
     "reach": ("reach", 4, 39, 500, 0.0125),
-    "push": ("push", 7, 20, 100, 0.02),
+    "push": ("push", 7, 21, 100, 0.02),
     "push_mw": ("push", 4, 39, 500, 0.0125),
-    "table_tennis": ("table_tennis", 7, 20, 350, 0.008),
-    "hopper": ("hopper", 3, 15, 250, 0.008),
+    "table_tennis": ("table_tennis", 7, 21, 350, 0.008),
+    "hopper": ("hopper", 3, 17, 250, 0.008),
+    "push_odd_obs": ("push", 7, 20, 100, 0.02),       # D = 35: the 4-byte store path
 }
 
 
