@@ -104,7 +104,10 @@ int tce_segment_accrew_f64(const double* rewards, const int64_t* pairs, int P,
  * exactly these times / init_time (left there by an earlier call: the table is
  * not rebuilt -- one rollout or update evaluates the same grid ~100 times);
  * pair log-prob only, bit 2 set: `work` still holds the per-pair factors of
- * this very L from the forward call (the backward then skips that kernel).
+ * this very L from the forward call (the backward then skips that kernel);
+ * bit 3 set (with bit 0 clear, shared L): the caller has checked on the host
+ * that all init_time are equal, so the general-path kernels -- which exit at
+ * once on the device in that case -- are not launched at all.
  * out [N, T, 2*dof] = cat[pos, vel].
  */
 int tce_times_f32(const float* init_time, float off_first, float off_last,
@@ -351,6 +354,90 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
                       const double* L_new, const double* L_old, const double* L_proj, int64_t N,
                       int K, double tr_coeff, int tr_include_cov, double* out16,
                       double* grad_mean, double* grad_L, double* ws, void* stream);
+
+/* The whole objective of one TCE policy epoch and its gradient in ONE call
+ * (shared covariance, KL projection; mprl/rl/agent/temporal_correlated_agent.py:
+ * 523-612): mean projection -> covariance projection -> pair log-prob ->
+ * surrogate -> their backward passes -> KL diagnostics / entropy / trust
+ * region loss, i.e. tce_vec_env(mode 1), tce_kl_cov_proj_fwd, tce_pair_logprob_fwd,
+ * tce_surrogate, tce_pair_logprob_bwd, tce_kl_shared, tce_vec_env bwd,
+ * tce_kl_cov_proj_bwd with the arguments those take.  The single-workgroup
+ * K x K kernels run on a library-owned second stream beside the per-env kernels
+ * (fork / join by events on `stream`; works under stream capture).
+ * Outputs: grad_mean [N,K], grad_L [K,K] = d(surrogate + trust region loss
+ * - ent_coef * entropy) / d(mean_new, L_new); sur2 [2] as tce_surrogate; out16
+ * as tce_kl_shared.  ws: scratch of tce_policy_objective_ws_len(N, K, P)
+ * elements; pair_work / basis_ws / flag_ws / proj_ctx / sur_ws / kl_ws as in
+ * the separate calls (times_flags_fwd / _bwd: the times_flags of the two pair
+ * log-prob calls).  proj_started != 0: see tce_policy_objective_begin_*;
+ * defer_join != 0: see tce_policy_objective_end_*. */
+int64_t tce_policy_objective_ws_len(int64_t N, int K, int P);
+int tce_policy_objective_f32(
+    const float* mean_new, const float* L_new, const float* mean_old, const float* L_old,
+    const float* traj, const float* logp_old, const float* adv, const int64_t* pairs,
+    const float* tab, int M, int nbg, float tau, float delay, float scaled_dt,
+    float inv_scale_g, int rel_goal, const float* times, int times_flags_fwd,
+    int times_flags_bwd, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, float* basis_ws, int* flag_ws, float* pair_work,
+    float eps_mean, double eps_cov, const float* beta, int entropy_eq, double* proj_ctx,
+    float tr_coeff, int tr_include_cov, float ent_coef, double* sur_ws, double* kl_ws,
+    float* ws, float* grad_mean, float* grad_L, float* sur2, float* out16, int64_t N, int T,
+    int P, int dof, int K, int proj_started, int defer_join, void* stream);
+int tce_policy_objective_f64(
+    const double* mean_new, const double* L_new, const double* mean_old, const double* L_old,
+    const double* traj, const double* logp_old, const double* adv, const int64_t* pairs,
+    const double* tab, int M, int nbg, double tau, double delay, double scaled_dt,
+    double inv_scale_g, int rel_goal, const double* times, int times_flags_fwd,
+    int times_flags_bwd, const double* init_time, const double* init_pos,
+    const double* init_vel, double reg, double* basis_ws, int* flag_ws, double* pair_work,
+    double eps_mean, double eps_cov, const double* beta, int entropy_eq, double* proj_ctx,
+    double tr_coeff, int tr_include_cov, double ent_coef, double* sur_ws, double* kl_ws,
+    double* ws, double* grad_mean, double* grad_L, double* sur2, double* out16, int64_t N,
+    int T, int P, int dof, int K, int proj_started, int defer_join, void* stream);
+/* Optional first half: the Cholesky head (tce_chol_build_fwd of var_vec -> L_new
+ * [K,K]) and the covariance projection of the coming tce_policy_objective call
+ * (same ws / proj_ctx / N / K / P, proj_started = 1, L_new = this output) are
+ * put on the second stream at once -- they depend on the variance parameters
+ * only and run beside whatever `stream` does until that call (the forward pass
+ * of the mean net). */
+int tce_policy_objective_begin_f32(const float* var_vec, int nvec, float min_std,
+                                   const float* L_old, double eps_cov, const float* beta,
+                                   int entropy_eq, double* proj_ctx, float* L_new, float* ws,
+                                   int64_t N, int K, int P, void* stream);
+int tce_policy_objective_begin_f64(const double* var_vec, int nvec, double min_std,
+                                   const double* L_old, double eps_cov, const double* beta,
+                                   int entropy_eq, double* proj_ctx, double* L_new,
+                                   double* ws, int64_t N, int K, int P, void* stream);
+/* Optional last half (defer_join != 0 in tce_policy_objective): that call then
+ * returns with grad_mean complete but the side stream still working on the
+ * backward pass of the covariance projection -- grad_L holds the trust-region
+ * part only -- so that `stream` can go on with the mean net's backward pass;
+ * this call joins the side stream and adds the missing part to grad_L.  It must
+ * follow every deferred call (before the next objective call, and before the
+ * end of a stream capture). */
+int tce_policy_objective_end_f32(float* grad_L, float* ws, int64_t N, int K, int P,
+                                 void* stream);
+int tce_policy_objective_end_f64(double* grad_L, double* ws, int64_t N, int K, int P,
+                                 void* stream);
+
+/* Gradient of a final Linear layer y = h W^T + b (the mean net's output layer,
+ * mprl/util/util_nn.py:225-246 under autograd) from grad_out = dL/dy [N,K] and
+ * hidden = h [N,H]: grad_W [K,H] = grad_out^T h, grad_b [K] = sum_n grad_out.
+ * K <= 64, H <= 256; ws: real [tce_out_layer_grad_ws_len(N, K, H)].
+ * policy_record: the per-epoch record row {surrogate, entropy loss, trust
+ * region loss, total, entropy, |g|, |g| clipped, 12 KL means} (the quantities
+ * temporal_correlated_agent.py:598-636 appends per epoch) from the outputs of
+ * tce_policy_objective and the optimizer's two gradient norms, without a host
+ * round trip. */
+int64_t tce_out_layer_grad_ws_len(int64_t N, int K, int H);
+int tce_out_layer_grad_f32(const float* grad_out, const float* hidden, float* grad_W,
+                           float* grad_b, float* ws, int64_t N, int K, int H, void* stream);
+int tce_out_layer_grad_f64(const double* grad_out, const double* hidden, double* grad_W,
+                           double* grad_b, double* ws, int64_t N, int K, int H, void* stream);
+int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
+                          float ent_coef, float* row19, void* stream);
+int tce_policy_record_f64(const double* sur2, const double* out16, const double* norms2,
+                          double ent_coef, double* row19, void* stream);
 
 /* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
  * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->

@@ -15,6 +15,7 @@
 // find for eta on the eigenvalues, reassemble, Cholesky; the backward pass is
 // the closed-form implicit gradient in the eigenbasis.
 #include "smallmat.h"
+#include "lanevec.h"
 
 namespace {
 
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256) void chol_build_bwd_kernel(const real* __restr
 //         bwd: dx = g/s - (g.delta) q / (2 eps s^3)   (active), g (inactive)
 // MODE 2: log N(x; y, L L^T)               bwd: dy = g q (dx unused), and
 //           dL = g (q d^T - diag(1/L_ii)) per env (lower triangle)
-// One thread per env; a shared L is staged in LDS.
+// A per-env L (contextual covariance): one thread per env (vec_env_kernel); a
+// shared L (sL = 0, every shipped config): one wave per env, lane = vector
+// element (vec_env_shared_kernel, lanevec.h).
 // ---------------------------------------------------------------------------
 constexpr int VE_MAXK = 64;
 
@@ -91,18 +94,12 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
     int64_t sL, real eps, const real* __restrict__ gout, real* __restrict__ out,
     real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // LDS: d[K][64] | q[K][64] (lane = env: conflict free) | shared L [K][K]
+  // LDS: d[K][64] | q[K][64] (lane = env: conflict free)
   real* dS = reinterpret_cast<real*>(smem_raw);
   real* qS = dS + K * 64;
-  real* Ls = qS + K * 64;
-  const bool shared = (sL == 0);
-  if (shared) {
-    for (int e = threadIdx.x; e < K * K; e += 64) Ls[e] = L[e];
-    __syncthreads();
-  }
   const int64_t n = blockIdx.x * 64ll + threadIdx.x;
   if (n >= N) return;
-  const real* Ln = shared ? Ls : L + n * sL;
+  const real* Ln = L + n * sL;
   real* d = dS + threadIdx.x;          // d[k] -> d[k * 64]
   real quad = 0, logdet = 0;
 #pragma unroll 1
@@ -164,6 +161,102 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
           if (c <= r) v = g * (q[r * 64] * d[c * 64] - (r == c ? real(1) / Ln[r * K + r] : real(0)));
           gl[r * K + c] = v;
         }
+    }
+  }
+}
+
+// Shared L: wave = env (VS_EPW envs per wave, two at a time), lane = element.
+constexpr int VS_BT = 256, VS_EPW = 4, VS_EPB = (VS_BT / 64) * VS_EPW;
+
+template <typename real, int MODE, bool BWD>
+__global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
+    const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
+    real eps, const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gx,
+    real* __restrict__ gLout, int64_t N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* Ls = reinterpret_cast<real*>(smem_raw);               // [K][KP]
+  const int KP = sm_pitch(K);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < K * K; e += VS_BT) {
+    const int i = e / K, j = e - i * K;
+    Ls[i * KP + j] = L[e];
+  }
+  __syncthreads();
+  const bool in = lane < K;
+  const real lkk = in ? Ls[lane * KP + lane] : real(1);
+  const real rdk = in ? real(1) / lkk : real(0);
+  real logdet = 0;
+  if (MODE == 2) logdet = wave_sum(in ? log(lkk) : real(0));
+  const int64_t n0 = (int64_t)blockIdx.x * VS_EPB + wave * VS_EPW;
+  for (int i0 = 0; i0 < VS_EPW; i0 += 2) {
+    if (n0 + i0 >= N) break;
+    int64_t n[2] = {n0 + i0, n0 + i0 + 1};
+    const bool ok1 = n[1] < N;
+    if (!ok1) n[1] = n[0];                                    // the pair's second env repeats the first
+    real xv[2], yv[2], d[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      xv[s] = in ? x[n[s] * K + lane] : real(0);
+      yv[s] = in ? y[n[s] * K + lane] : real(0);
+      d[s] = xv[s] - yv[s];
+    }
+    const real* const Lp[2] = {Ls, Ls};
+    const real rd[2] = {rdk, rdk};
+    lv_solve_lower<real, 2>(d, Lp, rd, K, KP, lane);
+    real quad[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) quad[s] = wave_sum(d[s] * d[s]);
+    if (!BWD) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s == 1 && !ok1) break;
+        if (MODE == 0 && lane == 0) out[n[s]] = quad[s];
+        if (MODE == 2 && lane == 0)
+          out[n[s]] = real(-0.5) * quad[s] - logdet - real(0.5 * LOG_2PI) * (real)K;
+        if (MODE == 1 && in) {
+          const real m = real(0.5) * quad[s];
+          real o = xv[s];
+          if (m > eps) {
+            const real om = sqrt(m / eps) - real(1);
+            o = (xv[s] + om * yv[s]) / (real(1) + om + real(1e-16));
+          }
+          out[n[s] * K + lane] = o;
+        }
+      }
+      continue;
+    }
+    // backward: q = L^-T d
+    real q[2] = {d[0], d[1]};
+    lv_solve_lower_t<real, 2>(q, Lp, rd, K, KP, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 1 && !ok1) break;
+      if (MODE == 0) {
+        if (in) gx[n[s] * K + lane] = real(2) * gout[n[s]] * q[s];
+      } else if (MODE == 1) {
+        const real go = in ? gout[n[s] * K + lane] : real(0);
+        const real m = real(0.5) * quad[s];
+        real o = go;
+        if (m > eps) {                                        // uniform over the wave
+          const real sc = sqrt(m / eps);
+          const real gd = wave_sum(go * (xv[s] - yv[s]));
+          const real coef = gd / (real(2) * eps * sc * sc * sc);
+          o = go / sc - coef * q[s];
+        }
+        if (in) gx[n[s] * K + lane] = o;
+      } else {
+        const real g = gout[n[s]];
+        if (in) gx[n[s] * K + lane] = g * q[s];               // d logp / d mean
+        if (gLout) {
+          real* gl = gLout + n[s] * (int64_t)K * K;
+          for (int r = 0; r < K; ++r) {
+            const real qr = lv_bcast(q[s], r);
+            real v = 0;
+            if (lane <= r) v = g * (qr * d[s] - (lane == r ? rdk : real(0)));
+            if (in) gl[r * K + lane] = v;
+          }
+        }
+      }
     }
   }
 }
@@ -470,6 +563,41 @@ int set_lds(F kern, size_t lds) {
   return 0;
 }
 
+
+template <typename real, int MODE, bool BWD>
+int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, real eps,
+                      const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
+                      hipStream_t st) {
+  if (sL == 0) {
+    const size_t lds = (size_t)K * sm_pitch(K) * sizeof(real);
+    set_lds(vec_env_shared_kernel<real, MODE, BWD>, lds);
+    hipLaunchKernelGGL((vec_env_shared_kernel<real, MODE, BWD>),
+                       dim3((unsigned)ceil_div(N, VS_EPB)), dim3(VS_BT), lds, st, x, y, L, eps,
+                       gout, out, gx, gL, N, K);
+  } else {
+    const size_t lds = 2 * (size_t)K * 64 * sizeof(real);
+    set_lds(vec_env_kernel<real, MODE, BWD>, lds);
+    hipLaunchKernelGGL((vec_env_kernel<real, MODE, BWD>), dim3((unsigned)ceil_div(N, 64)),
+                       dim3(64), lds, st, x, y, L, sL, eps, gout, out, gx, gL, N, K);
+  }
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename real>
+int vec_env_launch(int mode, int bwd, const real* x, const real* y, const real* L, int64_t sL,
+                   real eps, const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
+                   hipStream_t st) {
+#define VE_CASE(M, B)                                                                       \
+  if (mode == M && (bwd != 0) == B)                                                         \
+    return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st);
+  VE_CASE(0, false) VE_CASE(0, true) VE_CASE(1, false) VE_CASE(1, true) VE_CASE(2, false)
+  VE_CASE(2, true)
+#undef VE_CASE
+  tce_set_error("vec_env: unknown mode");
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -509,46 +637,8 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
                   "vec_env: bad arguments (K <= 64)");                            \
     TCE_CHECK_ARG(bwd ? (grad_out && grad_x) : (out != nullptr),                  \
                   "vec_env: null output");                                        \
-    const unsigned nb = (unsigned)ceil_div(N, 64);                                \
-    const size_t lds = (2 * (size_t)K * 64 + (L_stride == 0 ? (size_t)K * K : 0)) \
-                       * sizeof(REAL);                                            \
-    hipStream_t st = (hipStream_t)stream;                                         \
-    if (mode == 0 && !bwd)                                                        \
-      { set_lds(vec_env_kernel<REAL, 0, false>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 0, false>), dim3(nb), dim3(64),    \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else if (mode == 0)                                                           \
-      { set_lds(vec_env_kernel<REAL, 0, true>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 0, true>), dim3(nb), dim3(64),     \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else if (mode == 1 && !bwd)                                                   \
-      { set_lds(vec_env_kernel<REAL, 1, false>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 1, false>), dim3(nb), dim3(64),    \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else if (mode == 1)                                                           \
-      { set_lds(vec_env_kernel<REAL, 1, true>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 1, true>), dim3(nb), dim3(64),     \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else if (mode == 2 && !bwd)                                                   \
-      { set_lds(vec_env_kernel<REAL, 2, false>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 2, false>), dim3(nb), dim3(64),    \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else if (mode == 2)                                                           \
-      { set_lds(vec_env_kernel<REAL, 2, true>, lds);                                  \
-      hipLaunchKernelGGL((vec_env_kernel<REAL, 2, true>), dim3(nb), dim3(64),     \
-                         lds, st, x, y, L, L_stride, eps, grad_out, out, grad_x,  \
-                         grad_L, N, K); }                                           \
-    else {                                                                        \
-      tce_set_error("vec_env: unknown mode");                                     \
-      return 1;                                                                   \
-    }                                                                             \
-    TCE_LAUNCH_CHECK();                                                           \
-    return 0;                                                                     \
+    return vec_env_launch<REAL>(mode, bwd, x, y, L, L_stride, eps, grad_out, out,   \
+                                grad_x, grad_L, N, K, (hipStream_t)stream);         \
   }                                                                               \
   int tce_kl_cov_part_##SFX(int bwd, const REAL* L, const REAL* L_old,            \
                             int64_t L_old_stride, const REAL* grad_out,           \

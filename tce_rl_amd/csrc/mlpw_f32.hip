@@ -25,7 +25,7 @@ int64_t tce_mlpw_num_params(int din, int hidden) { return mlpw_num_params(din, h
 
 // workspace elements: W2 images + (backward) H1, dY2, dY1 [R][hidden]
 int64_t tce_mlpw_workspace_len(int64_t R, int hidden, int backward) {
-  return 2 * (int64_t)hidden * hidden + (backward ? 3 * R * hidden : 0);
+  return 2 * (int64_t)hidden * hidden + (backward ? 3 * mlpw_ws_rows(R) * hidden : 0);
 }
 
 }  // extern "C"

@@ -55,11 +55,13 @@ template <> struct WV<float> {
   typedef float v4 __attribute__((ext_vector_type(4), aligned(16)));
   typedef float v2 __attribute__((ext_vector_type(2), aligned(8)));
   typedef float acc __attribute__((ext_vector_type(4)));
+  typedef v4 chunk;                                          // 16 bytes
 };
 template <> struct WV<double> {
   typedef double v4 __attribute__((ext_vector_type(4), aligned(16)));
   typedef double v2 __attribute__((ext_vector_type(2), aligned(16)));
   typedef double acc __attribute__((ext_vector_type(4)));
+  typedef v2 chunk;                                          // 16 bytes
 };
 
 __device__ inline WV<float>::acc wmfma(float a, float b, WV<float>::acc c) {
@@ -150,6 +152,9 @@ struct WCfg {
   static constexpr int KC = sizeof(real) == 4 ? 16 : 8;     // gradient kernel: rows per stage
 };
 
+// rows of the [rows][H] workspaces: R rounded up to whole tiles of either type
+__host__ __device__ inline int64_t mlpw_ws_rows(int64_t R) { return (R + 127) / 128 * 128; }
+
 __host__ __device__ inline int64_t mlpw_num_params(int din, int H) {
   return (int64_t)H * din + H + (int64_t)H * H + H + H + 1;
 }
@@ -205,6 +210,9 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
   constexpr int WP = H + WCfg<real>::WPAD;
   constexpr int NTILE = WCfg<real>::NTILE;
   constexpr int NJ = H / 16;
+  // (fp64: two lanes of every ds_read_b128 group meet on a bank whatever the
+  // pitch; a pair-swap of the 32-byte pieces of rows 4..11 removes that and
+  // changed nothing measurable -- the LDS is not the limit here)
   const real* p = pan + m * WP + 4 * g;
   if (NTILE == 1) {
     // one output tile: two interleaved accumulation chains over the even / odd
@@ -216,16 +224,25 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
 #pragma unroll
     for (int Jk = 0; Jk < NJ; Jk += 2) {
       const int b = (Jk >> 1) & 1;
+      // the next block's fragments are requested behind this block's first
+      // MFMAs: the wait at the top of the next block finds them there
+#pragma unroll
+      for (int i = 0; i < 1; ++i) {
+        acc[0] = wmfma(A[b][0][i], bop[Jk][i], acc[0]);
+        alt = wmfma(A[b][1][i], bop[Jk + 1][i], alt);
+      }
+      wfence();
       if (Jk + 2 < NJ) {
         A[b ^ 1][0] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 2));
         A[b ^ 1][1] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 3));
       }
       wfence();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 1; i < 4; ++i) {
         acc[0] = wmfma(A[b][0][i], bop[Jk][i], acc[0]);
         alt = wmfma(A[b][1][i], bop[Jk + 1][i], alt);
       }
+      wfence();
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[0][i] += alt[i];
@@ -237,6 +254,11 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
 #pragma unroll
     for (int Jk = 0; Jk < NJ; ++Jk) {
       const int b = Jk & 1;
+#pragma unroll
+      for (int i = 0; i < 1; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) acc[jj] = wmfma(A[b][jj][i], bop[Jk][i], acc[jj]);
+      wfence();
       if (Jk + 1 < NJ) {
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj)
@@ -244,9 +266,10 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
       }
       wfence();
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 1; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = wmfma(A[b][jj][i], bop[Jk][i], acc[jj]);
+      wfence();
     }
   }
   wfence();
@@ -262,8 +285,6 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   constexpr int NJ = H / 16, NP = H / C::PU, NTILE = C::NTILE, NT = C::NT;
   constexpr int W1P = LD::W1P, WP = LD::WP;
   constexpr int NSTEP = BWD ? 2 * NP : NP;                   // panels per tile
-  constexpr int CPT = C::PU * H / 4 / NT;                    // 4-element chunks per thread and panel
-  static_assert(C::PU * H % (4 * NT) == 0 && H % (4 * CPT) == 0, "panel copy");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* W1s = reinterpret_cast<real*>(smem_raw);             // [H][W1P] natural rows
   real* Bs = W1s + H * W1P;                                  // b1 | b2 | w3, position order
@@ -294,26 +315,35 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   auto panel_src = [&](int s) -> const real* {
     return s < NP ? a.w2p + (int64_t)s * C::PU * H : a.w2tp + (int64_t)(s - NP) * C::PU * H;
   };
-  // thread t moves the 4 CPT consecutive elements [4 CPT t, 4 CPT (t + 1)) of a
-  // panel (one LDS row piece): ONE lane address per panel, the chunks are
-  // immediate offsets of it
-  v4 stg[CPT];
-  const unsigned goff = (unsigned)tid * (4u * CPT);
-  const int soff = (int)(goff / H) * WP + (int)(goff % H);
+  // a panel moves in 16-byte chunks, chunk q NT + t by thread t: consecutive
+  // lanes load consecutive 16 bytes and write them to consecutive LDS banks
+  // (a thread writing 64 or 128 contiguous bytes put 4 / 8 lanes of every
+  // ds_write_b128 group on one bank).  ONE 32-bit lane offset per panel: the
+  // chunks differ in the uniform base (global) / an immediate offset (LDS).
+  typedef typename WV<real>::chunk chunk;
+  constexpr int EPC = 16 / (int)sizeof(real);                // elements per chunk
+  constexpr int CPR = H / EPC;                               // chunks per panel row
+  constexpr int NCH = C::PU * CPR / NT;                      // chunks per thread and panel
+  static_assert(C::PU * CPR % NT == 0 && NT % CPR == 0, "panel copy");
+  chunk stg[NCH];
+  const unsigned goff = (unsigned)tid * EPC;
+  const int soff = (tid / CPR) * WP + (tid % CPR) * EPC;
   auto fetch = [&](int s) {
     // uniform (SGPR) base + 32-bit lane offset; the empty asm keeps the
     // compiler from hoisting one 64-bit lane address per panel out of the tile
-    // loop (32 registers, which then spill)
+    // loop (32 registers, which then spill).  It also hides where the pointer
+    // came from: without the explicit global address space these would be
+    // FLAT loads, which count in lgkmcnt as well.
     const real* base = panel_src(s);
     asm volatile("" : "+s"(base));
-    const real* src = base + goff;
+    typedef const __attribute__((address_space(1))) chunk* gchunkp;
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) stg[q] = *reinterpret_cast<const v4*>(src + 4 * q);
+    for (int q = 0; q < NCH; ++q) stg[q] = *(gchunkp)(base + q * NT * EPC + goff);
   };
   auto stash = [&](int buf) {
     real* dst = pan + buf * LD::PANEL + soff;
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) *reinterpret_cast<v4*>(dst + 4 * q) = stg[q];
+    for (int q = 0; q < NCH; ++q) *reinterpret_cast<chunk*>(dst + q * (NT / CPR) * WP) = stg[q];
   };
   fetch(0);
   stash(0);
@@ -393,7 +423,10 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     real* ph = a.h1s + r * H + 4 * g;
     real* pd = a.dy2s + r * H + 4 * g;
     real* p1s = a.dy1s + r * H + 4 * g;
-    if (BWD && rok) {
+    // (the workspaces hold whole tiles: rows past R are written and read like
+    // the others -- no data-dependent branch around a store, so the waits on
+    // the shared load / store counter stay countable -- and never used)
+    if (BWD) {
 #pragma unroll
       for (int J = 0; J < NJ; ++J) *reinterpret_cast<v4*>(ph + 16 * J) = h1[J];
     }
@@ -413,6 +446,12 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       for (int jj = 0; jj < NTILE; ++jj)
         acc[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + 4 * g);
       panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc);
+      WSTAMP(4)
+      // the other buffer is free since the last barrier: the next panel goes
+      // there now (fills the result latency of the last MFMAs, and its wait
+      // for the fetch comes before this step's stores enter the same counter)
+      if (pre) stash((s & 1) ^ 1);
+      WSTAMP(5)
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj) {
         const int J = s * NTILE + jj;
@@ -422,9 +461,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           acc[jj][i] = wact<real, ACT>(acc[jj][i]);
           v += w3v[i] * acc[jj][i];
         }
-        if (BWD && rok) *reinterpret_cast<v4*>(pd + 16 * J) = acc[jj];
+        if (BWD) *reinterpret_cast<v4*>(pd + 16 * J) = acc[jj];
       }
-      if (pre) stash((s & 1) ^ 1);
+      WSTAMP(6)
       __syncthreads();
     }
 
@@ -460,8 +499,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       vacc dy2[NJ];
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
-        const v4 z = {0, 0, 0, 0};
-        dy2[J] = rok ? *reinterpret_cast<const v4*>(pd + 16 * J) : z;
+        dy2[J] = *reinterpret_cast<const v4*>(pd + 16 * J);
       }
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
@@ -475,7 +513,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           dy2[J][i] = dy;
           t2[i] = dy;
         }
-        if (rok) *reinterpret_cast<v4*>(pd + 16 * J) = dy2[J];
+        *reinterpret_cast<v4*>(pd + 16 * J) = dy2[J];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           t3[i] = row16_sum(t3[i]);
@@ -503,13 +541,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         vacc hb[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
-          const v4 z = {0, 0, 0, 0};
-          hb[jj] = rok ? *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj)) : z;
+          hb[jj] = *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj));
         }
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
         panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc);
+        if (pre) stash(((NP + s) & 1) ^ 1);
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
@@ -519,7 +557,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
             acc[jj][i] *= wact_d<real, ACT>(hb[jj][i]);
             t1[i] = row16_sum(acc[jj][i]);
           }
-          if (rok) *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
+          *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
           if (m == 0) {
             real* q1 = my_acc + 16 * J + 4 * g;
 #pragma unroll
@@ -529,7 +567,6 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
             }
           }
         }
-        if (pre) stash(((NP + s) & 1) ^ 1);
         __syncthreads();
       }
       WSTAMP(3)
@@ -841,8 +878,9 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
   a.w2p = w2p;
   a.w2tp = w2tp;
   a.h1s = w2tp + (int64_t)H * H;
-  a.dy2s = a.h1s + a.R * H;
-  a.dy1s = a.dy2s + a.R * H;
+  const int64_t rows = mlpw_ws_rows(a.R);                   // whole tiles
+  a.dy2s = a.h1s + rows * H;
+  a.dy1s = a.dy2s + rows * H;
   hipLaunchKernelGGL(mlpw_prep_kernel<real>, dim3((H * H + 255) / 256), dim3(256), 0, st, w2,
                      H, w2p, w2tp);
   TCE_LAUNCH_CHECK();

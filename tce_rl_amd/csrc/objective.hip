@@ -11,12 +11,14 @@
 // env: thread = env for those (triangular solves against factors held in LDS),
 // one workgroup for the K x K parts (fp64 in LDS, smallmat.h).
 #include "smallmat.h"
+#include "lanevec.h"
+#include "../../include/tce_hip.h"
 
 namespace {
 
 // out[0] = -mean(ratio * adv), out[1] = mean(ratio); grad[i] = -ratio_i adv_i / M.
 // Grid of blocks with per-block partial sums; the block that finishes last
-// adds them in index order (deterministic) and re-arms the ticket.
+// adds them in a fixed order (deterministic) and re-arms the ticket.
 constexpr int SUR_BT = 256;
 constexpr int SUR_MAX_BLOCKS = 128;
 
@@ -49,23 +51,35 @@ __global__ __launch_bounds__(SUR_BT) void surrogate_kernel(const real* __restric
     last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
-  if (last && threadIdx.x == 0) {
+  if (last) {                                         // uniform over the block
+    // the partials are summed by the first wave, lane b <- blocks b, b + 64:
+    // a fixed order (one thread adding 128 values was a chain of 256 dependent
+    // L2 loads, 15 of the kernel's 20 us)
     __threadfence();
     double ts = 0, tr = 0;
-    for (unsigned b = 0; b < gridDim.x; ++b) {
-      ts += __builtin_nontemporal_load(partials + 2 * b);
-      tr += __builtin_nontemporal_load(partials + 2 * b + 1);
+    if (threadIdx.x < 64) {
+      for (unsigned b = threadIdx.x; b < gridDim.x; b += 64) {
+        ts += __builtin_nontemporal_load(partials + 2 * b);
+        tr += __builtin_nontemporal_load(partials + 2 * b + 1);
+      }
+      ts = wave_sum(ts);
+      tr = wave_sum(tr);
     }
-    out[0] = (real)(-ts / (double)M);
-    out[1] = (real)(tr / (double)M);
-    *ticket = 0;
+    if (threadIdx.x == 0) {
+      out[0] = (real)(-ts / (double)M);
+      out[1] = (real)(tr / (double)M);
+      *ticket = 0;
+    }
   }
 }
 
-constexpr int KE_BT = 64;
+constexpr int KE_BT = 256;          // 4 waves
+constexpr int KE_EPW = 4;           // envs per wave, one after the other
+constexpr int KE_EPB = (KE_BT / 64) * KE_EPW;
 
-// thread = env: maha(new, old), maha(new, proj), maha(proj, old) and
-// grad_mean = coeff / N * Sigma_proj^-1 (mean_new - mean_proj)
+// wave = env, lane = element of the mean vector (lanevec.h): maha(new, old),
+// maha(new, proj), maha(proj, old) -- three forward substitutions side by side
+// -- and grad_mean = coeff / N * Sigma_proj^-1 (mean_new - mean_proj)
 template <typename real>
 __global__ __launch_bounds__(KE_BT) void kl_shared_env_kernel(
     const real* __restrict__ mn, const real* __restrict__ mo, const real* __restrict__ mp,
@@ -75,48 +89,39 @@ __global__ __launch_bounds__(KE_BT) void kl_shared_env_kernel(
   real* Los = reinterpret_cast<real*>(smem_raw);     // [K][KP]
   const int KP = sm_pitch(K);
   real* Lps = Los + K * KP;
-  real* vs = Lps + K * KP;                            // [KE_BT][KP]
   __shared__ double red[4];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < K * K; e += KE_BT) {
     const int i = e / K, j = e - i * K;
     Los[i * KP + j] = Lo[e];
     Lps[i * KP + j] = Lp[e];
   }
   __syncthreads();
-  const int64_t n = (int64_t)blockIdx.x * KE_BT + tid;
-  const bool ok = n < N;
-  const int64_t nc = ok ? n : N - 1;
-  real* v = vs + tid * KP;
-  // z = Lq^-1 d in place, returns |z|^2
-  auto solve = [&](const real* Ls) {
-    real q = 0;
-    for (int r = 0; r < K; ++r) {
-      real acc = v[r];
-      for (int k = 0; k < r; ++k) acc -= Ls[r * KP + k] * v[k];
-      acc /= Ls[r * KP + r];
-      v[r] = acc;
-      q += acc * acc;
+  const bool in = lane < K;
+  const real rdo = in ? real(1) / Los[lane * KP + lane] : real(0);
+  const real rdp = in ? real(1) / Lps[lane * KP + lane] : real(0);
+  double m1 = 0, m2 = 0, m3 = 0;                      // this lane's share of the sums
+  const int64_t n0 = (int64_t)blockIdx.x * KE_EPB + wave * KE_EPW;
+  for (int i = 0; i < KE_EPW; ++i) {
+    const int64_t n = n0 + i;
+    if (n >= N) break;
+    real a = 0, b = 0, c = 0;
+    if (in) { a = mn[n * K + lane]; b = mo[n * K + lane]; c = mp[n * K + lane]; }
+    real v[3] = {a - b, c - b, a - c};
+    const real* const Ls[3] = {Los, Los, Lps};
+    const real rd[3] = {rdo, rdo, rdp};
+    lv_solve_lower<real, 3>(v, Ls, rd, K, KP, lane);
+    m1 += (double)v[0] * (double)v[0];
+    m3 += (double)v[1] * (double)v[1];
+    m2 += (double)v[2] * (double)v[2];
+    if (gmean) {                                      // w = Lp^-T z
+      real w[1] = {v[2]};
+      const real* const Lw[1] = {Lps};
+      const real rw[1] = {rdp};
+      lv_solve_lower_t<real, 1>(w, Lw, rw, K, KP, lane);
+      if (in) gmean[n * K + lane] = gscale * w[0];
     }
-    return q;
-  };
-  for (int k = 0; k < K; ++k) v[k] = mn[nc * K + k] - mo[nc * K + k];
-  double m1 = (double)solve(Los);
-  for (int k = 0; k < K; ++k) v[k] = mp[nc * K + k] - mo[nc * K + k];
-  double m3 = (double)solve(Los);
-  for (int k = 0; k < K; ++k) v[k] = mn[nc * K + k] - mp[nc * K + k];
-  double m2 = (double)solve(Lps);
-  if (gmean) {                                        // w = Lp^-T z
-    for (int r = K - 1; r >= 0; --r) {
-      real acc = v[r];
-      for (int k = r + 1; k < K; ++k) acc -= Lps[k * KP + r] * v[k];
-      acc /= Lps[r * KP + r];
-      v[r] = acc;
-    }
-    if (ok)
-      for (int k = 0; k < K; ++k) gmean[n * K + k] = gscale * v[k];
   }
-  if (!ok) { m1 = 0; m2 = 0; m3 = 0; }
   m1 = block_sum(m1, red);
   m2 = block_sum(m2, red);
   m3 = block_sum(m3, red);
@@ -183,10 +188,11 @@ __global__ __launch_bounds__(SM_BT) void kl_shared_mat_kernel(
   double lp_ld = 0;
   for (int i = threadIdx.x; i < K; i += SM_BT) lp_ld += log(C[i * KP + i]);
   lp_ld = sm_block_sum(lp_ld, red);
+  double m[3] = {0, 0, 0};
+  for (int b = threadIdx.x; b < nparts; b += SM_BT)
+    for (int k = 0; k < 3; ++k) m[k] += partials[b * 3 + k];
+  for (int k = 0; k < 3; ++k) m[k] = sm_block_sum(m[k], red);
   if (threadIdx.x == 0) {
-    double m[3] = {0, 0, 0};
-    for (int b = 0; b < nparts; ++b)
-      for (int k = 0; k < 3; ++k) m[k] += partials[b * 3 + k];
     const double f[3] = {f1, f2, f3}, l[3] = {l1, l2, l3};
     double tr = 0;
     for (int k = 0; k < 3; ++k) {
@@ -223,8 +229,8 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
               real* gmean, real* gL, double* ws, hipStream_t st) {
   TCE_CHECK_ARG(mn && mo && mp && Ln && Lo && Lp && out && ws && N > 0 && K > 0 && K <= 64,
                 "kl_shared: bad arguments (K <= 64)");
-  const int nblk = (int)ceil_div(N, KE_BT);
-  const size_t lds_e = ((size_t)2 * K * sm_pitch(K) + (size_t)KE_BT * sm_pitch(K)) * sizeof(real);
+  const int nblk = (int)ceil_div(N, KE_EPB);
+  const size_t lds_e = (size_t)2 * K * sm_pitch(K) * sizeof(real);
   if (lds_e > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_env_kernel<real>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e);
@@ -242,11 +248,317 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// The whole objective of one epoch in one call (tce_policy_objective_*): the
+// chain of rl/objective.py `evaluate`, with the single-workgroup K x K kernels
+// (covariance projection forward / backward, the matrix part of the KL
+// diagnostics) on a second stream beside the per-env kernels.
+// ---------------------------------------------------------------------------
+struct ObjSide {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+inline ObjSide* obj_side() {
+  static ObjSide s;
+  static bool tried = false, ok = false;
+  if (!tried) {
+    tried = true;
+    ok = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 5; ++i)
+      ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
+  }
+  return ok ? &s : nullptr;
+}
+
+inline int64_t obj_up4(int64_t n) { return (n + 3) / 4 * 4; }
+inline int64_t obj_ws_len(int64_t N, int K, int P) {
+  return 3 * obj_up4(N * K) + 2 * obj_up4(N * P) + 3 * obj_up4((int64_t)K * K);
+}
+template <typename real>
+inline real* obj_proj_L(real* ws, int64_t N, int K, int P) {
+  return ws + 3 * obj_up4(N * K) + 2 * obj_up4(N * P);
+}
+
+// a[i] += b[i] for two pairs of arrays in one launch; c[i,i] -= s / d[i,i] first
+template <typename real>
+__global__ __launch_bounds__(256) void obj_add2_kernel(real* __restrict__ a1,
+                                                       const real* __restrict__ b1, int64_t n1,
+                                                       real* __restrict__ a2,
+                                                       const real* __restrict__ b2, int64_t n2) {
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < n1) a1[i] += b1[i];
+  else if (i - n1 < n2) a2[i - n1] += b2[i - n1];
+}
+// g[i,i] -= coef / L[i,i]  (gradient of -coef * entropy(L) w.r.t. L)
+template <typename real>
+__global__ __launch_bounds__(64) void obj_ent_diag_kernel(real* __restrict__ g,
+                                                          const real* __restrict__ L, int K,
+                                                          real coef) {
+  const int i = threadIdx.x;
+  if (i < K) g[i * K + i] -= coef / L[i * K + i];
+}
+
+template <typename real> struct ObjApi;
+template <> struct ObjApi<float> {
+  static constexpr auto vec_env = tce_vec_env_f32;
+  static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f32;
+  static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f32;
+  static constexpr auto pl_fwd = tce_pair_logprob_fwd_f32;
+  static constexpr auto pl_bwd = tce_pair_logprob_bwd_f32;
+  static constexpr auto chol_fwd = tce_chol_build_fwd_f32;
+};
+template <> struct ObjApi<double> {
+  static constexpr auto vec_env = tce_vec_env_f64;
+  static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f64;
+  static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f64;
+  static constexpr auto pl_fwd = tce_pair_logprob_fwd_f64;
+  static constexpr auto pl_bwd = tce_pair_logprob_bwd_f64;
+  static constexpr auto chol_fwd = tce_chol_build_fwd_f64;
+};
+
+#define OBJ_TRY(call)          \
+  do {                         \
+    const int rc_ = (call);    \
+    if (rc_ != 0) return rc_;  \
+  } while (0)
+#define OBJ_HIP(call)                                          \
+  do {                                                         \
+    if ((call) != hipSuccess) {                                \
+      tce_set_error("policy_objective: stream / event call");  \
+      return 1;                                                \
+    }                                                          \
+  } while (0)
+
+template <typename real>
+int policy_objective(const real* mean_new, const real* L_new, const real* mean_old,
+                     const real* L_old, const real* traj, const real* logp_old,
+                     const real* adv, const int64_t* pairs, const real* tab, int M, int nbg,
+                     real tau, real delay, real scaled_dt, real inv_scale_g, int rel_goal,
+                     const real* times, int flags_fwd, int flags_bwd, const real* t0,
+                     const real* y0, const real* v0, real reg, real* basis_ws, int* flag_ws,
+                     real* pl_work, real eps_mean, double eps_cov, const real* beta,
+                     int entropy_eq, double* proj_ctx, real tr_coeff, int tr_include_cov,
+                     real ent_coef, double* sur_ws, double* kl_ws, real* ws, real* grad_mean,
+                     real* grad_L, real* sur2, real* out16, int64_t N, int T, int P, int dof,
+                     int K, int proj_started, int defer_join, hipStream_t st) {
+  typedef ObjApi<real> A;
+  TCE_CHECK_ARG(mean_new && L_new && mean_old && L_old && traj && logp_old && adv && pairs &&
+                    proj_ctx && sur_ws && kl_ws && ws && grad_mean && grad_L && sur2 && out16,
+                "policy_objective: null buffer");
+  TCE_CHECK_ARG(N > 0 && T > 0 && P > 0 && K == dof * nbg && K <= 64,
+                "policy_objective: bad sizes (K = dof * nbg <= 64)");
+  ObjSide* S = obj_side();
+  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  hipStream_t sd = S->side;
+  real* pm = ws;                                  // projected mean [N,K]
+  real* g_pm = pm + obj_up4(N * K);               // d / d pm
+  real* gm_p = g_pm + obj_up4(N * K);             // ... back through the mean projection
+  real* logp = gm_p + obj_up4(N * K);             // [N,P]
+  real* glp = logp + obj_up4(N * P);
+  real* pL = obj_proj_L(ws, N, K, P);             // projected factor [K,K]
+  real* g_pL = pL + obj_up4((int64_t)K * K);
+  real* gL_p = g_pL + obj_up4((int64_t)K * K);
+  // ---- fork: covariance projection (one workgroup) beside the mean projection
+  // (proj_started: tce_policy_objective_begin_* has put it on the side stream)
+  if (!proj_started) {
+    OBJ_HIP(hipEventRecord(S->ev[0], st));
+    OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
+    OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
+    OBJ_HIP(hipEventRecord(S->ev[1], sd));
+  }
+  OBJ_TRY(A::vec_env(1, 0, mean_new, mean_old, L_old, 0, eps_mean, nullptr, pm, nullptr,
+                     nullptr, N, K, st));
+  OBJ_HIP(hipEventRecord(S->ev[2], st));
+  // ---- side: KL diagnostics, entropy, trust region loss and its gradients
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
+  OBJ_TRY(kl_shared<real>(mean_new, mean_old, pm, L_new, L_old, pL, N, K, tr_coeff,
+                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd));
+  // ---- main: pair log-prob under the projection, surrogate, and back
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
+  OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                    rel_goal, times, flags_fwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
+                    pl_work, N, T, P, dof, st));
+  OBJ_TRY(surrogate<real>(logp, logp_old, adv, N * (int64_t)P, sur2, glp, sur_ws, st));
+  OBJ_TRY(A::pl_bwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                    rel_goal, times, flags_bwd, t0, y0, v0, reg, glp, g_pm, g_pL, basis_ws,
+                    flag_ws, pl_work, N, T, P, dof, st));
+  if (ent_coef != real(0)) {
+    hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
+                       ent_coef);
+    TCE_LAUNCH_CHECK();
+  }
+  OBJ_HIP(hipEventRecord(S->ev[3], st));
+  // ---- back through the two projections, side by side
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[3], 0));
+  OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p, 1, K, sd));
+  OBJ_HIP(hipEventRecord(S->ev[4], sd));
+  OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
+                     nullptr, N, K, st));
+  const int64_t n1 = N * K, n2 = (int64_t)K * K;
+  if (defer_join) {
+    // grad_mean is complete after this; grad_L lacks the projection's part until
+    // tce_policy_objective_end_* joins the side stream
+    hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st,
+                       grad_mean, gm_p, n1, grad_L, gL_p, (int64_t)0);
+    TCE_LAUNCH_CHECK();
+    return 0;
+  }
+  // ---- join
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+  hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(n1 + n2, 256)), dim3(256), 0,
+                     st, grad_mean, gm_p, n1, grad_L, gL_p, n2);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename real>
+int policy_objective_end(real* grad_L, real* ws, int64_t N, int K, int P, hipStream_t st) {
+  TCE_CHECK_ARG(grad_L && ws && N > 0 && K > 0 && K <= 64, "policy_objective_end: bad arguments");
+  ObjSide* S = obj_side();
+  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+  const int64_t n2 = (int64_t)K * K;
+  real* gL_p = obj_proj_L(ws, N, K, P) + 2 * obj_up4(n2);
+  hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st,
+                     grad_L, gL_p, n2, grad_L, gL_p, (int64_t)0);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Cholesky head + covariance projection of the coming objective call on the
+// side stream: they depend on the variance parameters only, so they can run
+// beside the forward pass of the mean net.
+template <typename real>
+int policy_objective_begin(const real* var_vec, int nvec, real min_std, const real* L_old,
+                           double eps_cov, const real* beta, int entropy_eq, double* proj_ctx,
+                           real* L_new, real* ws, int64_t N, int K, int P, hipStream_t st) {
+  typedef ObjApi<real> A;
+  TCE_CHECK_ARG(var_vec && L_old && proj_ctx && L_new && ws && N > 0 && K > 0 && K <= 64,
+                "policy_objective_begin: bad arguments");
+  ObjSide* S = obj_side();
+  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  OBJ_HIP(hipEventRecord(S->ev[0], st));
+  OBJ_HIP(hipStreamWaitEvent(S->side, S->ev[0], 0));
+  OBJ_TRY(A::chol_fwd(var_vec, L_new, 1, K, nvec, min_std, S->side));
+  OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, obj_proj_L(ws, N, K, P),
+                      proj_ctx, 1, K, 1, S->side));
+  OBJ_HIP(hipEventRecord(S->ev[1], S->side));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Output layer of the mean net, y = h W^T + b, from g = dL/dy [N,K] and the
+// hidden activations h [N,H]: dW [K,H] = g^T h, db [K] = sum_n g.  (As a
+// library GEMM this [K x N] . [N x H] product with K = 24 ran on 4 workgroups:
+// 26 us.)  Blocks of OL_ROWS rows -> partial [K H + K] slabs -> one reduction.
+// ---------------------------------------------------------------------------
+constexpr int OL_ROWS = 32, OL_MAXK = 64;
+
+template <typename real>
+__global__ __launch_bounds__(256) void out_layer_grad_kernel(const real* __restrict__ g,
+                                                             const real* __restrict__ h,
+                                                             int64_t N, int K, int H,
+                                                             real* __restrict__ part) {
+  __shared__ real gs[OL_ROWS][OL_MAXK + 1];
+  const int j = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * OL_ROWS;
+  const int nr = (int)tmin<int64_t>(OL_ROWS, N - r0);
+  const int K8 = (K + 7) & ~7;
+  for (int e = threadIdx.x; e < OL_ROWS * K8; e += blockDim.x) {
+    const int r = e / K8, k = e - r * K8;
+    gs[r][k] = (r < nr && k < K) ? g[(r0 + r) * K + k] : real(0);
+  }
+  __syncthreads();
+  real* out = part + (int64_t)blockIdx.x * ((int64_t)K * H + K);
+  if (j < H) {
+    real hb[OL_ROWS];                                  // all loads of the block in flight
+#pragma unroll
+    for (int r = 0; r < OL_ROWS; ++r) hb[r] = r < nr ? h[(r0 + r) * H + j] : real(0);
+    // 8 outputs at a time (columns of gs past K are zero)
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      real acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < OL_ROWS; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc[kk] += gs[r][k0 + kk] * hb[r];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+        if (k0 + kk < K) out[(int64_t)(k0 + kk) * H + j] = acc[kk];
+    }
+  }
+  if (j < K) {
+    real sb = 0;
+    for (int r = 0; r < OL_ROWS; ++r) sb += gs[r][j];
+    out[(int64_t)K * H + j] = sb;
+  }
+}
+
+// dst[e] = sum_b part[b][e] (fixed order, 8 loads in flight); e < KH -> dW, else db
+template <typename real>
+__global__ __launch_bounds__(256) void out_layer_reduce_kernel(const real* __restrict__ part,
+                                                               int nb, int64_t KH, int K,
+                                                               real* __restrict__ dW,
+                                                               real* __restrict__ db) {
+  const int64_t e = blockIdx.x * 256ll + threadIdx.x;
+  const int64_t M = KH + K;
+  if (e >= M) return;
+  real a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += part[(int64_t)(b + u) * M + e];
+  }
+  for (; b < nb; ++b) a8[0] += part[(int64_t)b * M + e];
+  const real sum = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  if (e < KH) dW[e] = sum;
+  else db[e - KH] = sum;
+}
+
+template <typename real>
+int out_layer_grad(const real* g, const real* h, real* dW, real* db, real* ws, int64_t N, int K,
+                   int H, hipStream_t st) {
+  TCE_CHECK_ARG(g && h && dW && db && ws && N > 0 && K > 0 && K <= OL_MAXK && H > 0 && H <= 256,
+                "out_layer_grad: bad arguments (K <= 64, H <= 256)");
+  const int nb = (int)ceil_div(N, OL_ROWS);
+  hipLaunchKernelGGL(out_layer_grad_kernel<real>, dim3(nb), dim3(H <= 128 ? 128 : 256), 0, st, g,
+                     h, N, K, H, ws);
+  TCE_LAUNCH_CHECK();
+  const int64_t KH = (int64_t)K * H;
+  hipLaunchKernelGGL(out_layer_reduce_kernel<real>, dim3((unsigned)ceil_div(KH + K, 256)),
+                     dim3(256), 0, st, ws, nb, KH, K, dW, db);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+// record row of one policy epoch: {surrogate, entropy loss, trust region loss,
+// total, entropy, |g|, |g| clipped, 12 KL means}
+template <typename real>
+__global__ __launch_bounds__(64) void policy_record_kernel(const real* __restrict__ sur2,
+                                                           const real* __restrict__ out16,
+                                                           const real* __restrict__ norms2,
+                                                           real ent_coef,
+                                                           real* __restrict__ row19) {
+  const int i = threadIdx.x;
+  if (i >= 19) return;
+  const real entl = ent_coef == real(0) ? real(0) : -ent_coef * out16[12];
+  real v;
+  if (i == 0) v = sur2[0];
+  else if (i == 1) v = entl;
+  else if (i == 2) v = out16[13];
+  else if (i == 3) v = ent_coef == real(0) ? sur2[0] + out16[13] : sur2[0] + out16[13] + entl;
+  else if (i == 4) v = out16[12];
+  else if (i < 7) v = norms2[i - 5];
+  else v = out16[i - 7];
+  row19[i] = v;
+}
+
 }  // namespace
 
 extern "C" {
 
-int64_t tce_kl_shared_ws_len(int64_t N) { return 3 * ceil_div(N, KE_BT); }
+int64_t tce_kl_shared_ws_len(int64_t N) { return 3 * ceil_div(N, KE_EPB); }
 
 int64_t tce_surrogate_ws_len(void) { return 1 + 2 * SUR_MAX_BLOCKS; }
 
@@ -271,6 +583,73 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
                       double* grad_mean, double* grad_L, double* ws, void* stream) {
   return kl_shared<double>(mean_new, mean_old, mean_proj, L_new, L_old, L_proj, N, K, tr_coeff,
                            tr_include_cov, out16, grad_mean, grad_L, ws, (hipStream_t)stream);
+}
+
+int64_t tce_policy_objective_ws_len(int64_t N, int K, int P) { return obj_ws_len(N, K, P); }
+
+#define DEFINE_POLICY_OBJECTIVE(SFX, REAL)                                                \
+  int tce_policy_objective_##SFX(                                                         \
+      const REAL* mean_new, const REAL* L_new, const REAL* mean_old, const REAL* L_old,   \
+      const REAL* traj, const REAL* logp_old, const REAL* adv, const int64_t* pairs,      \
+      const REAL* tab, int M, int nbg, REAL tau, REAL delay, REAL scaled_dt,              \
+      REAL inv_scale_g, int rel_goal, const REAL* times, int times_flags_fwd,             \
+      int times_flags_bwd, const REAL* init_time, const REAL* init_pos,                   \
+      const REAL* init_vel, REAL reg, REAL* basis_ws, int* flag_ws, REAL* pair_work,      \
+      REAL eps_mean, double eps_cov, const REAL* beta, int entropy_eq, double* proj_ctx,  \
+      REAL tr_coeff, int tr_include_cov, REAL ent_coef, double* sur_ws, double* kl_ws,    \
+      REAL* ws, REAL* grad_mean, REAL* grad_L, REAL* sur2, REAL* out16, int64_t N, int T, \
+      int P, int dof, int K, int proj_started, int defer_join, void* stream) {                                              \
+    return policy_objective<REAL>(                                                        \
+        mean_new, L_new, mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau,   \
+        delay, scaled_dt, inv_scale_g, rel_goal, times, times_flags_fwd, times_flags_bwd, \
+        init_time, init_pos, init_vel, reg, basis_ws, flag_ws, pair_work, eps_mean,       \
+        eps_cov, beta, entropy_eq, proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws,  \
+        kl_ws, ws, grad_mean, grad_L, sur2, out16, N, T, P, dof, K, proj_started,         \
+        defer_join, (hipStream_t)stream);                                                 \
+  }                                                                                       \
+  int tce_policy_objective_end_##SFX(REAL* grad_L, REAL* ws, int64_t N, int K, int P,     \
+                                     void* stream) {                                      \
+    return policy_objective_end<REAL>(grad_L, ws, N, K, P, (hipStream_t)stream);          \
+  }                                                                                       \
+  int tce_policy_objective_begin_##SFX(                                                   \
+      const REAL* var_vec, int nvec, REAL min_std, const REAL* L_old, double eps_cov,     \
+      const REAL* beta, int entropy_eq, double* proj_ctx, REAL* L_new, REAL* ws,          \
+      int64_t N, int K, int P, void* stream) {                                            \
+    return policy_objective_begin<REAL>(var_vec, nvec, min_std, L_old, eps_cov, beta,     \
+                                        entropy_eq, proj_ctx, L_new, ws, N, K, P,         \
+                                        (hipStream_t)stream);                             \
+  }
+DEFINE_POLICY_OBJECTIVE(f32, float)
+DEFINE_POLICY_OBJECTIVE(f64, double)
+
+int64_t tce_out_layer_grad_ws_len(int64_t N, int K, int H) {
+  return ceil_div(N, OL_ROWS) * ((int64_t)K * H + K);
+}
+int tce_out_layer_grad_f32(const float* grad_out, const float* hidden, float* grad_W,
+                           float* grad_b, float* ws, int64_t N, int K, int H, void* stream) {
+  return out_layer_grad<float>(grad_out, hidden, grad_W, grad_b, ws, N, K, H,
+                               (hipStream_t)stream);
+}
+int tce_out_layer_grad_f64(const double* grad_out, const double* hidden, double* grad_W,
+                           double* grad_b, double* ws, int64_t N, int K, int H, void* stream) {
+  return out_layer_grad<double>(grad_out, hidden, grad_W, grad_b, ws, N, K, H,
+                                (hipStream_t)stream);
+}
+int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
+                          float ent_coef, float* row19, void* stream) {
+  TCE_CHECK_ARG(sur2 && out16 && norms2 && row19, "policy_record: null buffer");
+  hipLaunchKernelGGL(policy_record_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     sur2, out16, norms2, ent_coef, row19);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+int tce_policy_record_f64(const double* sur2, const double* out16, const double* norms2,
+                          double ent_coef, double* row19, void* stream) {
+  TCE_CHECK_ARG(sur2 && out16 && norms2 && row19, "policy_record: null buffer");
+  hipLaunchKernelGGL(policy_record_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     sur2, out16, norms2, ent_coef, row19);
+  TCE_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // extern "C"

@@ -138,7 +138,7 @@ class AbstractAgent(ABC):
             after = before
         return before, after
 
-    def _optimizer_step(self, opt, params, clip):
+    def _optimizer_step(self, opt, params, clip, want_norms=True):
         """grad_norm_clip + Adam step (one flat buffer; one collective when
         the envs are sharded over ranks)."""
         if self.dist.active:
@@ -148,6 +148,8 @@ class AbstractAgent(ABC):
                 opt.flat_grad, self._policy_group
                 if opt is self.policy_optimizer else None, average=False)
         opt.step(clip, grad_scale=1.0 / self.dist.world)   # mean over ranks
+        if not want_norms:                      # the caller reads dev_state[1:3]
+            return None
         norms = opt.dev_state[1:3].clone()      # the state is reused next step
         return norms[0], norms[1]
 

@@ -45,6 +45,11 @@ class Context:
         self.v0 = c(dataset["segment_init_vel"])
         self.times = c(times)
         self.general = 0 if getattr(times, "_tce_affine", False) else 1
+        # all segments start at the same time (every shipped config): checked
+        # once per update on the host (one small copy), so the ~100 objective
+        # evaluations skip the launches of the general-path kernels
+        if not self.general and bool((self.t0 == self.t0.flatten()[0]).all()):
+            self.general |= 8
         self.pairs = c(agent.sampler.pred_pairs.to(torch.int64))
         self.eps_mean, self.eps_cov = proj.mean_bound, proj.cov_bound
         self.beta = None if beta is None else \
@@ -61,72 +66,66 @@ class Context:
         self.sur_ws = torch.zeros(_lib.load().tce_surrogate_ws_len(),
                                   dtype=torch.float64,
                                   device=self.mean_old.device)
+        self.ws = self.kl_ws = self.pl_work = self.ws_key = None
 
 
-def evaluate(mean_new, L_new, c):
+def _workspaces(c, N, K, P, ref):
+    lib = _lib.load()
+    if c.ws is None or c.ws_key != (N, K, P, ref.dtype):
+        c.ws = torch.empty(lib.tce_policy_objective_ws_len(N, K, P),
+                           dtype=ref.dtype, device=ref.device)
+        c.kl_ws = torch.empty(lib.tce_kl_shared_ws_len(N),
+                              dtype=torch.float64, device=ref.device)
+        c.pl_work = ops._pl_work(ref, N, P, c.mp, 0, True)
+        c.ws_key = (N, K, P, ref.dtype)
+
+
+def begin(var_vec, min_std, L_out, c, N):
+    """Cholesky head + covariance projection of the coming ``evaluate(...,
+    started=True)`` on the library's second stream (tce_policy_objective_begin_*):
+    they only need the variance parameters and run beside the mean net."""
+    K, P = L_out.shape[-1], c.pairs.shape[0]
+    _workspaces(c, N, K, P, L_out)
+    call("tce_policy_objective_begin_" + sfx(L_out.dtype), ptr(var_vec),
+         var_vec.numel(), float(min_std), ptr(c.L_old), float(c.eps_cov),
+         ptr(c.beta), c.entropy_eq, ptr(c.proj_ctx), ptr(L_out), ptr(c.ws), N,
+         K, P, stream())
+
+
+def end(g_L, c, N):
+    """Join of a deferred ``evaluate`` (tce_policy_objective_end_*): adds the
+    covariance projection's part to g_L."""
+    K, P = g_L.shape[-1], c.pairs.shape[0]
+    call("tce_policy_objective_end_" + sfx(g_L.dtype), ptr(g_L), ptr(c.ws), N,
+         K, P, stream())
+
+
+def evaluate(mean_new, L_new, c, started=False, defer=False):
     """The objective of one epoch and its gradient, kernels only (no autograd):
     -> (g_mean [N, K], g_L [K, K], sur [2], out [16]) with sur[0] the surrogate
-    loss and out = {12 KL means, entropy, trust region loss, -, -}."""
+    loss and out = {12 KL means, entropy, trust region loss, -, -}.  ONE C call
+    (tce_policy_objective_*): ~14 kernels, the single-workgroup K x K ones on
+    a second stream beside the per-env ones."""
     N, K = mean_new.shape
     dt, dev = mean_new.dtype, mean_new.device
-    s = sfx(dt)
-    st = stream()
     mp = c.mp
     T, P = c.times.shape[1], c.pairs.shape[0]
+    _workspaces(c, N, K, P, mean_new)
     new = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
-    # ---- projection: mean (closed form per env), covariance (one matrix)
-    pm = new(N, K)
-    call("tce_vec_env_" + s, 1, 0, ptr(mean_new), ptr(c.mean_old),
-         ptr(c.L_old), 0, float(c.eps_mean), None, ptr(pm), None, None, N,
-         K, st)
-    pL = new(1, K, K)
-    # one context buffer per update: the next epoch's eigen-decomposition
-    # starts from this epoch's eigenvectors (the backward kernel below has
-    # consumed the context by then)
-    cbuf = c.proj_ctx
-    call("tce_kl_cov_proj_fwd_" + s, ptr(L_new), ptr(c.L_old), 0,
-         float(c.eps_cov), ptr(c.beta), c.entropy_eq, ptr(pL), ptr(cbuf),
-         1, K, 1, st)
-    # ---- pair log-prob of the stored trajectories under the projection
-    logp = new(N, P)
+    g_mean, g_L, sur, out = new(N, K), new(K, K), new(2), new(16)
     B, flag = ops._mp_ws(mp, T, dev)
-    work = ops._pl_work(mean_new, N, P, mp, 0, True)
     flags = c.general | (ops._times_flags(mp, c.times, c.t0) & 2)
-    pl = lambda f: (ptr(c.traj), ptr(pm), ptr(pL), 0, ptr(c.pairs),
-                    *mp.c_args(), ptr(c.times), f, ptr(c.t0), ptr(c.y0),
-                    ptr(c.v0), mp.cov_reg)
-    pl_args = pl(flags)
-    call("tce_pair_logprob_fwd_" + s, *pl_args, ptr(logp), ptr(B),
-         ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
-    # ---- surrogate loss and d/d logp
-    sur = new(2)
-    glp = new(N, P)
-    call("tce_surrogate_" + s, ptr(logp), ptr(c.lp_old), ptr(c.adv),
-         N * P, ptr(sur), ptr(glp), ptr(c.sur_ws), st)
-    g_pm, g_pL = new(N, K), new(K, K)
-    pl_args = pl(c.general | 2 | 4)     # the forward call left table + pair factors
-    call("tce_pair_logprob_bwd_" + s, *pl_args, ptr(glp), ptr(g_pm),
-         ptr(g_pL), ptr(B), ptr(flag), ptr(work), N, T, P, mp.num_dof, st)
-    # ---- KL diagnostics, entropy, trust region loss (+ its gradients)
-    out = new(16)
-    g_mean, g_L = new(N, K), new(K, K)
-    ws = torch.empty(_lib.load().tce_kl_shared_ws_len(N),
-                     dtype=torch.float64, device=dev)
-    call("tce_kl_shared_" + s, ptr(mean_new), ptr(c.mean_old), ptr(pm),
-         ptr(L_new), ptr(c.L_old), ptr(pL), N, K, float(c.tr_coeff),
-         c.tr_include_cov, ptr(out), ptr(g_mean), ptr(g_L), ptr(ws), st)
-    if c.ent_coef != 0.0:           # d(-coef * entropy(proj)) / d proj_L
-        g_pL = g_pL - c.ent_coef * torch.diag(1.0 / pL[0].diagonal())
-    # ---- back through the projection
-    gm_p = new(N, K)
-    call("tce_vec_env_" + s, 1, 1, ptr(mean_new), ptr(c.mean_old),
-         ptr(c.L_old), 0, float(c.eps_mean), ptr(g_pm), None, ptr(gm_p),
-         None, N, K, st)
-    gL_p = new(1, K, K)
-    call("tce_kl_cov_proj_bwd_" + s, ptr(L_new), ptr(c.L_old), 0, ptr(pL),
-         ptr(cbuf), ptr(g_pL), ptr(gL_p), 1, K, st)
-    g_mean.add_(gm_p)
-    g_L.add_(gL_p[0])
+    # one context buffer per update: the next epoch's eigen-decomposition
+    # starts from this epoch's eigenvectors
+    call("tce_policy_objective_" + sfx(dt), ptr(mean_new), ptr(L_new),
+         ptr(c.mean_old), ptr(c.L_old), ptr(c.traj), ptr(c.lp_old), ptr(c.adv),
+         ptr(c.pairs), *mp.c_args(), ptr(c.times), flags, c.general | 2 | 4,
+         ptr(c.t0), ptr(c.y0), ptr(c.v0), mp.cov_reg, ptr(B), ptr(flag),
+         ptr(c.pl_work), float(c.eps_mean), float(c.eps_cov), ptr(c.beta),
+         c.entropy_eq, ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov,
+         c.ent_coef, ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(g_mean),
+         ptr(g_L), ptr(sur), ptr(out), N, T, P, mp.num_dof, K, int(started),
+         int(defer), stream())
     return g_mean, g_L, sur, out
 
 
@@ -219,7 +218,9 @@ class DirectEpoch:
                                         (self.N + 63) // 64), P + 2,
                                     dtype=torch.float32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.zero1 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ol_ws = torch.empty(lib.tce_out_layer_grad_ws_len(self.N, self.K,
+                                                               128),
+                                 dtype=torch.float32, device=dev)
 
     def run(self, rec_row):
         """One epoch; rec_row [19] receives {surrogate, entropy loss, trust
@@ -231,15 +232,15 @@ class DirectEpoch:
         self.opt.bind_grads()
         with torch.no_grad():
             # ---- forward
+            L = new(1, K, K)
+            begin(self.var, self.min_std, L, c, N)    # second stream
             h2 = new(N, 128)
             call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
                  *[ptr(t) for t in self.w], self.act, None, ptr(h2), None,
                  None, None, st)
             mean = torch.addmm(self.b3, h2, self.w3.t())
-            L = new(1, K, K)
-            call("tce_chol_build_fwd_f32", ptr(self.var), ptr(L), 1, K,
-                 self.nvec, self.min_std, st)
-            g_mean, g_L, sur, out = evaluate(mean, L[0], c)
+            g_mean, g_L, sur, out = evaluate(mean, L[0], c, started=True,
+                                             defer=True)
             # ---- backward into the flat gradient.  The hidden layers' launch
             # fills [0, P) (its w3 / b3 slots with zeros), so it goes first.
             gh = torch.mm(g_mean, self.w3)
@@ -247,17 +248,16 @@ class DirectEpoch:
                  *[ptr(t) for t in self.w], self.act, ptr(gh), None,
                  ptr(self.partials), ptr(self.opt.flat_grad), ptr(self.stats),
                  st)
-            torch.mm(g_mean.t(), h2, out=self.g_w3)
-            torch.sum(g_mean, 0, out=self.g_b3)
+            call("tce_out_layer_grad_f32", ptr(g_mean), ptr(h2),
+                 ptr(self.g_w3), ptr(self.g_b3), ptr(self.ol_ws), N, K, 128,
+                 st)
+            end(g_L, c, N)          # g_L complete (second stream joined)
             call("tce_chol_build_bwd_f32", ptr(self.var), ptr(g_L),
                  ptr(self.g_var), 1, K, self.nvec, st)
             ag = self.agent
             ag._optimizer_step(self.opt, ag.policy_net_params,
-                               ag.clip_grad_norm)
+                               ag.clip_grad_norm, want_norms=False)
             # ---- record
-            entl = self.zero1 if c.ent_coef == 0.0 else \
-                (-c.ent_coef) * out[12:13]
-            total = sur[:1] + out[13:14] if c.ent_coef == 0.0 else \
-                sur[:1] + out[13:14] + entl
-            torch.cat([sur[:1], entl, out[13:14], total, out[12:13],
-                       self.opt.dev_state[1:3], out[:12]], out=rec_row)
+            assert rec_row.is_contiguous() and rec_row.numel() == 19
+            call("tce_policy_record_f32", ptr(sur), ptr(out),
+                 ptr(self.opt.dev_state) + 4, c.ent_coef, ptr(rec_row), st)
