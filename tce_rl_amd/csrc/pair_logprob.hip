@@ -364,12 +364,13 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
   }
 }
 
-// Block = EB (<= 64) envs x 4 waves; wave q takes the pairs q, q + 4, ...; lane
+// Block = EB (<= 64) envs x NW waves (blockDim / 64, <= 16); wave q takes the
+// pairs q, q + NW, ...; lane
 // = env.  The per-pair reduction S_p over the block's envs runs inside the
 // wave (alpha goes through a wave-private LDS slab, no block barrier), the
-// pair-sum of dmean over the 4 waves through LDS at the end.
+// pair-sum of dmean over the waves through LDS at the end.
 template <typename real, bool BWD>
-__global__ __launch_bounds__(256) void pair_env_kernel(
+__global__ __launch_bounds__(1024) void pair_env_kernel(
     const real* __restrict__ traj, const real* __restrict__ mean,
     const int64_t* __restrict__ pairs, const int* __restrict__ nonuniform,
     const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
@@ -385,16 +386,17 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
   real* Ws = smem;                               // [P][2 nbg + 4 + R*R + 1] compact
   const int cw = 2 * nbg + 4 + R * R + 1;
   real* ms = Ws + P * cw;                        // [EB][KP]      mean_n
-  real* gmp = ms + EB * KP;                      // [4][EB][KP]   grad mean per wave (BWD)
-  real* Ab = gmp + (BWD ? 4 * EB * KP : 0);      // [4][EB][RP]   alpha of the wave's current pair
-  real* gs = Ab + (BWD ? 4 * EB * RP : 0);       // [4][EB]
+  const int NW = blockDim.x >> 6, NT = blockDim.x;
+  real* gmp = ms + EB * KP;                      // [NW][EB][KP]  grad mean per wave (BWD)
+  real* Ab = gmp + (BWD ? NW * EB * KP : 0);     // [NW][EB][RP]  alpha of the wave's current pair
+  real* gs = Ab + (BWD ? NW * EB * RP : 0);      // [NW][EB]
   const int tid = threadIdx.x, q = tid >> 6, e = tid & 63;
   const int64_t n0 = (int64_t)blockIdx.x * EB;
   const int64_t n = n0 + e;
   const bool act = e < EB;
   const bool ok = act && n < N;
   const int64_t nc = n < N ? n : N - 1;
-  for (int i = tid; i < P * cw; i += 256) {
+  for (int i = tid; i < P * cw; i += NT) {
     const int p = i / cw, j = i - p * cw;
     const real* w = ws + (int64_t)p * wsp;
     real v;
@@ -403,18 +405,18 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
     else v = w[2 * nbg + 4 + R * K + 2 * R * R];                                            // logdet
     Ws[i] = v;
   }
-  for (int i = tid; i < EB * K; i += 256) {
+  for (int i = tid; i < EB * K; i += NT) {
     const int en = i / K, k = i - en * K;
     const int64_t nn = n0 + en < N ? n0 + en : N - 1;
     ms[en * KP + k] = mean[nn * K + k];
   }
   if (BWD)
-    for (int i = tid; i < 4 * EB * KP; i += 256) gmp[i] = 0;
+    for (int i = tid; i < NW * EB * KP; i += NT) gmp[i] = 0;
   __syncthreads();
   real* gmq = gmp + q * EB * KP + e * KP;
   real* Abq = Ab + q * EB * RP;
   real* gsq = gs + q * EB;
-  for (int p = q; p < P; p += 4) {
+  for (int p = q; p < P; p += NW) {
     const real* Hs = Ws + p * cw;
     const real* cs = Hs + 2 * nbg;
     const real* Li = cs + 4;
@@ -491,11 +493,13 @@ __global__ __launch_bounds__(256) void pair_env_kernel(
   }
   if (BWD) {
     __syncthreads();
-    for (int i = tid; i < EB * K; i += 256) {
+    for (int i = tid; i < EB * K; i += NT) {
       const int en = i / K, k = i - en * K;
       if (n0 + en < N) {
         const real* g0 = gmp + en * KP + k;
-        gmean[(n0 + en) * K + k] = (g0[0] + g0[EB * KP]) + (g0[2 * EB * KP] + g0[3 * EB * KP]);
+        real acc = 0;
+        for (int w = 0; w < NW; ++w) acc += g0[w * EB * KP];
+        gmean[(n0 + en) * K + k] = acc;
       }
     }
   }
@@ -614,10 +618,11 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   PFShape f{K, 2 * dof, P, nbg, dof};
   // envs per block of the fast path: as many as the LDS budget allows
   const int cw = 2 * nbg + 4 + f.R * f.R + 1;
-  auto env_lds = [&](int eb) {
-    return ((size_t)P * cw + (size_t)eb * pl_pitch(K) * (bwd ? 5 : 1) +
-            (bwd ? 4 * ((size_t)eb * (f.R + 1) + eb) : 0)) * sizeof(real);
+  auto env_lds_w = [&](int eb, int nw) {
+    return ((size_t)P * cw + (size_t)eb * pl_pitch(K) * (bwd ? 1 + nw : 1) +
+            (bwd ? nw * ((size_t)eb * (f.R + 1) + eb) : 0)) * sizeof(real);
   };
+  auto env_lds = [&](int eb) { return env_lds_w(eb, 4); };
   // up to 64 envs (one lane each) per block of 4 waves; fewer when the four
   // per-wave gradient slabs would not fit the LDS (fp64, K = 63)
   int EB = 64;
@@ -626,6 +631,11 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   // = 64 blocks of 64): the kernel is a chain of dependent steps per wave, so
   // blocks of 16 envs on every unit beat full waves on a quarter of them
   while (EB > 16 && ceil_div(N, EB) < pl_cu_count()) EB >>= 1;
+  // waves per block: 4, or -- few envs per block -- up to 12 so that a wave
+  // walks through 2-3 pairs instead of P / 4
+  int NWV = 4;
+  if (EB <= 16)
+    while (NWV < 12 && NWV * 2 < P && env_lds_w(EB, NWV + 4) <= 64 * 1024) NWV += 4;
   const int nblk = (int)ceil_div(N, EB);
   const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1) +
                            (bwd ? (int64_t)P * K * K : 0);
@@ -645,13 +655,13 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
                          flag, reg, wsp, f);
       TCE_LAUNCH_CHECK();
     }
-    const size_t lds = env_lds(EB);
+    const size_t lds = env_lds_w(EB, NWV);
     TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: fast path LDS");
     if (bwd) {
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(256), lds, stream,
+      hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f, EB);
       TCE_LAUNCH_CHECK();
@@ -668,7 +678,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(256), lds, stream,
+      hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f, EB);
     }
