@@ -409,14 +409,17 @@ def test_bbrl_step_matches_cpu_oracle():
                                oracle.var.detach(), rtol=5e-3, atol=5e-4)
 
 
-def test_fused_objective_reports_the_same_metrics():
-    """The fused policy objective (one autograd node) and the op-by-op path
-    return the same losses and KL diagnostics."""
+@pytest.mark.parametrize("ent_coef", [0.0, 0.01])
+def test_fused_objective_reports_the_same_metrics(ent_coef):
+    """The fused policy objective (ONE C call, tce_policy_objective_*) and the
+    op-by-op path return the same losses, KL diagnostics and gradient norm --
+    also with an entropy bonus (its gradient is added inside the call)."""
     res = []
     for fused in (True, False):
         torch.manual_seed(3)
         agent, _ = build(64, 4, False, fused_policy_objective=fused,
-                         graph_policy_update=fused)
+                         graph_policy_update=fused,
+                         entropy_penalty_coef=ent_coef)
         torch.manual_seed(5)
         res.append(agent.step())
     a, b = res
@@ -491,3 +494,31 @@ def test_agent_option_matrix(opts):
         assert np.isfinite(res[k]), k
     for p in exp.agent.policy.parameters + exp.agent.critic.parameters:
         assert torch.isfinite(p).all()
+
+
+def test_full_size_step_is_repeatable_and_inside_the_trust_region():
+    """BASELINE configs[1] at full size (4096 envs, T 500, 50 + 50 epochs), the
+    size-independent properties: two runs from the same seeds end bit-identical
+    (every reduction has a fixed order, also with the critic, the policy and
+    the K x K kernels on three streams), the projected policy stays inside the
+    KL bounds and nothing is non-finite."""
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        agent, cfg = build(4096, 50, True, num_basis=5)
+        torch.manual_seed(12)
+        res = [agent.step() for _ in range(2)][-1]
+        runs.append((res, to_cpu_params(agent.policy.mean_net),
+                     to_cpu_params(agent.critic.net),
+                     agent.policy.variance_net.variable.detach().cpu().clone()))
+        del agent
+    (ra, pa, ca, va), (rb, pb, cb, vb) = runs
+    for x, y in zip(pa + ca + [va], pb + cb + [vb]):
+        assert torch.equal(x, y)
+    p = cfg["params"]["projection"]["args"]
+    assert ra["projection_proj_old_cov_diff_max"] <= p["cov_bound"] * 1.02
+    assert ra["projection_proj_old_mean_diff_max"] <= p["mean_bound"] * 1.02
+    for k, v in ra.items():
+        if isinstance(v, float):
+            assert np.isfinite(v), k
+    assert ra["num_global_steps"] == 2 * 4096 * 500

@@ -96,3 +96,59 @@ def test_kl_shared_vs_oracle(dtype, N, K, include_cov):
                                                                    dtype=f64)
     torch.testing.assert_close(gL.double().cpu(), want_gL, rtol=tol,
                                atol=tol * max(want_gL.abs().max().item(), 1.0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("N,K,H", [(1, 24, 128), (33, 8, 64), (4096, 24, 128),
+                                   (1000, 63, 256), (257, 3, 128)])
+def test_out_layer_grad(dtype, N, K, H):
+    """dW = g^T h, db = sum g of a final Linear layer against torch float64."""
+    from tce_rl_amd import _lib
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    gen = torch.Generator().manual_seed(N + K + H)
+    g = torch.randn(N, K, generator=gen, dtype=torch.float64)
+    h = torch.randn(N, H, generator=gen, dtype=torch.float64)
+    gd, hd = g.to(dtype).cuda(), h.to(dtype).cuda()
+    dW = torch.empty(K, H, dtype=dtype, device="cuda")
+    db = torch.empty(K, dtype=dtype, device="cuda")
+    ws = torch.empty(_lib.load().tce_out_layer_grad_ws_len(N, K, H),
+                     dtype=dtype, device="cuda")
+    call("tce_out_layer_grad_" + sfx(dtype), ptr(gd), ptr(hd), ptr(dW),
+         ptr(db), ptr(ws), N, K, H, stream())
+    tol = 2e-5 if dtype == torch.float32 else 1e-12
+    scale = math.sqrt(N)
+    torch.testing.assert_close(dW.double().cpu(), g.t() @ h, rtol=tol,
+                               atol=tol * scale)
+    torch.testing.assert_close(db.double().cpu(), g.sum(0), rtol=tol,
+                               atol=tol * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ent_coef", [0.0, 0.05])
+def test_policy_record_row(dtype, ent_coef):
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    sur = torch.tensor([0.7, 1.01], dtype=dtype, device="cuda")
+    out = torch.arange(16, dtype=dtype, device="cuda") * 0.1 + 1
+    norms = torch.tensor([3.0, 0.5], dtype=dtype, device="cuda")
+    row = torch.empty(19, dtype=dtype, device="cuda")
+    call("tce_policy_record_" + sfx(dtype), ptr(sur), ptr(out), ptr(norms),
+         ent_coef, ptr(row), stream())
+    entl = -ent_coef * out[12]
+    want = torch.cat([sur[:1], entl[None], out[13:14],
+                      (sur[0] + out[13] + entl)[None], out[12:13], norms,
+                      out[:12]])
+    torch.testing.assert_close(row, want, rtol=1e-6, atol=0)
+
+
+def test_objective_entry_points_reject_bad_arguments():
+    import ctypes
+    lib = __import__("tce_rl_amd._lib", fromlist=["load"]).load()
+    x = torch.zeros(64, device="cuda")
+    p = x.data_ptr()
+    assert lib.tce_out_layer_grad_f32(p, p, p, p, p, 4, 65, 128, None) != 0
+    assert b"K <= 64" in lib.tce_last_error()
+    assert lib.tce_out_layer_grad_f32(None, p, p, p, p, 4, 8, 128, None) != 0
+    assert lib.tce_policy_record_f32(None, p, p, 0.0, p, None) != 0
+    assert lib.tce_policy_objective_end_f32(None, p, 4, 8, 2, None) != 0
+    assert lib.tce_policy_objective_begin_f32(None, 3, 1e-3, p, 1e-3, None, 0,
+                                              p, p, p, 4, 8, 2, None) != 0
