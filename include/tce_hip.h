@@ -178,6 +178,11 @@ int tce_pair_logprob_bwd_f64(
     const double* init_vel, double reg, const double* grad_logp, double* grad_mean,
     double* grad_L, double* basis_ws, int* flag_ws, double* work, int64_t N, int T,
     int P, int dof, void* stream);
+/* Scheduling hint, process-wide: the number of compute units the caller expects
+ * to be free for the kernels it is about to enqueue (0 = the whole chip, the
+ * default).  The pair log-prob fast path trades latency for wave-instructions
+ * only when most of the chip is free; results do not depend on it. */
+int tce_set_cu_budget(int compute_units);
 /* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
  * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M);

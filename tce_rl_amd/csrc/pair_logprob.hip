@@ -274,6 +274,7 @@ inline int64_t tce_sum_dim0_slices_impl(int64_t N, int64_t M) {
 }
 
 struct PFShape { int K, R, P, nbg, dof; };
+int g_cu_budget = 0;       // tce_set_cu_budget: compute units the caller expects to be free (0: all)
 inline int pl_cu_count() {
   static int n = 0;
   if (!n) {
@@ -630,11 +631,16 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   // ... and fewer when that leaves compute units without a block (C2: 4096 envs
   // = 64 blocks of 64): the kernel is a chain of dependent steps per wave, so
   // blocks of 16 envs on every unit beat full waves on a quarter of them
-  while (EB > 16 && ceil_div(N, EB) < pl_cu_count()) EB >>= 1;
+  const int cus_free = g_cu_budget > 0 ? g_cu_budget : pl_cu_count();
+  while (EB > 16 && ceil_div(N, EB) < cus_free) EB >>= 1;
   // waves per block: 4, or -- few envs per block -- up to 12 so that a wave
   // walks through 2-3 pairs instead of P / 4
+  // -- unless the caller has said that most of the chip is busy with something
+  // else (tce_set_cu_budget: the critic epochs beside the policy stream); then
+  // wave-instructions count, not latency, and 12 quarter-filled waves lose
+  // (measured beside the critic: backward 103 -> 147 us, step 111.5 -> 112.6 ms)
   int NWV = 4;
-  if (EB <= 16)
+  if (EB <= 16 && (g_cu_budget <= 0 || g_cu_budget >= pl_cu_count() / 2))
     while (NWV < 12 && NWV * 2 < P && env_lds_w(EB, NWV + 4) <= 64 * 1024) NWV += 4;
   const int nblk = (int)ceil_div(N, EB);
   const int64_t fast_len = (int64_t)P * pf_ws_pair(f) + (int64_t)nblk * P * (f.R * f.R + 1) +
@@ -740,6 +746,11 @@ int64_t pl_work_len(int64_t N, int P, int dof, int nbg, int64_t sL, bool bwd) {
 extern "C" {
 
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M) { return tce_sum_dim0_slices_impl(N, M); }
+
+int tce_set_cu_budget(int compute_units) {
+  g_cu_budget = compute_units;
+  return 0;
+}
 
 /* workspace (in elements of the dtype) of the pair log-prob calls; 0 for a
  * per-env L */

@@ -400,7 +400,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
             side.wait_event(ev[0])
             with torch.cuda.stream(side):
                 ev[2].record(side)
-                policy_loss_dict = self.update_policy(dataset)
+                policy_loss_dict = self._update_policy_beside_critic(dataset)
                 ev[3].record(side)
                 finish_side = side_work() if side_work is not None else dict
             main.wait_stream(side)
@@ -427,7 +427,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         side.wait_event(ev[0])
         with torch.cuda.stream(side):
             ev[2].record(side)
-            policy_loss_dict = self.update_policy(dataset)
+            policy_loss_dict = self._update_policy_beside_critic(dataset)
             ev[3].record(side)
             finish_side = side_work() if side_work is not None else dict
             ev[5].record(side)
@@ -459,6 +459,17 @@ class TemporalCorrelatedAgent(AbstractAgent):
         return critic_loss_dict, policy_loss_dict, \
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
+
+    def _update_policy_beside_critic(self, dataset):
+        """The policy update while the critic's persistent grid holds most of
+        the chip: tell the library so (tce_set_cu_budget), its kernels then
+        prefer few full waves over many short ones."""
+        from .._lib import call
+        call("tce_set_cu_budget", 256 - min(self.critic_workgroups, 224))
+        try:
+            return self.update_policy(dataset)
+        finally:
+            call("tce_set_cu_budget", 0)
 
     def _make_update_streams(self):
         """Second stream for the policy epochs; with ``critic_cus_per_xcd`` both
