@@ -6,6 +6,16 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+_DEVIATIONS = None
+
+
+def _close(name, got, want, rel):
+    """max |got - want| <= rel * max(1, max |want|)."""
+    scale = max(1.0, want.abs().max().item())
+    err = (got.double() - want.double()).abs().max().item()
+    if _DEVIATIONS is not None:                 # scripts/probe_agent_tol.py
+        _DEVIATIONS.append((name, err, scale))
+    assert err <= rel * scale, (name, err, rel * scale)
 
 
 def build(num_env, epochs, overlap, env="metaworld", num_basis=5,
@@ -130,31 +140,45 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32", **kw):
     ref = oracle.last
     assert np.array_equal(agent.sampler.pred_pairs.cpu().numpy(),
                           ref["pred_pairs"].numpy())           # bit-exact indexing
-    tol = dict(rtol=2e-4, atol=2e-4)
-    torch.testing.assert_close(captured["step_actions"], ref["step_actions"],
-                               rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(captured["step_rewards"], ref["step_rewards"],
-                               rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(captured["step_values"], ref["step_values"],
-                               **tol)
-    torch.testing.assert_close(captured["step_returns"], ref["step_returns"],
-                               rtol=2e-4, atol=2e-3)
-    torch.testing.assert_close(captured["step_advantages"],
-                               ref["step_advantages"], rtol=2e-4, atol=2e-3)
-    torch.testing.assert_close(captured["segment_advantage"],
-                               ref["segment_advantage"], rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(captured["segment_log_prob_estimate"],
-                               ref["segment_log_prob_estimate"], rtol=5e-4,
-                               atol=5e-3)
+    # Tolerances: max |gpu - oracle| <= rel * max(1, max |oracle|) per tensor,
+    # rel = 8-10 x the largest deviation seen over every case of this file
+    # (scripts/probe_agent_tol.py, table in DESIGN.md section 5) -- all of it
+    # float32 rounding, nothing structural:
+    #  * actions: a K-term dot product of basis values and parameters, a few
+    #    eps32 = 6e-8 per term (seen 2e-7 relative);
+    #  * values: three 128-wide layers (2e-6); returns / advantages: the
+    #    lambda-discounted scan over T steps adds the value errors of the later
+    #    steps, relative to max |return| that is still 3e-7;
+    #  * log-prob: the pair covariance has a 1e-4 floor, so a mean error is
+    #    amplified by up to 1 / sigma_min = 100 (seen 4e-6 of max |logp|);
+    #  * parameters after EPOCHS Adam steps: Adam's step lr m / (sqrt v + eps)
+    #    is scale free, so a relative gradient error delta moves a parameter by
+    #    ~ lr * delta per step; the policy's gradient passes the projection's
+    #    implicit derivative (seen 5e-5 of max |w|), the critic's 8e-6.
+    # float64 runs: the rollout quantities keep a floor of ~1e-6 because the
+    # product's and the oracle's ProDMP tables are two independent
+    # discretisations of the same ODE (tests/test_prodmp_ode_cpu.py bounds
+    # both against the integrated ODE); the parameters agree to 1e-7.
+    f64 = dtype == "float64"
+
+    close = _close
+    close("step_actions", captured["step_actions"], ref["step_actions"], 3e-6)
+    close("step_rewards", captured["step_rewards"], ref["step_rewards"], 3e-6)
+    close("step_values", captured["step_values"], ref["step_values"], 2e-5)
+    close("step_returns", captured["step_returns"], ref["step_returns"], 5e-6)
+    close("step_advantages", captured["step_advantages"],
+          ref["step_advantages"], 5e-6)
+    close("segment_advantage", captured["segment_advantage"],
+          ref["segment_advantage"], 5e-6)
+    close("segment_log_prob_estimate", captured["segment_log_prob_estimate"],
+          ref["segment_log_prob_estimate"], 4e-5)
     # parameters after EPOCHS critic + policy updates
     for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
-        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=2e-3,
-                                   atol=2e-5)
+        close("critic", pg.detach().cpu(), po.detach(), 1e-7 if f64 else 5e-5)
     for pg, po in zip(agent.policy.mean_net.parameters(), oracle.pnet):
-        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=5e-3,
-                                   atol=5e-5)
-    torch.testing.assert_close(agent.policy.variance_net.variable.detach().cpu(),
-                               oracle.var.detach(), rtol=5e-3, atol=5e-5)
+        close("policy", pg.detach().cpu(), po.detach(), 1e-6 if f64 else 3e-4)
+    close("variance", agent.policy.variance_net.variable.detach().cpu(),
+          oracle.var.detach(), 1e-6 if f64 else 3e-5)
     assert np.isfinite(res["critic_loss_mean"])
 
 
@@ -203,21 +227,18 @@ def test_deterministic_evaluation_matches_cpu_oracle(env, nb):
     assert sto == {}
     assert np.array_equal(agent.sampler.pred_pairs.cpu().numpy(),
                           ref["pred_pairs"].numpy())
-    # the policy / critic differ by one fp32 training step (tolerances of
-    # _agent_vs_oracle: parameters agree to rtol 5e-3 there); the evaluation
-    # rollout itself adds nothing to that
+    # the policy / critic differ by one fp32 training step (parameters agree to
+    # 3e-4 there, see _agent_vs_oracle); the evaluation rollout itself adds
+    # float32 rounding only.  Bounds = 10 x the largest deviation seen
+    # (scripts/probe_agent_tol.py).
     c = lambda k: det[k].detach().cpu()
-    torch.testing.assert_close(c("step_actions"), ref["step_actions"],
-                               rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(c("step_rewards"), ref["step_rewards"],
-                               rtol=1e-3, atol=2e-3)
-    torch.testing.assert_close(c("episode_reward"), ref["episode_reward"],
-                               rtol=1e-3, atol=5e-2)
-    torch.testing.assert_close(c("step_values"), ref["step_values"],
-                               rtol=2e-3, atol=2e-3)
-    torch.testing.assert_close(c("segment_log_prob_estimate"),
-                               ref["segment_log_prob_estimate"], rtol=5e-4,
-                               atol=5e-3)
+    _close("eval step_actions", c("step_actions"), ref["step_actions"], 1e-5)
+    _close("eval step_rewards", c("step_rewards"), ref["step_rewards"], 1e-5)
+    _close("eval episode_reward", c("episode_reward"), ref["episode_reward"],
+           3e-6)
+    _close("eval step_values", c("step_values"), ref["step_values"], 1e-5)
+    _close("eval log_prob", c("segment_log_prob_estimate"),
+           ref["segment_log_prob_estimate"], 1e-5)
     assert torch.equal(c("success"), ref["success"])
     # deterministic: the trajectory is the one of the mean parameters
     mean = det["segment_params_mean"]
@@ -389,24 +410,24 @@ def test_bbrl_step_matches_cpu_oracle():
     agent.step()
     oracle.step()
     ref = oracle.last
-    torch.testing.assert_close(captured["segment_action"],
-                               ref["segment_action"], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(captured["segment_log_prob"],
-                               ref["segment_log_prob"], rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(captured["segment_value"], ref["segment_value"],
-                               rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(captured["segment_reward"],
-                               ref["segment_reward"], rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(captured["segment_advantage"],
-                               ref["segment_advantage"], rtol=1e-3, atol=1e-3)
+    # float32 rounding only: bounds = 10-30 x the largest deviation seen
+    # (32-wide nets, diagonal covariance: shorter sums than the TCE step)
+    _close("segment_action", captured["segment_action"], ref["segment_action"],
+           3e-6)
+    _close("segment_log_prob", captured["segment_log_prob"],
+           ref["segment_log_prob"], 2e-6)
+    _close("segment_value", captured["segment_value"], ref["segment_value"],
+           2e-6)
+    _close("segment_reward", captured["segment_reward"], ref["segment_reward"],
+           2e-6)
+    _close("segment_advantage", captured["segment_advantage"],
+           ref["segment_advantage"], 5e-6)
     for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
-        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=2e-3,
-                                   atol=2e-5)
+        _close("critic", pg.detach().cpu(), po.detach(), 2e-6)
     for pg, po in zip(agent.policy.mean_net.parameters(), oracle.pnet):
-        torch.testing.assert_close(pg.detach().cpu(), po.detach(), rtol=5e-3,
-                                   atol=5e-5)
-    torch.testing.assert_close(agent.policy.variance_net.variable.detach().cpu(),
-                               oracle.var.detach(), rtol=5e-3, atol=5e-4)
+        _close("policy", pg.detach().cpu(), po.detach(), 3e-6)
+    _close("variance", agent.policy.variance_net.variable.detach().cpu(),
+           oracle.var.detach(), 3e-6)
 
 
 @pytest.mark.parametrize("ent_coef", [0.0, 0.01])
@@ -501,11 +522,15 @@ def test_full_size_step_is_repeatable_and_inside_the_trust_region():
     size-independent properties: two runs from the same seeds end bit-identical
     (every reduction has a fixed order, also with the critic, the policy and
     the K x K kernels on three streams), the projected policy stays inside the
-    KL bounds and nothing is non-finite."""
+    KL bounds and nothing is non-finite.  The adaptive critic split is off:
+    it picks, from measured times, how many critic epochs run on 224 instead
+    of 256 workgroups, and the number of per-workgroup gradient slabs is part
+    of the summation order (float32 rounding, not repeatable bit for bit)."""
     runs = []
     for _ in range(2):
         torch.manual_seed(11)
-        agent, cfg = build(4096, 50, True, num_basis=5)
+        agent, cfg = build(4096, 50, True, num_basis=5,
+                           adaptive_critic_split=False)
         torch.manual_seed(12)
         res = [agent.step() for _ in range(2)][-1]
         runs.append((res, to_cpu_params(agent.policy.mean_net),
