@@ -1,0 +1,47 @@
+"""torch.library registration of the hot-path operators (tce_rl_amd/torch_ops.py):
+schemas exist, shape inference works without a GPU, and there is no CPU
+implementation to fall back to."""
+import pytest
+import torch
+
+
+def test_ops_are_registered_with_schemas():
+    import tce_rl_amd.torch_ops  # noqa: F401
+    ns = torch.ops.tce_rl_amd
+    for name in ("gae", "segment_advantage", "mdp_reward", "rms_update",
+                 "mvn_log_prob", "maha", "kl_mean_projection",
+                 "kl_cov_projection", "critic_values"):
+        op = getattr(ns, name)
+        assert "tce_rl_amd::" + name in str(op.default._schema)
+    s = str(ns.rms_update.default._schema)            # mutation is declared
+    assert "!) mean" in s and "!) var" in s
+
+
+def test_fake_implementations_infer_shapes():
+    import tce_rl_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ns = torch.ops.tce_rl_amd
+    with FakeTensorMode():
+        r = torch.empty(8, 50)
+        v = torch.empty(8, 51)
+        d = torch.empty(8, 50, dtype=torch.bool)
+        adv, ret = ns.gae(r, v, d, d, 0.99, 0.95, True)
+        assert adv.shape == ret.shape == (8, 50)
+        pairs = torch.empty(6, 2, dtype=torch.int64)
+        seg = ns.segment_advantage("value_subtraction", r, v, adv, pairs, 0.99,
+                                   True, 0.0)
+        assert seg.shape == (8, 6)
+        x, L = torch.empty(8, 5), torch.empty(5, 5)
+        assert ns.mvn_log_prob(x, x, L).shape == (8,)
+        assert ns.kl_mean_projection(x, x, L, 0.01).shape == (8, 5)
+        proj, ctx = ns.kl_cov_projection(torch.empty(1, 5, 5), L, 1e-3)
+        assert proj.shape == (1, 5, 5) and ctx.dtype == torch.float64
+
+
+def test_no_cpu_implementation():
+    import tce_rl_amd.torch_ops  # noqa: F401
+    r = torch.zeros(4, 10)
+    v = torch.zeros(4, 11)
+    d = torch.zeros(4, 10, dtype=torch.bool)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.tce_rl_amd.gae(r, v, d, d, 0.99, 0.95, True)
