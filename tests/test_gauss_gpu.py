@@ -262,3 +262,64 @@ def test_kl_cov_projection_kernel_is_the_constrained_optimum(ops, K):
     # objective (eta = O(10) here)
     assert abs(f - f_ref) <= 1e-8 * max(1.0, abs(f_ref)) + 20 * abs(slack)
     np.testing.assert_allclose(proj.numpy(), C_ref, rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("N,K", [(1, 1), (1, 64), (2, 2), (15, 3), (17, 64),
+                                 (33, 63), (130, 24), (4096, 24)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_shared_factor_lane_vector_kernels_edge_shapes(ops, N, K, dtype):
+    """vec_env_shared_kernel (wave = env, lane = vector element; csrc/lanevec.h)
+    at the edges of its mapping: one env, odd env counts (a wave's second env
+    missing, partial last block), K = 1 and K = 64 (every lane) -- maha,
+    log-prob and the mean projection with their gradients against the
+    float64 oracle formulas."""
+    g = torch.Generator().manual_seed(1000 * K + N)
+    L = rand_chol(K, 0.7, g, 1)[0]
+    x = torch.randn(N, K, generator=g, dtype=F64)
+    y = x + 0.4 * torch.randn(N, K, generator=g, dtype=F64)
+    w = torch.randn(N, generator=g, dtype=F64)
+    wk = torch.randn(N, K, generator=g, dtype=F64)
+    Lf = L.expand(N, -1, -1)
+    tol = dict(rtol=3e-4, atol=3e-4) if dtype == torch.float32 else \
+        dict(rtol=1e-9, atol=1e-9)
+    dev = lambda t: t.to(dtype).cuda()
+    Lg = ops.expand_shared(dev(L), N)
+    # maha + gradient
+    xc = x.clone().requires_grad_(True)
+    mc = O.maha(xc, y, Lf)
+    (mc * w).sum().backward()
+    xg = dev(x).requires_grad_(True)
+    mg = ops.maha(xg, dev(y), Lg)
+    (mg * dev(w)).sum().backward()
+    torch.testing.assert_close(mg.double().cpu(), mc.detach(), **tol)
+    torch.testing.assert_close(xg.grad.double().cpu(), xc.grad, **tol)
+    # log-prob + gradients w.r.t. mean and the shared factor
+    mean_c = y.clone().requires_grad_(True)
+    L_c = L.clone().requires_grad_(True)
+    lp_c = torch.distributions.MultivariateNormal(
+        mean_c, scale_tril=L_c.expand(N, -1, -1)).log_prob(x)
+    (lp_c * w).sum().backward()
+    mean_g = dev(y).requires_grad_(True)
+    L_g = dev(L).requires_grad_(True)
+    lp_g = ops.mvn_log_prob(dev(x), mean_g, ops.expand_shared(L_g, N))
+    (lp_g * dev(w)).sum().backward()
+    torch.testing.assert_close(lp_g.double().cpu(), lp_c.detach(),
+                               rtol=tol["rtol"], atol=tol["atol"] * K)
+    torch.testing.assert_close(mean_g.grad.double().cpu(), mean_c.grad, **tol)
+    scale = max(1.0, L_c.grad.abs().max().item())
+    torch.testing.assert_close(torch.tril(L_g.grad.double().cpu()),
+                               torch.tril(L_c.grad), rtol=tol["rtol"],
+                               atol=tol["atol"] * scale)
+    # mean projection (some rows active, some not) + gradient
+    eps = 0.5 * float(mc.detach().median()) * 0.5 + 1e-6
+    mu_c = x.clone().requires_grad_(True)
+    maha_c, _ = KO.gaussian_kl(mu_c, Lf, y, Lf)
+    pm_c = KO.mean_projection(mu_c, y, maha_c, eps)
+    (pm_c * wk).sum().backward()
+    mu_g = dev(x).requires_grad_(True)
+    pm_g = ops.kl_mean_projection(mu_g, dev(y), Lg, eps)
+    (pm_g * dev(wk)).sum().backward()
+    torch.testing.assert_close(pm_g.double().cpu(), pm_c.detach(), **tol)
+    gs = max(1.0, mu_c.grad.abs().max().item())
+    torch.testing.assert_close(mu_g.grad.double().cpu(), mu_c.grad,
+                               rtol=tol["rtol"], atol=tol["atol"] * gs)
