@@ -377,6 +377,12 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
  * log-prob calls).  proj_started != 0: see tce_policy_objective_begin_*;
  * defer_join != 0: see tce_policy_objective_end_*. */
 int64_t tce_policy_objective_ws_len(int64_t N, int K, int P);
+/* n = 1: everything on the caller's stream (no second stream, no events); n = 2
+ * (default): as described above.  A process that already drives more streams
+ * than the device has hardware queues (e.g. the critic stream, the policy
+ * stream and the streams of two RCCL communicators) should say 1: streams that
+ * share a hardware queue wait for each other's kernels. */
+int tce_policy_objective_streams(int n);
 int tce_policy_objective_f32(
     const float* mean_new, const float* L_new, const float* mean_old, const float* L_old,
     const float* traj, const float* logp_old, const float* adv, const int64_t* pairs,

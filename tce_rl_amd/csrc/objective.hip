@@ -260,6 +260,8 @@ struct ObjSide {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+int g_obj_streams = 2;            // tce_policy_objective_streams: 1 = everything on the caller's stream
+
 inline ObjSide* obj_side() {
   static ObjSide s;
   static bool tried = false, ok = false;
@@ -325,7 +327,7 @@ template <> struct ObjApi<double> {
   } while (0)
 #define OBJ_HIP(call)                                          \
   do {                                                         \
-    if ((call) != hipSuccess) {                                \
+    if (!single && (call) != hipSuccess) {                     \
       tce_set_error("policy_objective: stream / event call");  \
       return 1;                                                \
     }                                                          \
@@ -349,9 +351,10 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
                 "policy_objective: null buffer");
   TCE_CHECK_ARG(N > 0 && T > 0 && P > 0 && K == dof * nbg && K <= 64,
                 "policy_objective: bad sizes (K = dof * nbg <= 64)");
-  ObjSide* S = obj_side();
-  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
-  hipStream_t sd = S->side;
+  const bool single = g_obj_streams < 2;
+  ObjSide* S = single ? nullptr : obj_side();
+  TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+  hipStream_t sd = single ? st : S->side;
   real* pm = ws;                                  // projected mean [N,K]
   real* g_pm = pm + obj_up4(N * K);               // d / d pm
   real* gm_p = g_pm + obj_up4(N * K);             // ... back through the mean projection
@@ -416,8 +419,9 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
 template <typename real>
 int policy_objective_end(real* grad_L, real* ws, int64_t N, int K, int P, hipStream_t st) {
   TCE_CHECK_ARG(grad_L && ws && N > 0 && K > 0 && K <= 64, "policy_objective_end: bad arguments");
-  ObjSide* S = obj_side();
-  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  const bool single = g_obj_streams < 2;
+  ObjSide* S = single ? nullptr : obj_side();
+  TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
   const int64_t n2 = (int64_t)K * K;
   real* gL_p = obj_proj_L(ws, N, K, P) + 2 * obj_up4(n2);
@@ -437,14 +441,16 @@ int policy_objective_begin(const real* var_vec, int nvec, real min_std, const re
   typedef ObjApi<real> A;
   TCE_CHECK_ARG(var_vec && L_old && proj_ctx && L_new && ws && N > 0 && K > 0 && K <= 64,
                 "policy_objective_begin: bad arguments");
-  ObjSide* S = obj_side();
-  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  const bool single = g_obj_streams < 2;
+  ObjSide* S = single ? nullptr : obj_side();
+  TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+  hipStream_t sd = single ? st : S->side;
   OBJ_HIP(hipEventRecord(S->ev[0], st));
-  OBJ_HIP(hipStreamWaitEvent(S->side, S->ev[0], 0));
-  OBJ_TRY(A::chol_fwd(var_vec, L_new, 1, K, nvec, min_std, S->side));
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
+  OBJ_TRY(A::chol_fwd(var_vec, L_new, 1, K, nvec, min_std, sd));
   OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, obj_proj_L(ws, N, K, P),
-                      proj_ctx, 1, K, 1, S->side));
-  OBJ_HIP(hipEventRecord(S->ev[1], S->side));
+                      proj_ctx, 1, K, 1, sd));
+  OBJ_HIP(hipEventRecord(S->ev[1], sd));
   return 0;
 }
 
@@ -586,6 +592,11 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
 }
 
 int64_t tce_policy_objective_ws_len(int64_t N, int K, int P) { return obj_ws_len(N, K, P); }
+
+int tce_policy_objective_streams(int n) {
+  g_obj_streams = n < 2 ? 1 : 2;
+  return 0;
+}
 
 #define DEFINE_POLICY_OBJECTIVE(SFX, REAL)                                                \
   int tce_policy_objective_##SFX(                                                         \

@@ -460,6 +460,18 @@ class TemporalCorrelatedAgent(AbstractAgent):
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
 
+    def _objective_streams(self):
+        """The fused objective's second stream only where hardware queues are
+        to spare: a sharded run already drives the critic stream, the policy
+        stream and the streams of two RCCL communicators, and streams that
+        share a hardware queue wait for each other's kernels (measured: the
+        K x K kernels queued behind 2 ms critic launches, 2.7 ms per epoch)."""
+        import os
+        from .._lib import call
+        n = int(os.environ.get("TCE_OBJECTIVE_STREAMS", "0")) or \
+            (1 if self.dist.active else 2)
+        call("tce_policy_objective_streams", n)
+
     def _update_policy_beside_critic(self, dataset):
         """The policy update while the critic's persistent grid holds most of
         the chip: tell the library so (tce_set_cu_budget), its kernels then
@@ -581,6 +593,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
 
     # ---- policy ------------------------------------------------------------------
     def update_policy(self, dataset):
+        self._objective_streams()
         D2 = self.policy.num_dof * 2
         states = dataset["segment_state"][..., :-D2]
         actions = dataset["step_actions"]

@@ -547,3 +547,20 @@ def test_full_size_step_is_repeatable_and_inside_the_trust_region():
         if isinstance(v, float):
             assert np.isfinite(v), k
     assert ra["num_global_steps"] == 2 * 4096 * 500
+
+
+def test_objective_on_one_stream_equals_two_streams(monkeypatch):
+    """tce_policy_objective_streams(1) -- what a sharded run uses, where the
+    second stream would share a hardware queue with the critic's -- runs the
+    same kernels in one stream order: bit-identical parameters."""
+    out = []
+    for n in ("1", "2"):
+        monkeypatch.setenv("TCE_OBJECTIVE_STREAMS", n)
+        torch.manual_seed(21)
+        agent, _ = build(256, 4, True, adaptive_critic_split=False)
+        torch.manual_seed(22)
+        agent.step()
+        out.append(to_cpu_params(agent.policy.mean_net) +
+                   [agent.policy.variance_net.variable.detach().cpu().clone()])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
