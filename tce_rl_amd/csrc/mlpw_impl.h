@@ -25,12 +25,14 @@
 //   written to the other buffer; ONE barrier per panel.  W2 stays L2 resident
 //   (every workgroup streams the same 2 x H*H*s bytes per tile).  The kernel
 //   also writes H1, dY2 and dY1 of its rows to HBM ([R][H] each) and sums
-//   db1, db2, dw3, db3 and the loss.
+//   dw3, db3 and the loss.
 //  gradient kernel (mlpw_grad_kernel): dW2 = dY2^T H1 and dW1 = dY1^T X as a
 //   split-K product over those arrays: a workgroup takes a contiguous range
 //   of rows, stages KC rows at a time in LDS ([row][unit], double buffered)
 //   and keeps its dW2 / dW1 block in the registers of its 8 waves (fp64,
-//   H = 256: two workgroups per row range, half of dW2 each).
+//   H = 256: two workgroups per row range, half of dW2 each); db2 / db1 are
+//   the column sums of its dY2 / dY1 fragments (one add per fragment load
+//   instead of 128 DPP row sums per tile in the chain kernel).
 //  mlpw_finish_kernel reduces the per-workgroup slabs in fixed order (+ Adam).
 //
 // MFMA-bound: per row 2 (D H + H H + H) forward + 2 H H (dH1) + 2 (H H + D H)
@@ -182,7 +184,7 @@ struct ChainLds {
   static constexpr int PANEL = WCfg<real>::PU * WP;
   static constexpr size_t bytes(bool bwd) {
     return sizeof(real) * ((size_t)H * W1P + 3 * H + 2 * PANEL +
-                           (bwd ? (size_t)WCfg<real>::NACC * 3 * H : 0)) + 64;
+                           (bwd ? (size_t)WCfg<real>::NACC * H : 0)) + 64;
   }
 };
 
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   real* W1s = reinterpret_cast<real*>(smem_raw);             // [H][W1P] natural rows
   real* Bs = W1s + H * W1P;                                  // b1 | b2 | w3, position order
   real* pan = Bs + 3 * H;                                    // [2][PU][WP]
-  real* gacc = pan + 2 * LD::PANEL;                          // [NACC][3][H] db1 | db2 | dw3 (positions)
+  real* gacc = pan + 2 * LD::PANEL;                          // [NACC][H] dw3 (positions)
   __shared__ real sred[2 * C::WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     Bs[2 * H + e] = a.w3[u];
   }
   if (BWD)
-    for (int e = tid; e < C::NACC * 3 * H; e += NT) gacc[e] = real(0);
+    for (int e = tid; e < C::NACC * H; e += NT) gacc[e] = real(0);
 
   // ---- panel stream: step s of a tile reads W2p rows (s < NP) or W2Tp rows
   auto panel_src = [&](int s) -> const real* {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   const real b3 = a.b3[0];
   const real inv_n = real(1) / (real)a.R;
   real loss_sum = 0, gb3 = 0;
-  real* my_acc = gacc + (wave % C::NACC) * 3 * H;
+  real* my_acc = gacc + (wave % C::NACC) * H;
   constexpr bool ACC_ATOMIC = C::NACC < C::WAVES;
 
   // x fragment: lane group g holds features KPG g + s of the lane's row (zeros
@@ -494,8 +496,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       }
       // dY2 = dv w3 act'(H2): the parked H2 tiles come back (this lane reads
       // what it wrote), dY2 replaces them in the workspace and stays in
-      // registers as the B operand of the backward panels; dw3, db2 = sums
-      // over the 16 batch lanes of a row
+      // registers as the B operand of the backward panels; dw3 = sums over the
+      // 16 batch lanes of a row (db2 and db1 are column sums of the dY2 / dY1
+      // rows: the gradient kernel takes them from its A fragments for free)
       vacc dy2[NJ];
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
@@ -504,28 +507,22 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
         const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
-        vacc t3, t2;
+        vacc t3;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const real hv = dy2[J][i];
           t3[i] = dv * hv;
-          const real dy = dv * w3v[i] * wact_d<real, ACT>(hv);
-          dy2[J][i] = dy;
-          t2[i] = dy;
+          dy2[J][i] = dv * w3v[i] * wact_d<real, ACT>(hv);
         }
         *reinterpret_cast<v4*>(pd + 16 * J) = dy2[J];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          t3[i] = row16_sum(t3[i]);
-          t2[i] = row16_sum(t2[i]);
-        }
+        for (int i = 0; i < 4; ++i) t3[i] = row16_sum(t3[i]);
         if (m == 0) {
-          real* q2 = my_acc + H + 16 * J + 4 * g;
-          real* q3 = my_acc + 2 * H + 16 * J + 4 * g;
+          real* q3 = my_acc + 16 * J + 4 * g;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (ACC_ATOMIC) { unsafeAtomicAdd(q2 + i, t2[i]); unsafeAtomicAdd(q3 + i, t3[i]); }
-            else { q2[i] += t2[i]; q3[i] += t3[i]; }
+            if (ACC_ATOMIC) unsafeAtomicAdd(q3 + i, t3[i]);
+            else q3[i] += t3[i];
           }
         }
         wfence();
@@ -551,21 +548,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
-          vacc t1;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[jj][i] *= wact_d<real, ACT>(hb[jj][i]);
-            t1[i] = row16_sum(acc[jj][i]);
-          }
+          for (int i = 0; i < 4; ++i) acc[jj][i] *= wact_d<real, ACT>(hb[jj][i]);
           *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
-          if (m == 0) {
-            real* q1 = my_acc + 16 * J + 4 * g;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (ACC_ATOMIC) unsafeAtomicAdd(q1 + i, t1[i]);
-              else q1[i] += t1[i];
-            }
-          }
         }
         __syncthreads();
       }
@@ -578,7 +563,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #endif
 
   if (BWD) {
-    // ---- slab: b1, b2, w3 (unit order), b3, loss
+    // ---- slab: w3 (unit order), b3, loss
     loss_sum = wave_sum(loss_sum);
     gb3 = wave_sum(gb3);
     if (lane == 0) { sred[wave] = gb3; sred[C::WAVES + wave] = loss_sum; }
@@ -587,13 +572,11 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     real* ob1 = out + (int64_t)H * din;
     real* ob2 = ob1 + H + (int64_t)H * H;
     real* ow3 = ob2 + H;
-    for (int e = tid; e < 3 * H; e += NT) {
-      const int which = e / H, p = e - which * H;
+    for (int p = tid; p < H; p += NT) {
       real s = 0;
 #pragma unroll
-      for (int w = 0; w < C::NACC; ++w) s += gacc[w * 3 * H + e];
-      const int u = unit_of_pos<real>(p);
-      (which == 0 ? ob1 : (which == 1 ? ob2 : ow3))[u] = s;
+      for (int w = 0; w < C::NACC; ++w) s += gacc[w * H + p];
+      ow3[unit_of_pos<real>(p)] = s;
     }
     if (tid == 0) {
       real s3 = 0, sl = 0;
@@ -661,6 +644,9 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
     for (int xt = 0; xt < NXT; ++xt) acc1[at][xt] = (vacc){0, 0, 0, 0};
   }
 
+  real sb2[NAT], sb1[NAT];
+#pragma unroll
+  for (int at = 0; at < NAT; ++at) { sb2[at] = 0; sb1[at] = 0; }
   v4 sa2[NVA], sa1[NVA], sb[NVB];
   real sx[NVX];
   auto fetch = [&](int64_t r0) {
@@ -751,6 +737,8 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       for (int at = 0; at < NAT; ++at) {
         a2[at] = A2[row * LD::PA + wave * G::UW + 16 * at + m];
         a1[at] = A1[row * LD::PA + wave * G::UW + 16 * at + m];
+        sb2[at] += a2[at];                                    // db2, db1: column sums
+        sb1[at] += a1[at];
       }
 #pragma unroll
       for (int bt = 0; bt < NJ; ++bt) {
@@ -770,10 +758,25 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
     cur ^= 1;
   }
 
-  // ---- slab sections W1 and W2 (unit order) of this workgroup's units
+  // ---- slab sections W1, b1, W2, b2 (unit order) of this workgroup's units
   real* out = a.partials + (int64_t)blockIdx.x * (a.P + 2);
   real* oW1 = out;
-  real* oW2 = out + (int64_t)H * din + H;
+  real* ob1 = out + (int64_t)H * din;
+  real* oW2 = ob1 + H;
+  real* ob2 = oW2 + (int64_t)H * H;
+#pragma unroll
+  for (int at = 0; at < NAT; ++at) {
+    real v2 = sb2[at], v1 = sb1[at];                          // rows 4 ks + g: sum over g
+    v2 += __shfl_xor(v2, 16, 64);
+    v2 += __shfl_xor(v2, 32, 64);
+    v1 += __shfl_xor(v1, 16, 64);
+    v1 += __shfl_xor(v1, 32, 64);
+    if (g == 0) {
+      const int u = unit_of_pos<real>(ubase + wave * G::UW + 16 * at + m);
+      ob2[u] = v2;
+      ob1[u] = v1;
+    }
+  }
 #pragma unroll
   for (int at = 0; at < NAT; ++at)
 #pragma unroll
