@@ -66,7 +66,7 @@ def run():
             e.record(); torch.cuda.synchronize()
             res.append(s.elapsed_time(e) / 5)
         print(f"{name:10s} fwd+bwd {res[0]:.3f} ms   fwd {res[1]:.3f} ms", flush=True)
-        if name == "stamp":
+        if name.startswith("stamp"):
             go(True); torch.cuda.synchronize()
             st = partials[0, :14].cpu().tolist()
             names = ["forward", "P1a bar+loss+dY2", "barrier P1b", "P2 writes+bar", "B2 loop", "epilogue", "barrier P3", "P4 writes+bar", "-", "loop top",
