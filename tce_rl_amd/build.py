@@ -37,6 +37,9 @@ def build_library(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
                if f.endswith(".h")]
+    api = os.path.join(os.path.dirname(PKG), "include", "tce_hip.h")
+    if os.path.exists(api):                 # objective.hip checks itself against it
+        headers.append(api)
     jobs = []
     for src in _sources():
         s = os.path.join(CSRC, src)
