@@ -124,7 +124,7 @@ def hbm_entry(name, alg, us, us_cold=None, note=None, traffic=None):
     return d
 
 
-def roofline(agent, critic_ms_in_step):
+def roofline(agent, critic_ms_in_step, with_f16=False):
     """Rooflines measured live with HIP events on the launch stream.
 
     dominant kernel = mlp_critic_bwd_kernel (+ mlp_finish_kernel: the 50 critic
@@ -149,8 +149,11 @@ def roofline(agent, critic_ms_in_step):
     saved = [p.grad for p in net.parameters()]
     run = critic_ops.EpochRunner(net)
     us_c = kernel_time_us(lambda: run.epoch(xs, rets, rets, 0.0), launches=5)
-    run16 = critic_ops.EpochRunner(net, arith="f16x2")
-    us_c16 = kernel_time_us(lambda: run16.epoch(xs, rets, rets, 0.0), launches=5)
+    us_c16 = None
+    if with_f16:
+        run16 = critic_ops.EpochRunner(net, arith="f16x2")
+        us_c16 = kernel_time_us(lambda: run16.epoch(xs, rets, rets, 0.0),
+                                launches=5)
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
@@ -171,7 +174,7 @@ def roofline(agent, critic_ms_in_step):
               "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel"),
               "algorithmic_flops": flops,
               "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
-    critic16 = {
+    critic16 = None if us_c16 is None else {
         "kernel": "mlp_critic_bwd16_kernel<relu,2> (+ mlp_finish_kernel)",
         "bound": "mfma", "achieved": round(flops / us_c16 / 1e6, 2),
         "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -184,7 +187,7 @@ def roofline(agent, critic_ms_in_step):
         "dtype": "f16x2 split operands, fp32 accumulate "
                  "(v_mfma_f32_16x16x32_f16; 3 MFMAs per product)"}
     del full, xs
-    extra = {"critic_split_f16": critic16}
+    extra = {} if critic16 is None else {"critic_split_f16": critic16}
 
     def gae_case(n):
         r = torch.randn(n, T, device="cuda", generator=g)
@@ -345,8 +348,8 @@ def self_launch(args):
            "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
-    if args.no_split_f16:
-        cmd.append("--no-split-f16")
+    if args.with_split_f16:
+        cmd.append("--with-split-f16")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -371,8 +374,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-split-f16", action="store_true",
+                    help="add a second timed region with the agent option "
+                         "critic_arith=f16x2 (split-f16 critic kernel: an "
+                         "option, not the reported value)")
     ap.add_argument("--no-split-f16", action="store_true",
-                    help="skip the second timed region (critic_arith=f16x2)")
+                    help="accepted for older command lines (the default now)")
     args = ap.parse_args()
     # N > 1 without a launcher: become the launcher BEFORE any GPU call
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -457,7 +464,7 @@ def main():
     # split-f16 kernel (agent option critic_arith="f16x2"), reported beside
     # the fp32 figure as "split_f16_critic"
     fast = None
-    if not args.no_split_f16:
+    if args.with_split_f16:
         agent.critic_arith = "f16x2"
         agent._critic_split = 0
         for _ in range(args.warmup):
@@ -477,7 +484,8 @@ def main():
         env_steps = world * NUM_ENV * T * args.steps
         print("[bench] timed region: %.3f s" % elapsed, file=sys.stderr,
               flush=True)
-        roof, extra = roofline(agent, crit_time / args.steps * 1e3)
+        roof, extra = roofline(agent, crit_time / args.steps * 1e3,
+                               args.with_split_f16)
         print("[bench] roofline done", file=sys.stderr, flush=True)
         out = {
             "metric": "env-steps/sec (TCE rollout + update, Metaworld-reach-"

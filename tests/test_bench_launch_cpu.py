@@ -31,7 +31,7 @@ def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
         return types.SimpleNamespace(returncode=0, stdout=out.encode())
     monkeypatch.setattr(subprocess, "run", fake_run)
     args = types.SimpleNamespace(gpus=4, steps=3, warmup=1,
-                                 no_cpu_baseline=True, no_split_f16=False)
+                                 no_cpu_baseline=True, with_split_f16=False)
     assert bench.self_launch(args) == 0
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
@@ -53,7 +53,7 @@ def test_self_launch_reports_a_failed_child(monkeypatch):
     monkeypatch.setattr(subprocess, "run", lambda *a, **k:
                         types.SimpleNamespace(returncode=3, stdout=b""))
     args = types.SimpleNamespace(gpus=2, steps=1, warmup=0,
-                                 no_cpu_baseline=False, no_split_f16=True)
+                                 no_cpu_baseline=False, with_split_f16=True)
     assert bench.self_launch(args) == 3
 
 
