@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <unordered_map>
 
 #define TCE_WAVE 64
 
@@ -24,6 +25,19 @@ extern "C" void tce_set_error(const char* msg);
       return 2;                                                         \
     }                                                                   \
   } while (0)
+
+// Raise a kernel's dynamic-LDS limit (needed above 48 KiB) ONCE per kernel and
+// size, not on every launch: the attribute call is a runtime round trip on the
+// launch path.
+inline void tce_lds_limit(const void* kern, size_t bytes) {
+  static std::unordered_map<const void*, size_t> have;
+  if (bytes <= 48 * 1024) return;
+  size_t& h = have[kern];
+  if (bytes > h) {
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    h = bytes;
+  }
+}
 
 template <typename T> __host__ __device__ inline T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __host__ __device__ inline T tmax(T a, T b) { return a > b ? a : b; }

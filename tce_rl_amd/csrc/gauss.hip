@@ -558,8 +558,7 @@ __global__ __launch_bounds__(SM_BT) void kl_cov_proj_bwd_kernel(
 template <typename F>
 int set_lds(F kern, size_t lds) {
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    tce_lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds));
   return 0;
 }
 

@@ -589,18 +589,15 @@ void mlp_launch(const MlpArgs& a, int grid, hipStream_t st) {
   constexpr size_t lds = mlp_lds_bytes<KPGE>();
   static_assert(lds <= 160 * 1024, "LDS budget");
   if (BWD && a.gh != nullptr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, true>), (size_t)(lds));
     hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE, true>), dim3(grid), dim3(2 * MLP_BT), lds,
                        st, a);
   } else if (BWD) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_bwd_kernel<ACT, KPGE, false>), (size_t)(lds));
     hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE, false>), dim3(grid), dim3(2 * MLP_BT), lds,
                        st, a);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>), (size_t)(lds));
     hipLaunchKernelGGL((mlp_critic_fwd_kernel<ACT, KPGE>), dim3(grid), dim3(MLP_BT), lds, st, a);
   }
 }

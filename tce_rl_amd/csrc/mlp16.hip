@@ -683,13 +683,11 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd16_kernel(Mlp16Ar
 template <int ACT>
 void launch16(const Mlp16Args& aa, int grid, hipStream_t st) {
   if (aa.a.din <= 32) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd16_kernel<ACT, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_bwd16_kernel<ACT, 1>), (size_t)(LDS16_BYTES));
     hipLaunchKernelGGL((mlp_critic_bwd16_kernel<ACT, 1>), dim3(grid), dim3(2 * MLP_BT), LDS16_BYTES,
                        st, aa);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_critic_bwd16_kernel<ACT, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_bwd16_kernel<ACT, 2>), (size_t)(LDS16_BYTES));
     hipLaunchKernelGGL((mlp_critic_bwd16_kernel<ACT, 2>), dim3(grid), dim3(2 * MLP_BT), LDS16_BYTES,
                        st, aa);
   }

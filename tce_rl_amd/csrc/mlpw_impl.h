@@ -891,12 +891,9 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
   if (bwd) {
     static bool set = false;
     if (!set) {
-      (void)hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, true>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      tce_lds_limit(reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, true>), (size_t)(lds));
       const int glds0 = (int)GradLds<real, H, KPG>::bytes();
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlpw_grad_kernel<real, H, KPG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, glds0);
+      tce_lds_limit(reinterpret_cast<const void*>(&mlpw_grad_kernel<real, H, KPG>), (size_t)(glds0));
       set = true;
     }
     hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, true>), dim3(grid), dim3(C::NT), lds,
@@ -913,9 +910,7 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
   } else {
     static bool set = false;
     if (!set) {
-      (void)hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, false>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      tce_lds_limit(reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, false>), (size_t)(lds));
       set = true;
     }
     hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, false>), dim3(grid), dim3(C::NT), lds,

@@ -232,16 +232,14 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
   const int nblk = (int)ceil_div(N, KE_EPB);
   const size_t lds_e = (size_t)2 * K * sm_pitch(K) * sizeof(real);
   if (lds_e > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_env_kernel<real>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e);
+    tce_lds_limit(reinterpret_cast<const void*>(kl_shared_env_kernel<real>), (size_t)(lds_e));
   hipLaunchKernelGGL(kl_shared_env_kernel<real>, dim3(nblk), dim3(KE_BT), lds_e, st, mn, mo, mp,
                      Lo, Lp, N, K, coeff / (real)N, gmean, ws);
   TCE_LAUNCH_CHECK();
   const int par = (size_t)6 * K * sm_pitch(K) * sizeof(double) <= 150 * 1024;   // K <= 55
   const size_t lds_m = (size_t)(par ? 6 : 4) * K * sm_pitch(K) * sizeof(double);
   if (lds_m > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_shared_mat_kernel<real>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    tce_lds_limit(reinterpret_cast<const void*>(kl_shared_mat_kernel<real>), (size_t)(lds_m));
   hipLaunchKernelGGL(kl_shared_mat_kernel<real>, dim3(1), dim3(SM_BT), lds_m, st, Ln, Lo, Lp, N,
                      K, coeff, include_cov, ws, nblk, out, gL, par);
   TCE_LAUNCH_CHECK();

@@ -665,8 +665,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: fast path LDS");
     if (bwd) {
       if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, true>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f, EB);
@@ -682,8 +681,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
                          (int64_t)P, (const int*)nullptr, flag);
     } else {
       if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_env_kernel<real, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, false>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f, EB);
@@ -700,8 +698,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: problem too large for LDS");
   auto kern = bwd ? pair_logprob_kernel<real, true> : pair_logprob_kernel<real, false>;
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    tce_lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds));
   TCE_CHECK_ARG(N < (1ll << 31), "pair_logprob: too many envs");
   // with the fast path launched, gL of the general kernel is per env: the fast
   // path writes the already-reduced [K,K] gradient into gL_shared instead
