@@ -131,6 +131,7 @@ class SyntheticTCEEnv:
                  "step_rewards": out["rewards"],
                  "step_terminations": term, "step_truncations": trunc,
                  "segment_length": torch.full((N,), T, device=self.device),
+                 "num_steps_host": N * T,
                  "success": out["metrics"][:, 0],
                  "final_distance": out["metrics"][:, 1],
                  "obs_moment_partials": out["partials"]}
@@ -171,6 +172,7 @@ class SyntheticBBEnv(SyntheticTCEEnv):
                               self.dt, KP, KD, want_states=False)
         infos = {"trajectory_length":
                  torch.full((N,), self.num_times, device=self.device),
+                 "num_steps_host": N * self.num_times,
                  "success": out["metrics"][:, 0],
                  "final_distance": out["metrics"][:, 1]}
         episode_reward = out["rewards"].sum(-1)

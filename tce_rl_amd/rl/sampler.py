@@ -190,7 +190,10 @@ class BlackBoxSampler(AbstractSampler):
             state, reward, done, info = envs.step(action)
             out["segment_reward"].append(reward.to(self.dtype))
             out["segment_done"].append(done)
-            num_steps += info["trajectory_length"].sum()
+            # (extension: an env that knows its step count on the host says so,
+            # and the rollout ends without a device -> host read)
+            num_steps += info.get("num_steps_host",
+                                  None) or info["trajectory_length"].sum()
             for m in metrics:
                 metrics[m].append(info[m].to(self.dtype))
         res = {}
@@ -334,7 +337,8 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
             out["segment_init_vel"].append(init_vel)
             out["segment_params_mean"].append(mean)
             out["segment_params_L"].append(L)
-            num_steps = num_steps + infos["segment_length"].sum()
+            num_steps = num_steps + (infos.get("num_steps_host", None) or
+                                     infos["segment_length"].sum())
             for m in metrics:
                 metrics[m].append(infos[m].to(self.dtype))
             init_state = next_state
