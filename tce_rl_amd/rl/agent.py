@@ -153,18 +153,22 @@ class AbstractAgent(ABC):
         norms = opt.dev_state[1:3].clone()      # the state is reused next step
         return norms[0], norms[1]
 
-    def _capture(self, fn):
+    def _capture(self, fn, pool_key=None):
         """Record fn() (kernel launches only, fixed buffers) into a HIP graph
         on a side stream, without the device-wide synchronisation of
-        torch.cuda.graph() -- the critic epochs keep running meanwhile."""
+        torch.cuda.graph() -- the critic epochs keep running meanwhile.
+        pool_key: graphs that are replayed CONCURRENTLY (the black-box agent's
+        critic and policy epochs) must not share a memory pool."""
         if getattr(self, "_graph_stream", None) is None:
             self._graph_stream = torch.cuda.Stream(device=self.device)
-            self._graph_pool = torch.cuda.graph_pool_handle()
+            self._graph_pools = {}
+        if pool_key not in self._graph_pools:
+            self._graph_pools[pool_key] = torch.cuda.graph_pool_handle()
         graph = torch.cuda.CUDAGraph()
         cur = torch.cuda.current_stream()
         self._graph_stream.wait_stream(cur)
         with torch.cuda.stream(self._graph_stream):
-            graph.capture_begin(pool=self._graph_pool)
+            graph.capture_begin(pool=self._graph_pools[pool_key])
             try:
                 fn()
             finally:
@@ -177,11 +181,19 @@ class AbstractAgent(ABC):
         epoch runs eagerly, the second is recorded into a HIP graph and replayed
         -- the ~100 launches of an epoch leave the host."""
         if graph and E > 2 and not self.dist.active:
-            epoch()
-            g = self._capture(epoch)
-            for _ in range(E - 1):
+            # the very first update runs one epoch eagerly (lazy initialisation
+            # of the GEMM library must not happen under capture); afterwards
+            # all E epochs are replays -- an eager epoch costs 1.5 - 4 ms of
+            # host time and these updates are host-bound
+            n = E
+            if not getattr(opt, "_tce_graph_warm", False):
+                epoch()
+                opt._tce_graph_warm = True
+                n = E - 1
+            g = self._capture(epoch, pool_key=id(opt))
+            for _ in range(n):
                 g.replay()
-            opt.host_step += E - 2                # the capture counted one
+            opt.host_step += n - 1                # the capture counted one
             self._last_graphs = getattr(self, "_last_graphs", [])[-3:] + [g]
         else:
             for _ in range(E):
@@ -815,6 +827,39 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.sampler.load_rms(log_dir, epoch)
 
 
+class _EpochGraph:
+    """The E epochs of one update of the black-box agent as ONE HIP graph that
+    is kept across iterations: the update's inputs live in static buffers that
+    every iteration overwrites, the per-epoch record and its row counter are
+    static too.  Recording the epoch anew in every iteration (and destroying
+    the previous graph) cost 10 - 15 ms of host time per step -- these updates
+    are host-bound."""
+
+    def __init__(self, sig, inputs, rec_cols, E, dtype, device):
+        self.sig, self.graph, self.static, self.last = sig, None, {}, {}
+        for k, v in inputs.items():
+            base = getattr(v, "_tce_base", None)
+            if base is not None:                  # one factor shared by all envs
+                buf = torch.empty_like(base)
+                self.static[k] = (ops.expand_shared(buf, v.shape[0]), buf)
+            else:
+                buf = torch.empty_like(v, memory_format=torch.contiguous_format)
+                self.static[k] = (buf, buf)
+        self.rec = torch.zeros(E, rec_cols, dtype=dtype, device=device)
+        self.idx = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def bind(self, inputs):
+        """Copy this iteration's inputs into the static buffers."""
+        out = {}
+        for k, v in inputs.items():
+            view, buf = self.static[k]
+            base = getattr(v, "_tce_base", None)
+            buf.copy_(base if base is not None else v)
+            out[k] = view
+        self.idx.zero_()
+        return out
+
+
 class BlackBoxAgent(TemporalCorrelatedAgent):
     """black_box_agent.py: episode-level advantage R - V(s0), critic regresses
     the episode return, param-space log-prob; otherwise the same update."""
@@ -824,6 +869,51 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # the epochs of both updates are ~100 launch-bound kernels each and
         # nothing else runs beside them: replay them from HIP graphs
         self.graph_epochs = kwargs.get("graph_epochs", True)
+        # ... and keep the graphs across iterations (inputs in static buffers)
+        self.cache_epoch_graphs = kwargs.get("cache_epoch_graphs", True)
+        self._epoch_graphs = {}
+
+    def _epoch_graph(self, kind, E, opt, inputs, rec_cols):
+        """-> (_EpochGraph or None, inputs to use).  None: the update records
+        its epochs anew (or launches them eagerly) as before.  A graph is kept
+        while nothing the recording baked in changes: shapes, learning rate,
+        and -- a projection with an entropy schedule computes its bound from
+        the iteration number on the host -- only without such a schedule."""
+        if not (self.graph_epochs and self.cache_epoch_graphs and E > 2 and
+                self.num_minibatchs == 1 and not self.dist.active and
+                self.projection.entropy_schedule_type in (None, False)):
+            return None, inputs
+        g = opt.param_groups[0]
+        sig = (E, g["lr"], g.get("weight_decay", 0.0), self.clip_grad_norm,
+               self.clip_critic, self.entropy_penalty_coef, self.set_variance,
+               tuple((k, tuple(v.shape), v.dtype,
+                      getattr(v, "_tce_base", None) is not None)
+                     for k, v in inputs.items()))
+        eg = self._epoch_graphs.get(kind)
+        if eg is None or eg.sig != sig:
+            eg = _EpochGraph(sig, inputs, rec_cols, E, self.dtype, self.device)
+            self._epoch_graphs[kind] = eg
+        return eg, eg.bind(inputs)
+
+    def load_agent(self, log_dir, epoch):
+        super().load_agent(log_dir, epoch)
+        self._epoch_graphs = {}         # recorded against the old state
+
+    def _run_epoch_graph(self, eg, epoch, E, opt):
+        """Replay (or, the first time, record) the kept graph E times."""
+        if eg.graph is None:
+            n = E
+            if not getattr(opt, "_tce_graph_warm", False):
+                epoch()                           # see _run_epochs
+                opt._tce_graph_warm = True
+                n = E - 1
+            eg.graph = self._capture(epoch, pool_key=id(opt))
+            opt.host_step -= 1                    # the recording counted one
+        else:
+            n = E
+        for _ in range(n):
+            eg.graph.replay()
+        opt.host_step += n
 
     def step(self):
         self.num_iterations += 1
@@ -837,8 +927,23 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             {k: v for k, v in dataset.items()
              if k not in ("segment_params_L", "segment_state")}, "exploration")
         util.run_time_test(lock=True, key="update")
-        critic_loss_dict = self.update_critic(dataset)
-        policy_loss_dict = self.update_policy(dataset)
+        if self.overlap_updates and self.graph_epochs and \
+                self.num_minibatchs == 1 and not self.dist.active:
+            # the two updates are independent chains of ~100 small launches per
+            # epoch, replayed from HIP graphs: side by side on two streams
+            main = torch.cuda.current_stream()
+            if getattr(self, "_bb_stream", None) is None:
+                self._bb_stream = torch.cuda.Stream(device=self.device)
+            side = self._bb_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                finish_critic = self.update_critic(dataset, defer=True)
+            policy_loss_dict = self.update_policy(dataset)
+            main.wait_stream(side)
+            critic_loss_dict = finish_critic()
+        else:
+            critic_loss_dict = self.update_critic(dataset)
+            policy_loss_dict = self.update_policy(dataset)
         update_time = util.run_time_test(lock=False, key="update")
         result = {**dataset_stats, **critic_loss_dict, **policy_loss_dict,
                   "sampling_time": sampling_time, "update_time": update_time,
@@ -865,15 +970,26 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         dataset["segment_advantage"] = adv
         return dataset
 
-    def update_critic(self, dataset):
+    def update_critic(self, dataset, defer=False):
         states = dataset["segment_state"]
         old_values, returns = dataset["segment_value"], \
             dataset["segment_reward"]
         E = self.epochs_critic
+        stats = lambda host: {
+            **util.generate_stats(host[0], "critic_loss"),
+            **util.generate_stats(host[1], "critic_grad_norm"),
+            **util.generate_stats(host[2], "clipped_critic_grad_norm")}
         if self.num_minibatchs == 1:
+            eg, st = self._epoch_graph(
+                "critic", E, self.critic_optimizer,
+                dict(states=states, returns=returns, old_values=old_values), 3)
+            states, returns, old_values = st["states"], st["returns"], \
+                st["old_values"]
             # per-epoch record {loss, |g|, |g| clipped}, written on the device
-            rec = torch.zeros(E, 3, dtype=self.dtype, device=self.device)
-            idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+            rec = eg.rec if eg else torch.zeros(E, 3, dtype=self.dtype,
+                                                device=self.device)
+            idx = eg.idx if eg else torch.zeros(1, dtype=torch.int64,
+                                                device=self.device)
 
             def epoch():
                 loss = self.value_loss(
@@ -888,8 +1004,13 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                     [loss.detach(), g, gc])[None])
                 idx.add_(1)
 
-            self._run_epochs(epoch, E, self.critic_optimizer,
-                             self.graph_epochs)
+            if eg:
+                self._run_epoch_graph(eg, epoch, E, self.critic_optimizer)
+            else:
+                self._run_epochs(epoch, E, self.critic_optimizer,
+                                 self.graph_epochs)
+            if defer:             # the host read waits for the caller's join
+                return lambda: stats(rec.cpu().numpy().T)
             host = rec.cpu().numpy().T
         else:
             losses, norms, norms_c = [], [], []
@@ -909,9 +1030,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                     norms_c.append(gc)
             host = torch.stack([torch.stack(losses), torch.stack(norms),
                                 torch.stack(norms_c)]).cpu().numpy()
-        return {**util.generate_stats(host[0], "critic_loss"),
-                **util.generate_stats(host[1], "critic_grad_norm"),
-                **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+        return (lambda: stats(host)) if defer else stats(host)
 
     def update_policy(self, dataset):
         states = dataset["segment_state"]
@@ -924,9 +1043,18 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             ent0 = self.policy.entropy([mean_old, L_old]).mean()
             self.projection.initial_entropy = self.dist.mean_scalar(ent0)
         E = self.epochs_policy
-        rec = torch.zeros(E, 7, dtype=self.dtype, device=self.device)
-        idx = torch.zeros(1, dtype=torch.int64, device=self.device)
-        last = {}
+        eg, st = self._epoch_graph(
+            "policy", E, self.policy_optimizer,
+            dict(states=states, actions=actions, log_probs_old=log_probs_old,
+                 mean_old=mean_old, L_old=L_old, seg_adv=seg_adv), 7)
+        states, actions, log_probs_old = st["states"], st["actions"], \
+            st["log_probs_old"]
+        mean_old, L_old, seg_adv = st["mean_old"], st["L_old"], st["seg_adv"]
+        rec = eg.rec if eg else torch.zeros(E, 7, dtype=self.dtype,
+                                            device=self.device)
+        idx = eg.idx if eg else torch.zeros(1, dtype=torch.int64,
+                                            device=self.device)
+        last = eg.last if eg else {}
 
         def epoch():
             mean_new, L_new = self.policy.policy(states)
@@ -957,7 +1085,11 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             last["t"] = (mean_new.detach(), ops.detach_L(L_new),
                          proj_mean.detach(), ops.detach_L(proj_L))
 
-        self._run_epochs(epoch, E, self.policy_optimizer, self.graph_epochs)
+        if eg:
+            self._run_epoch_graph(eg, epoch, E, self.policy_optimizer)
+        else:
+            self._run_epochs(epoch, E, self.policy_optimizer,
+                             self.graph_epochs)
         host = rec.cpu().numpy()                          # ONE copy
         for name, bad in zip(("surrogate_loss", "entropy_loss",
                               "trust_region_loss"),

@@ -369,6 +369,36 @@ def test_bbrl_graph_epochs_equal_eager_epochs():
         assert abs(ra[k] - rb[k]) <= 1e-6 * abs(rb[k]) + 1e-8, k
 
 
+def test_bbrl_kept_graphs_equal_fresh_graphs_over_iterations():
+    """The black-box agent keeps the HIP graphs of its two updates across
+    iterations (inputs copied into static buffers, the two graphs replayed on
+    two streams).  Three iterations -- new rollouts, so new inputs -- end with
+    the parameters of an agent that records its epochs anew every time, and of
+    one that launches them eagerly one update after the other."""
+    out = []
+    for kw in (dict(), dict(cache_epoch_graphs=False),
+               dict(graph_epochs=False, overlap_updates=False)):
+        torch.manual_seed(0)
+        agent, _ = build_bbrl(96, 6)
+        for k, v in kw.items():
+            setattr(agent, k, v)
+        agent.evaluation_interval = 0
+        torch.manual_seed(1)
+        for _ in range(3):
+            res = agent.step()
+        out.append((res, [p.detach().clone() for p in
+                          agent.policy.parameters + agent.critic.parameters],
+                    agent.policy_optimizer.host_step,
+                    float(agent.policy_optimizer.dev_state[0])))
+    assert agent.num_global_steps == out[0][0]["num_global_steps"]
+    for res, params, host_step, dev_step in out:
+        assert host_step == dev_step == 18          # 3 iterations x 6 epochs
+        for a, b in zip(params, out[2][1]):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+        for k in ("critic_loss_mean", "surrogate_loss_mean", "entropy_mean"):
+            assert abs(res[k] - out[2][0][k]) <= 1e-6 * abs(out[2][0][k]) + 1e-8
+
+
 def test_bbrl_step_matches_cpu_oracle():
     """One BlackBoxAgent.step() (a16) against the CPU oracle step on the same
     weights, env state and parameter noise."""
