@@ -281,7 +281,7 @@ inline real* obj_proj_L(real* ws, int64_t N, int K, int P) {
   return ws + 3 * obj_up4(N * K) + 2 * obj_up4(N * P);
 }
 
-// a[i] += b[i] for two pairs of arrays in one launch; c[i,i] -= s / d[i,i] first
+// a[i] += b[i] for two pairs of arrays in one launch
 template <typename real>
 __global__ __launch_bounds__(256) void obj_add2_kernel(real* __restrict__ a1,
                                                        const real* __restrict__ b1, int64_t n1,
