@@ -431,6 +431,27 @@ int tce_policy_objective_end_f32(float* grad_L, float* ws, int64_t N, int K, int
 int tce_policy_objective_end_f64(double* grad_L, double* ws, int64_t N, int K, int P,
                                  void* stream);
 
+/* The same for the black-box agent (mprl/rl/agent/black_box_agent.py:283-357):
+ * the log-prob is BlackBoxPolicy.log_prob of the sampled parameter vectors
+ * `actions` [N,K] under the projected Gaussian (tce_vec_env mode 2) instead of
+ * the pair-wise trajectory log-prob; logp_old / adv [N].  proj_mean_out [N,K] /
+ * proj_L_out [K,K] (nullable) receive the projected distribution.  ws: scratch
+ * of tce_bb_policy_objective_ws_len(N, K) elements. */
+int64_t tce_bb_policy_objective_ws_len(int64_t N, int K);
+int tce_bb_policy_objective_f32(
+    const float* mean_new, const float* L_new, const float* mean_old, const float* L_old,
+    const float* actions, const float* logp_old, const float* adv, float eps_mean,
+    double eps_cov, const float* beta, int entropy_eq, double* proj_ctx, float tr_coeff,
+    int tr_include_cov, float ent_coef, double* sur_ws, double* kl_ws, float* ws,
+    float* grad_mean, float* grad_L, float* sur2, float* out16, float* proj_mean_out,
+    float* proj_L_out, int64_t N, int K, void* stream);
+int tce_bb_policy_objective_f64(
+    const double* mean_new, const double* L_new, const double* mean_old, const double* L_old,
+    const double* actions, const double* logp_old, const double* adv, double eps_mean,
+    double eps_cov, const double* beta, int entropy_eq, double* proj_ctx, double tr_coeff,
+    int tr_include_cov, double ent_coef, double* sur_ws, double* kl_ws, double* ws,
+    double* grad_mean, double* grad_L, double* sur2, double* out16, double* proj_mean_out,
+    double* proj_L_out, int64_t N, int K, void* stream);
 /* Gradient of a final Linear layer y = h W^T + b (the mean net's output layer,
  * mprl/util/util_nn.py:225-246 under autograd) from grad_out = dL/dy [N,K] and
  * hidden = h [N,H]: grad_W [K,H] = grad_out^T h, grad_b [K] = sum_n grad_out.

@@ -331,6 +331,14 @@ template <> struct ObjApi<double> {
     }                                                          \
   } while (0)
 
+#define OBJ_HIP_ALWAYS(call)                                   \
+  do {                                                         \
+    if ((call) != hipSuccess) {                                \
+      tce_set_error("policy_objective: runtime call");         \
+      return 1;                                                \
+    }                                                          \
+  } while (0)
+
 template <typename real>
 int policy_objective(const real* mean_new, const real* L_new, const real* mean_old,
                      const real* L_old, const real* traj, const real* logp_old,
@@ -426,6 +434,89 @@ int policy_objective_end(real* grad_L, real* ws, int64_t N, int K, int P, hipStr
   hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st,
                      grad_L, gL_p, n2, grad_L, gL_p, (int64_t)0);
   TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// The same objective for the black-box agent (black_box_agent.py:283-357): the
+// log-prob is the one of the sampled parameter vectors under the projected
+// Gaussian (tce_vec_env mode 2) instead of the pair-wise trajectory log-prob.
+// ---------------------------------------------------------------------------
+template <typename real> struct ObjSum;
+template <> struct ObjSum<float> { static constexpr auto sum_dim0 = tce_sum_dim0_f32; };
+template <> struct ObjSum<double> { static constexpr auto sum_dim0 = tce_sum_dim0_f64; };
+
+inline int64_t bb_obj_ws_len(int64_t N, int K) {
+  const int64_t KK = (int64_t)K * K;
+  return 3 * obj_up4(N * K) + 2 * obj_up4(N) + 3 * obj_up4(KK) + N * KK +
+         tce_sum_dim0_slices(N, KK) * KK;
+}
+
+template <typename real>
+int bb_policy_objective(const real* mean_new, const real* L_new, const real* mean_old,
+                        const real* L_old, const real* actions, const real* logp_old,
+                        const real* adv, real eps_mean, double eps_cov, const real* beta,
+                        int entropy_eq, double* proj_ctx, real tr_coeff, int tr_include_cov,
+                        real ent_coef, double* sur_ws, double* kl_ws, real* ws, real* grad_mean,
+                        real* grad_L, real* sur2, real* out16, real* proj_mean_out,
+                        real* proj_L_out, int64_t N, int K, hipStream_t st) {
+  typedef ObjApi<real> A;
+  TCE_CHECK_ARG(mean_new && L_new && mean_old && L_old && actions && logp_old && adv &&
+                    proj_ctx && sur_ws && kl_ws && ws && grad_mean && grad_L && sur2 && out16,
+                "bb_policy_objective: null buffer");
+  TCE_CHECK_ARG(N > 0 && K > 0 && K <= 64, "bb_policy_objective: bad sizes (K <= 64)");
+  const bool single = g_obj_streams < 2;
+  ObjSide* S = single ? nullptr : obj_side();
+  TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+  hipStream_t sd = single ? st : S->side;
+  const int64_t KK = (int64_t)K * K;
+  real* pm = ws;
+  real* g_pm = pm + obj_up4(N * K);
+  real* gm_p = g_pm + obj_up4(N * K);
+  real* logp = gm_p + obj_up4(N * K);
+  real* glp = logp + obj_up4(N);
+  real* pL = glp + obj_up4(N);
+  real* g_pL = pL + obj_up4(KK);
+  real* gL_p = g_pL + obj_up4(KK);
+  real* gL_env = gL_p + obj_up4(KK);              // [N,K,K] d logp / d L per env
+  real* sum_ws = gL_env + N * KK;
+  OBJ_HIP(hipEventRecord(S->ev[0], st));
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
+  OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
+  OBJ_HIP(hipEventRecord(S->ev[1], sd));
+  OBJ_TRY(A::vec_env(1, 0, mean_new, mean_old, L_old, 0, eps_mean, nullptr, pm, nullptr,
+                     nullptr, N, K, st));
+  OBJ_HIP(hipEventRecord(S->ev[2], st));
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
+  OBJ_TRY(kl_shared<real>(mean_new, mean_old, pm, L_new, L_old, pL, N, K, tr_coeff,
+                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd));
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
+  // log N(actions; pm, pL pL^T), surrogate, and back
+  OBJ_TRY(A::vec_env(2, 0, actions, pm, pL, 0, real(0), nullptr, logp, nullptr, nullptr, N, K,
+                     st));
+  OBJ_TRY(surrogate<real>(logp, logp_old, adv, N, sur2, glp, sur_ws, st));
+  OBJ_TRY(A::vec_env(2, 1, actions, pm, pL, 0, real(0), glp, nullptr, g_pm, gL_env, N, K, st));
+  OBJ_TRY(ObjSum<real>::sum_dim0(gL_env, g_pL, sum_ws, N, KK, st));
+  if (ent_coef != real(0)) {
+    hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
+                       ent_coef);
+    TCE_LAUNCH_CHECK();
+  }
+  OBJ_HIP(hipEventRecord(S->ev[3], st));
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[3], 0));
+  OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p, 1, K, sd));
+  OBJ_HIP(hipEventRecord(S->ev[4], sd));
+  OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
+                     nullptr, N, K, st));
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+  hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(N * K + KK, 256)), dim3(256),
+                     0, st, grad_mean, gm_p, N * (int64_t)K, grad_L, gL_p, KK);
+  TCE_LAUNCH_CHECK();
+  if (proj_mean_out)
+    OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_mean_out, pm, sizeof(real) * N * K,
+                                  hipMemcpyDeviceToDevice, st));
+  if (proj_L_out)
+    OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_L_out, pL, sizeof(real) * KK, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -591,6 +682,8 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
 
 int64_t tce_policy_objective_ws_len(int64_t N, int K, int P) { return obj_ws_len(N, K, P); }
 
+int64_t tce_bb_policy_objective_ws_len(int64_t N, int K) { return bb_obj_ws_len(N, K); }
+
 int tce_policy_objective_streams(int n) {
   g_obj_streams = n < 2 ? 1 : 2;
   return 0;
@@ -628,6 +721,22 @@ int tce_policy_objective_streams(int n) {
                                         entropy_eq, proj_ctx, L_new, ws, N, K, P,         \
                                         (hipStream_t)stream);                             \
   }
+#define DEFINE_BB_POLICY_OBJECTIVE(SFX, REAL)                                             \
+  int tce_bb_policy_objective_##SFX(                                                      \
+      const REAL* mean_new, const REAL* L_new, const REAL* mean_old, const REAL* L_old,   \
+      const REAL* actions, const REAL* logp_old, const REAL* adv, REAL eps_mean,          \
+      double eps_cov, const REAL* beta, int entropy_eq, double* proj_ctx, REAL tr_coeff,  \
+      int tr_include_cov, REAL ent_coef, double* sur_ws, double* kl_ws, REAL* ws,         \
+      REAL* grad_mean, REAL* grad_L, REAL* sur2, REAL* out16, REAL* proj_mean_out,        \
+      REAL* proj_L_out, int64_t N, int K, void* stream) {                                 \
+    return bb_policy_objective<REAL>(                                                     \
+        mean_new, L_new, mean_old, L_old, actions, logp_old, adv, eps_mean, eps_cov,      \
+        beta, entropy_eq, proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws,    \
+        ws, grad_mean, grad_L, sur2, out16, proj_mean_out, proj_L_out, N, K,              \
+        (hipStream_t)stream);                                                             \
+  }
+DEFINE_BB_POLICY_OBJECTIVE(f32, float)
+DEFINE_BB_POLICY_OBJECTIVE(f64, double)
 DEFINE_POLICY_OBJECTIVE(f32, float)
 DEFINE_POLICY_OBJECTIVE(f64, double)
 

@@ -871,6 +871,12 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         self.graph_epochs = kwargs.get("graph_epochs", True)
         # ... and keep the graphs across iterations (inputs in static buffers)
         self.cache_epoch_graphs = kwargs.get("cache_epoch_graphs", True)
+        # the objective as ONE autograd node (tce_bb_policy_objective_*) is
+        # an option here: with 32-wide nets and K = 20 the op-by-op graph is
+        # host-bound at 0.27 ms per epoch, the fused one device-bound at 0.45
+        # (its K x K kernels are single workgroups): 24 vs 27 ms per step
+        self.fused_policy_objective = kwargs.get("fused_policy_objective",
+                                                 False)
         self._epoch_graphs = {}
 
     def _epoch_graph(self, kind, E, opt, inputs, rec_cols):
@@ -1055,8 +1061,44 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         idx = eg.idx if eg else torch.zeros(1, dtype=torch.int64,
                                             device=self.device)
         last = eg.last if eg else {}
+        self._objective_streams()
+        fused_ctx = None
+        if self.fused_policy_objective and \
+                objective.bb_supported(self, L_old):
+            init = self.projection.initial_entropy
+            sched = self.projection.entropy_schedule_type
+            beta = None if sched in (None, False) else \
+                self.projection.entropy_schedule(
+                    init, self.projection.target_entropy,
+                    self.projection.temperature, self.num_iterations)
+            fused_ctx = last.get("ctx") if eg and eg.graph is not None else \
+                None
+            if fused_ctx is None:
+                fused_ctx = objective.BBContext(self, mean_old, L_old, actions,
+                                                log_probs_old, seg_adv, beta)
+                last["ctx"] = fused_ctx
+
+        def epoch_fused():
+            # projection -> log-prob -> surrogate -> entropy / trust region
+            # loss and their gradients as ONE autograd node (one C call)
+            mean_new, L_new = self.policy.policy(states)
+            policy_loss, rec17 = objective.policy_objective(mean_new, L_new,
+                                                            fused_ctx)
+            self.policy_optimizer.zero_grad(set_to_none=True)
+            policy_loss.backward()
+            g, gc = self._optimizer_step(self.policy_optimizer,
+                                         self.policy_net_params,
+                                         self.clip_grad_norm)
+            rec.index_copy_(0, idx, torch.cat(
+                [rec17[:5], torch.stack([g, gc]).to(rec17.dtype)])[None])
+            idx.add_(1)
+            last["t"] = (mean_new.detach(), ops.detach_L(L_new),
+                         fused_ctx.proj_mean,
+                         ops.expand_shared(fused_ctx.proj_L, states.shape[0]))
 
         def epoch():
+            if fused_ctx is not None:
+                return epoch_fused()
             mean_new, L_new = self.policy.policy(states)
             proj_mean, proj_L = self.projection(
                 self.policy, (mean_new, L_new), (mean_old, L_old),

@@ -69,6 +69,68 @@ class Context:
         self.ws = self.kl_ws = self.pl_work = self.ws_key = None
 
 
+def bb_supported(agent, L_old):
+    """The fused objective of the black-box agent: a shared (non-contextual)
+    covariance under the KL projection."""
+    pol, proj = agent.policy, agent.projection
+    return (not pol.contextual_std and type(proj) is KLProjectionLayer
+            and not proj.entropy_first and not proj.do_regression
+            and ops.split_L(L_old)[1] == 0)
+
+
+class BBContext:
+    """Per-update constants of the black-box agent's objective
+    (black_box_agent.py:283-357): old distribution, sampled parameter vectors,
+    their old log-probs and advantages.  The tensors are used as given (the
+    agent passes its static buffers when it keeps the epoch graph)."""
+    bb = True
+
+    def __init__(self, agent, mean_old, L_old, actions, lp_old, adv, beta):
+        c = lambda t: t if t.is_contiguous() else t.contiguous()
+        pol, proj = agent.policy, agent.projection
+        self.mean_old, self.actions = c(mean_old), c(actions)
+        self.L_old = c(ops.split_L(L_old)[0].detach())
+        self.lp_old, self.adv = c(lp_old), c(adv)
+        self.eps_mean, self.eps_cov = proj.mean_bound, proj.cov_bound
+        self.beta = None if beta is None else \
+            c(beta.detach().to(self.mean_old.dtype).reshape(1))
+        self.entropy_eq = int(bool(proj.entropy_eq))
+        self.tr_coeff = proj.trust_region_coeff
+        self.tr_include_cov = int(pol.contextual_std or not agent.set_variance)
+        self.ent_coef = float(agent.entropy_penalty_coef)
+        N, K = self.mean_old.shape
+        dev, dt, lib = self.mean_old.device, self.mean_old.dtype, _lib.load()
+        f64 = torch.float64
+        self.proj_ctx = torch.zeros(lib.tce_kl_cov_proj_ctx_len(K), dtype=f64,
+                                    device=dev)
+        self.sur_ws = torch.zeros(lib.tce_surrogate_ws_len(), dtype=f64,
+                                  device=dev)
+        self.kl_ws = torch.empty(lib.tce_kl_shared_ws_len(N), dtype=f64,
+                                 device=dev)
+        self.ws = torch.empty(lib.tce_bb_policy_objective_ws_len(N, K),
+                              dtype=dt, device=dev)
+        # the projected distribution of the latest evaluation
+        self.proj_mean = torch.empty(N, K, dtype=dt, device=dev)
+        self.proj_L = torch.empty(K, K, dtype=dt, device=dev)
+
+
+def evaluate_bb(mean_new, L_new, c):
+    """evaluate() for the black-box agent: ONE C call
+    (tce_bb_policy_objective_*)."""
+    N, K = mean_new.shape
+    dt, dev = mean_new.dtype, mean_new.device
+    new = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
+    g_mean, g_L, sur, out = new(N, K), new(K, K), new(2), new(16)
+    call("tce_bb_policy_objective_" + sfx(dt), ptr(mean_new), ptr(L_new),
+         ptr(c.mean_old), ptr(c.L_old), ptr(c.actions), ptr(c.lp_old),
+         ptr(c.adv), float(c.eps_mean), float(c.eps_cov), ptr(c.beta),
+         c.entropy_eq, ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov,
+         c.ent_coef, ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(g_mean),
+         ptr(g_L), ptr(sur), ptr(out), ptr(c.proj_mean), ptr(c.proj_L), N, K,
+         stream())
+    return g_mean, g_L, sur, out
+
+
 def _workspaces(c, N, K, P, ref):
     lib = _lib.load()
     if c.ws is None or c.ws_key != (N, K, P, ref.dtype):
@@ -132,7 +194,8 @@ def evaluate(mean_new, L_new, c, started=False, defer=False):
 class _Objective(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean_new, L_new, c):
-        g_mean, g_L, sur, out = evaluate(mean_new, L_new, c)
+        g_mean, g_L, sur, out = evaluate_bb(mean_new, L_new, c) \
+            if getattr(c, "bb", False) else evaluate(mean_new, L_new, c)
         ctx.save_for_backward(g_mean, g_L)
         # {surrogate, entropy loss, trust region loss, total, entropy, kl x 12}
         ent = out[12]

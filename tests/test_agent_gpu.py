@@ -399,13 +399,15 @@ def test_bbrl_kept_graphs_equal_fresh_graphs_over_iterations():
             assert abs(res[k] - out[2][0][k]) <= 1e-6 * abs(out[2][0][k]) + 1e-8
 
 
-def test_bbrl_step_matches_cpu_oracle():
+@pytest.mark.parametrize("fused", [False, True])
+def test_bbrl_step_matches_cpu_oracle(fused):
     """One BlackBoxAgent.step() (a16) against the CPU oracle step on the same
     weights, env state and parameter noise."""
     from oracle.agent_oracle import OracleBBRL
     N, EPOCHS = 24, 3
     agent, d_in = build_bbrl(N, EPOCHS)
     agent.evaluation_interval = 0
+    agent.fused_policy_objective = fused      # tce_bb_policy_objective_* / op by op
     oracle = OracleBBRL(BB_MP, N, d_in, [32, 32], [32, 32], "relu", True, 1e-5,
                         0.01, 3e-4, EPOCHS, 0.005, 0.0005, 1.0, True)
     with torch.no_grad():

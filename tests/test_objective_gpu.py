@@ -152,3 +152,8 @@ def test_objective_entry_points_reject_bad_arguments():
     assert lib.tce_policy_objective_end_f32(None, p, 4, 8, 2, None) != 0
     assert lib.tce_policy_objective_begin_f32(None, 3, 1e-3, p, 1e-3, None, 0,
                                               p, p, p, 4, 8, 2, None) != 0
+    assert lib.tce_bb_policy_objective_f32(
+        p, p, p, p, None, p, p, 0.01, 1e-3, None, 0, p, 1.0, 1, 0.0, p, p, p,
+        p, p, p, p, None, None, 4, 8, None) != 0
+    assert b"null buffer" in lib.tce_last_error()
+    assert lib.tce_bb_policy_objective_ws_len(4096, 20) > 4096 * 400
