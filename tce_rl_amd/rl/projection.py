@@ -104,12 +104,31 @@ class BaseProjectionLayer:
     def _projection(self, policy, p, q, eps, eps_cov, beta):
         """Trust region step, then entropy control (entropy_first=False, the
         setting of every shipped config; the scaling is fused into the
-        covariance kernel)."""
-        if self.entropy_first:
-            raise NotImplementedError("entropy_first")
+        covariance kernel) -- or the other way round."""
         if self.entropy_schedule_type in (None, False):
             beta = None                                # bound is -inf
+        if self.entropy_first and beta is not None:
+            # entropy control BEFORE the trust region step (no shipped config;
+            # a few elementwise torch ops on the factor, autograd through them)
+            p = self._entropy_projection(policy, p, beta)
+            beta = None
         return self._trust_region_projection(policy, p, q, eps, eps_cov, beta)
+
+    def _entropy_projection(self, policy, p, beta):
+        """Scale the factor by alpha = exp((beta - H) / K) where the entropy H
+        is below the bound beta (entropy_eq: everywhere)."""
+        mean, L = p
+        N, K = mean.shape
+        shared = not policy.contextual_std
+        Lb = ops.first_matrix(L) if shared else ops.full_L(L, N)
+        ent = 0.5 * K * (1.0 + np.log(2.0 * np.pi)) + \
+            Lb.diagonal(dim1=-2, dim2=-1).log().sum(-1)
+        b = beta.detach().to(ent.dtype).reshape(()).expand_as(ent)
+        alpha = torch.exp((b - ent) / K)
+        if not self.entropy_eq:
+            alpha = torch.where(ent < b, alpha, torch.ones_like(alpha))
+        Ls = Lb * alpha[..., None, None]
+        return mean, (ops.expand_shared(Ls, N) if shared else Ls)
 
     def trust_region_value(self, policy, p, q):
         return gaussian_kl(policy, p, q)

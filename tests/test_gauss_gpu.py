@@ -323,3 +323,53 @@ def test_shared_factor_lane_vector_kernels_edge_shapes(ops, N, K, dtype):
     gs = max(1.0, mu_c.grad.abs().max().item())
     torch.testing.assert_close(mu_g.grad.double().cpu(), mu_c.grad,
                                rtol=tol["rtol"], atol=tol["atol"] * gs)
+
+
+@pytest.mark.parametrize("contextual", [False, True])
+@pytest.mark.parametrize("entropy_eq", [False, True])
+def test_projection_layer_entropy_first(contextual, entropy_eq):
+    """KLProjectionLayer with entropy_first: the entropy control runs BEFORE the
+    trust region step (no shipped config; oracle/kl_oracle.project).  Forward
+    and gradients w.r.t. mean and factor, shared and per-env covariance."""
+    import types
+    from tce_rl_amd import ops
+    from tce_rl_amd.rl.projection import KLProjectionLayer
+    g = torch.Generator().manual_seed(5 + contextual)
+    N, K = 12, 10
+    B = N if contextual else 1
+    L_o = rand_chol(K, 1.0, g, B)
+    L = rand_chol(K, 0.7, g, B)             # lower entropy than the bound
+    mu_o = torch.randn(N, K, generator=g, dtype=F64)
+    mu = mu_o + 0.2 * torch.randn(N, K, generator=g, dtype=F64)
+    beta = float(KO.entropy(L).mean()) + 0.3
+    Wm = torch.randn(N, K, generator=g, dtype=F64)
+    WL = torch.randn(N, K, K, generator=g, dtype=F64)
+    full = lambda t: t if contextual else t.expand(N, -1, -1)
+    # oracle
+    mu_c, L_c = mu.clone().requires_grad_(True), L.clone().requires_grad_(True)
+    pm_c, pL_c = KO.project(mu_c, full(L_c), mu_o, full(L_o), 0.05, 5e-3,
+                            torch.tensor(beta, dtype=F64),
+                            contextual_std=contextual, entropy_eq=entropy_eq,
+                            entropy_first=True)
+    ((pm_c * Wm).sum() + (full(pL_c) * WL).sum()).backward()
+    # layer
+    layer = KLProjectionLayer(proj_type="kl", mean_bound=0.05, cov_bound=5e-3,
+                              entropy_schedule="linear", action_dim=K,
+                              total_train_steps=10, target_entropy=0.0,
+                              entropy_eq=entropy_eq, entropy_first=True,
+                              dtype=F64, cpu=False)
+    pol = types.SimpleNamespace(contextual_std=contextual)
+    mu_g = mu.cuda().requires_grad_(True)
+    L_g = L.cuda().requires_grad_(True)
+    Lg_in = L_g if contextual else ops.expand_shared(L_g[0], N)
+    Lo_in = L_o.cuda() if contextual else ops.expand_shared(L_o[0].cuda(), N)
+    pm, pL = layer._projection(pol, (mu_g, Lg_in), (mu_o.cuda(), Lo_in), 0.05,
+                               5e-3, torch.tensor(beta, dtype=F64).cuda())
+    pL_full = ops.full_L(pL, N)
+    torch.testing.assert_close(pm.cpu(), pm_c.detach(), rtol=1e-9, atol=1e-10)
+    torch.testing.assert_close(pL_full.cpu(), full(pL_c).detach(), rtol=1e-8,
+                               atol=1e-9)
+    ((pm * Wm.cuda()).sum() + (pL_full * WL.cuda()).sum()).backward()
+    torch.testing.assert_close(mu_g.grad.cpu(), mu_c.grad, rtol=1e-7, atol=1e-8)
+    torch.testing.assert_close(torch.tril(L_g.grad.cpu()), torch.tril(L_c.grad),
+                               rtol=1e-6, atol=1e-7)
