@@ -330,21 +330,25 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
     C[r][c] = acc + (r == c ? reg : real(0));
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < 64) {
+    // Cholesky, column by column, lane i = row i (R <= 16): the same sums in the
+    // same order as one thread would form them, R dependent steps instead of
+    // R^3 / 6 (the kernel sits on the critical path of every policy epoch)
     real logdet = 0;
     for (int j = 0; j < R; ++j) {
-      real sd = C[j][j];
-      for (int k = 0; k < j; ++k) sd -= C[j][k] * C[j][k];
-      const real ljj = sqrt(sd);
-      C[j][j] = ljj;
-      logdet += log(ljj);
-      for (int i = j + 1; i < R; ++i) {
-        real v = C[i][j];
-        for (int k = 0; k < j; ++k) v -= C[i][k] * C[j][k];
-        C[i][j] = v / ljj;
+      real v = 0;
+      if (tid >= j && tid < R) {
+        v = C[tid][j];
+        for (int k = 0; k < j; ++k) v -= C[tid][k] * C[j][k];
       }
+      const real ljj = sqrt(__shfl(v, j, 64));
+      logdet += log(ljj);
+      if (tid == j) C[j][j] = ljj;
+      else if (tid > j && tid < R) C[tid][j] = v / ljj;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
-    ld[0] = logdet;
+    if (tid == 0) ld[0] = logdet;
   }
   __syncthreads();
   if (tid < R) {                       // column tid of Lc^-1
