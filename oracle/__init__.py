@@ -16,20 +16,28 @@ Pinning status
   head, param-space Gaussian, MLP, losses, running mean/std, mdp-reward): pinned
   against golden vectors produced by importing the reference's own functions in
   the build container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
-* ``prodmp_oracle`` (ProDMP basis / trajectory / covariance): **parity
-  unpinned**.  The arithmetic lives in the un-vendored third-party package
-  ``mp_pytorch==0.1.4`` (``conda_env.sh:41``); it is restated from the ProDMP
-  paper (Li et al., RA-L 2023, cited at ``README.md:221-233``) and the
-  reference's call sites (``mprl/util/util_mp.py:11-46``,
-  ``mprl/rl/policy/temporal_correlated_policy.py:74-92,188-192``) and checked by
-  ODE / boundary-condition self-tests.  The *index plumbing* of the pair-wise
-  log-prob (gather order, dof-major flattening, MVN call) IS pinned by a golden
-  generated from the reference's ``TemporalCorrelatedPolicy.log_prob`` with this
-  oracle's ProDMP injected as ``policy.mp``.
-* ``kl_oracle`` (KL trust-region projection): **parity unpinned**.  Third-party
-  ``trust_region_projections`` @ ``TCE_ICLR24`` + ``cpp_projection`` (ITPAL)
-  (``conda_env.sh:34,56-60``); restated from Otto et al., ICLR 2021 and the
-  reference's call sites (``mprl/rl/projection/__init__.py:18-40``,
-  ``mprl/rl/agent/temporal_correlated_agent.py:439-441,530-567,641-686``);
-  checked by KKT / finite-difference self-tests.
+* ``prodmp_oracle`` (ProDMP basis / trajectory / covariance): **no reference
+  vectors exist** -- the arithmetic lives in the un-vendored third-party package
+  ``mp_pytorch==0.1.4`` (``conda_env.sh:41``), so parity with that package itself
+  is unpinned.  It is restated from the ProDMP paper (Li et al., RA-L 2023,
+  cited at ``README.md:221-233``) and the reference's call sites
+  (``mprl/util/util_mp.py:11-46``,
+  ``mprl/rl/policy/temporal_correlated_policy.py:74-92,188-192``) and pinned
+  against an INDEPENDENT numerical solution: ``tests/prodmp_ode.py`` integrates
+  the DMP ODE with scipy (DOP853), written from the paper and sharing no code
+  with this package; ``tests/test_prodmp_ode_cpu.py`` bounds oracle trajectory,
+  basis table and scale factors against it for every shipped MP configuration.
+  The *index plumbing* of the pair-wise log-prob (gather order, dof-major
+  flattening, MVN call) IS pinned by a golden generated from the reference's
+  ``TemporalCorrelatedPolicy.log_prob`` with this oracle's ProDMP injected as
+  ``policy.mp``.
+* ``kl_oracle`` (KL trust-region projection): **no reference vectors exist**
+  (third-party ``trust_region_projections`` @ ``TCE_ICLR24`` + ``cpp_projection``
+  (ITPAL), ``conda_env.sh:34,56-60``: parity with those packages is unpinned);
+  restated from Otto et al., ICLR 2021 and the reference's call sites
+  (``mprl/rl/projection/__init__.py:18-40``,
+  ``mprl/rl/agent/temporal_correlated_agent.py:439-441,530-567,641-686``) and
+  pinned against an INDEPENDENT solution of the constrained problem it solves:
+  ``tests/test_kl_optimum_cpu.py`` (scipy SLSQP on the Cholesky parameters), plus
+  KKT / finite-difference self-tests.
 """

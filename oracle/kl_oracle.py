@@ -1,4 +1,6 @@
-"""CPU restatement of the KL trust-region projection layer.  PARITY UNPINNED.
+"""CPU restatement of the KL trust-region projection layer.  No reference vectors
+exist (third-party arithmetic, absent): pinned against an independent SLSQP
+solution of the constrained problem instead (tests/test_kl_optimum_cpu.py).
 
 TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
 

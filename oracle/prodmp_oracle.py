@@ -1,4 +1,6 @@
-"""CPU restatement of the ProDMP trajectory generator.  PARITY UNPINNED.
+"""CPU restatement of the ProDMP trajectory generator.  No reference vectors
+exist (third-party arithmetic, absent): pinned against an independent scipy
+integration of the DMP ODE instead (tests/prodmp_ode.py, test_prodmp_ode_cpu.py).
 
 TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
 
