@@ -23,7 +23,7 @@ def supported(agent, dataset):
     pol, proj = agent.policy, agent.projection
     L_old = dataset["segment_params_L"]
     return (not pol.contextual_std and type(proj) is KLProjectionLayer
-            and not proj.entropy_first and not proj.do_regression
+            and not proj.entropy_first
             and ops.split_L(L_old)[1] == 0
             and not (pol.mp.disable_goal or pol.mp.disable_weights))
 
@@ -74,7 +74,7 @@ def bb_supported(agent, L_old):
     covariance under the KL projection."""
     pol, proj = agent.policy, agent.projection
     return (not pol.contextual_std and type(proj) is KLProjectionLayer
-            and not proj.entropy_first and not proj.do_regression
+            and not proj.entropy_first
             and ops.split_L(L_old)[1] == 0)
 
 

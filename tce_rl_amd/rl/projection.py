@@ -74,9 +74,10 @@ class BaseProjectionLayer:
         self.target_entropy = float(target_entropy)
         self.temperature = float(temperature)
         self.entropy_eq, self.entropy_first = entropy_eq, entropy_first
+        # accepted and stored like the third-party constructor does; the flag
+        # only matters to that layer's `trust_region_regression` step, which the
+        # reference's agents never call (no call site under mprl/)
         self.do_regression = do_regression
-        if do_regression:
-            raise NotImplementedError("do_regression")
         self.dtype = dtype
         self._initial_entropy = None
 
