@@ -81,39 +81,57 @@ def kernel_time_cold_us(fn, launches=5):
     return sorted(ts)[len(ts) // 2]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r02_pmc.json, else r01e / r01c: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, FETCH x2 correction); None if absent."""
-    for tag in ("r02", "r01e", "r01c"):
+PMC_TAGS = ("r03", "r02", "r01e", "r01c")
+STATS_CSV = ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv")
+
+
+def pmc_lookup(kernel):
+    """(HBM bytes per launch, source file) of `kernel` from the COMMITTED PMC
+    passes (profiles/<tag>_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, FETCH x2 correction on gfx950) -- read from the file, not
+    measured in this run; (None, None) if absent."""
+    for tag in PMC_TAGS:
         try:
-            with open(os.path.join(REPO, "profiles", tag + "_pmc.json")) as f:
-                return json.load(f)["kernels"][kernel]["traffic_bytes"]
+            rel = os.path.join("profiles", tag + "_pmc.json")
+            with open(os.path.join(REPO, rel)) as f:
+                return json.load(f)["kernels"][kernel]["traffic_bytes"], rel
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
+
+
+def pmc_traffic(kernel):
+    return pmc_lookup(kernel)[0]
+
+
+def pmc_source(kernel):
+    return pmc_lookup(kernel)[1]
 
 
 def profiled_us(kernel_substr):
-    """Average duration (us) of a kernel in the committed rocprofv3
-    --kernel-trace --stats summary of this same command
-    (profiles/r02_bench_kernel_stats.csv); None if absent."""
+    """(average duration in us, source file) of a kernel in the COMMITTED
+    rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/r03_bench_kernel_stats.csv, else r02) -- read from the file, not
+    measured in this run; (None, None) if absent."""
     import csv
-    try:
-        with open(os.path.join(REPO, "profiles",
-                               "r02_bench_kernel_stats.csv")) as f:
-            for row in csv.DictReader(f):
-                if kernel_substr in row["Name"]:
-                    return round(float(row["AverageNs"]) / 1e3, 1)
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    for name in STATS_CSV:
+        try:
+            rel = os.path.join("profiles", name)
+            with open(os.path.join(REPO, rel)) as f:
+                for row in csv.DictReader(f):
+                    if kernel_substr in row["Name"]:
+                        return round(float(row["AverageNs"]) / 1e3, 1), rel
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
-def hbm_entry(name, alg, us, us_cold=None, note=None, traffic=None):
+def hbm_entry(name, alg, us, us_cold=None, note=None, pmc_kernel=None):
+    traffic, src = pmc_lookup(pmc_kernel) if pmc_kernel else (None, None)
     d = {"kernel": name, "bound": "hbm", "achieved": round(alg / us / 1e3, 1),
          "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "traffic_source": src,
          "us_per_launch": round(us, 2), "algorithmic_bytes": alg}
     if us_cold is not None:
         d["cold"] = {"us_per_launch": round(us_cold, 2),
@@ -124,7 +142,7 @@ def hbm_entry(name, alg, us, us_cold=None, note=None, traffic=None):
     return d
 
 
-def roofline(agent, critic_ms_in_step, with_f16=False):
+def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
     """Rooflines measured live with HIP events on the launch stream.
 
     dominant kernel = mlp_critic_bwd_kernel (+ mlp_finish_kernel: the 50 critic
@@ -157,12 +175,15 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
+    # the timed steps hold envs_in_step envs per rank (4096 unless --scaling strong)
+    flops_step = flops * (envs_in_step or N) / N
     us_step = critic_ms_in_step * 1e3 / EPOCHS
     critic = {"kernel": "mlp_critic_bwd_kernel<relu,10> (+ mlp_finish_kernel)",
-              "bound": "mfma", "achieved": round(flops / us_step / 1e6, 2),
+              "bound": "mfma", "achieved": round(flops_step / us_step / 1e6, 2),
               "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-              "frac": round(flops / us_step / 1e6 / F32_MFMA_PEAK_TF, 4),
+              "frac": round(flops_step / us_step / 1e6 / F32_MFMA_PEAK_TF, 4),
               "traffic": pmc_traffic("mlp_critic_bwd_kernel"),
+              "traffic_source": pmc_source("mlp_critic_bwd_kernel"),
               "us_per_launch": round(us_step, 1),
               "measured": "HIP events on the critic stream around the 50 "
                           "epochs of every timed step (launch + slab "
@@ -171,8 +192,9 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
                   "us_per_launch": round(us_c, 1),
                   "achieved": round(flops / us_c / 1e6, 2),
                   "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4)},
-              "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel"),
-              "algorithmic_flops": flops,
+              "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel")[0],
+              "rocprof_source": profiled_us("mlp_critic_bwd_kernel")[1],
+              "algorithmic_flops": flops_step,
               "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     critic16 = None if us_c16 is None else {
         "kernel": "mlp_critic_bwd16_kernel<relu,2> (+ mlp_finish_kernel)",
@@ -180,6 +202,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
         "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": round(flops / us_c16 / 1e6 / F16_MFMA_PEAK_TF, 4),
         "traffic": pmc_traffic("mlp_critic_bwd16_kernel"),
+        "traffic_source": pmc_source("mlp_critic_bwd16_kernel"),
         "us_per_launch": round(us_c16, 1),
         "algorithmic_flops": flops,
         "mfma_flops_issued": 3 * flops,
@@ -203,7 +226,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
         "C2 size: the 37 MB working set stays in the 256 MB Infinity Cache "
         "between back-to-back launches (as in the step, where values and "
         "rewards were just produced); `cold` = after a 1 GiB fill",
-        pmc_traffic("gae_dpp_kernel"))
+        "gae_dpp_kernel")
     alg, us, us_cold = gae_case(8 * N)
     extra["gae_scan_32768_envs"] = hbm_entry(
         "gae_dpp_kernel<float,true,true,8>", alg, us, us_cold,
@@ -227,7 +250,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
         "trajectory kernel; the [T, 4+2(nb+1)] basis table (one 10 us kernel) "
         "is built once per time grid and reused by the ~100 trajectory / "
         "log-prob evaluations of a rollout + update (ops._times_flags)",
-        pmc_traffic("prodmp_traj_rows_kernel<float, 4"))
+        "prodmp_traj_rows_kernel<float, 4")
     alg, us, us_cold = traj_case(mp, 8 * N, T)
     extra["prodmp_traj_32768_envs"] = hbm_entry(
         "prodmp_traj_rows_kernel<float,4,6>", alg, us, us_cold,
@@ -241,7 +264,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
         "prodmp_traj_rows_kernel<float,7,9>", alg, us, us_cold,
         "BASELINE configs[2] rows (dof 7: 56-byte rows, stored through a "
         "wave-private LDS slab as contiguous 8-byte chunks), 65536 envs x T "
-        "100 = 367 MB", pmc_traffic("prodmp_traj_rows_kernel<float, 7"))
+        "100 = 367 MB", "prodmp_traj_rows_kernel<float, 7")
 
     # env rollout kernel: writes the [N, T+1, D] state buffer once, reads the
     # desired trajectory; column moments in the same pass
@@ -262,7 +285,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
         "buffer written once (%d MB), observation moments accumulated in the "
         "same pass; instruction-bound (one wave per env, ~200 instructions "
         "per step)" % (N, N * (T + 1) * D * 4 // 1000000),
-        pmc_traffic("env_rollout_kernel"))
+        "env_rollout_kernel")
     del acts
 
     # wide / fp64 critics of BASELINE configs[2] (box pushing): one epoch =
@@ -288,6 +311,8 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
             "traffic": (None if tag != "f32" or pmc_traffic("mlpw_chain_kernel")
                         is None else pmc_traffic("mlpw_chain_kernel") +
                         pmc_traffic("mlpw_grad_kernel")),
+            "traffic_source": pmc_source("mlpw_chain_kernel")
+            if tag == "f32" else None,
             "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
             "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
                         "D_in 22 -> 256 -> 256 -> 1, leaky_relu",
@@ -295,6 +320,134 @@ def roofline(agent, critic_ms_in_step, with_f16=False):
                             else " (v_mfma_f64_16x16x4_f64)")}
         del st, rt, runw, wide
     return critic, extra
+
+
+# The other BASELINE.json configs, a few timed steps each.
+# `kind`: "tce" -> tce_config(env, ...), "bbrl" -> bbrl_config(...).  C4 / C5
+# are multi-GPU configs in BASELINE.json (4 x 4096 / 8 x 4096 envs): what one
+# GPU runs of them -- its 4096-env shard -- is timed here.
+OTHER_CONFIGS = [
+    ("C3_box_push_f32", dict(
+        kind="tce", env="box_push", num_env=8192, num_basis=8, epochs=50,
+        dtype="float32",
+        workload="BASELINE.json configs[2]: TCE, box-pushing-like synthetic "
+                 "env, 8192 envs, T 100, dof 7, ProDMP 8 basis (K 63), critic "
+                 "22 -> 256 -> 256 -> 1 leaky_relu, 50 + 50 epochs, fp32 "
+                 "(mprl/config/box_push_random_init/tcp/entire/shared.yaml)")),
+    ("C3_box_push_f64", dict(
+        kind="tce", env="box_push", num_env=8192, num_basis=8, epochs=50,
+        dtype="float64",
+        workload="the same in float64, the reference's dtype for this task "
+                 "(box_push_random_init/tcp/entire/shared.yaml:7)")),
+    ("C4_bbrl_shard", dict(
+        kind="bbrl", num_env=4096, epochs=100, dtype="float32",
+        workload="BASELINE.json configs[3]: BBRL, Metaworld-push-like "
+                 "synthetic black-box env, one GPU's 4096-env shard of the "
+                 "16384, K 20 diagonal, 32 x 2 nets, 100 + 100 epochs "
+                 "(mprl/config/metaworld/bbrl/entire/shared.yaml:38-39), "
+                 "trust_region_coeff 10, set_variance, fp32")),
+    ("C5_table_tennis_nb3_shard", dict(
+        kind="tce", env="table_tennis", num_env=4096, num_basis=3, epochs=50,
+        dtype="float32",
+        workload="BASELINE.json configs[4] with the reference's 3 basis "
+                 "functions (K 28; table_tennis_4d/tcp/entire/shared.yaml:"
+                 "56-60): TCE, table-tennis-like synthetic env, one GPU's "
+                 "4096-env shard of the 32768, T 350, dof 7, MDP-reward, "
+                 "tanh 256 x 1 policy, leaky_relu 256 x 2 critic, fp32")),
+    ("C5_table_tennis_nb8_shard", dict(
+        kind="tce", env="table_tennis", num_env=4096, num_basis=8, epochs=50,
+        dtype="float32",
+        workload="BASELINE.json configs[4] as worded (ProDMP 8 basis, K 63), "
+                 "otherwise as above")),
+]
+
+
+def build_config_agent(spec, seed=0):
+    from tce_rl_amd.config import bbrl_config, tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    if spec["kind"] == "bbrl":
+        cfg = bbrl_config(num_env=spec["num_env"], epochs=spec["epochs"],
+                          dtype=spec["dtype"], device="cuda", seed=seed,
+                          evaluation_interval=0)
+    else:
+        cfg = tce_config(spec["env"], num_env=spec["num_env"],
+                         num_basis=spec["num_basis"], epochs=spec["epochs"],
+                         dtype=spec["dtype"], device="cuda", seed=seed,
+                         evaluation_interval=0)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    return exp.agent
+
+
+def run_config(name, spec, steps, warmup):
+    """One entry of the `configs` block: W untimed + K timed agent.step()s of
+    one BASELINE config on this GPU, synchronised wall time, plus the roofline
+    of its dominant kernel from the device time (HIP events on the critic's
+    stream) of the critic epochs INSIDE those steps."""
+    agent = build_config_agent(spec)
+    T = agent.sampler.num_times
+    N = spec["num_env"]
+    for _ in range(warmup):
+        agent.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    crit = pol = samp = 0.0
+    for _ in range(steps):
+        res = agent.step()
+        crit += res.get("update_critic_time", 0.0)
+        pol += res.get("update_policy_time", 0.0)
+        samp += res.get("sampling_time", 0.0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    E = spec["epochs"]
+    out = {"workload": spec["workload"], "num_env": N, "num_times": T,
+           "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],
+           "steps": steps, "warmup": warmup,
+           "ms_per_step": round(el / steps * 1e3, 2),
+           "env_steps_per_sec": round(N * T * steps / el, 1),
+           "sampling_ms": round(samp / steps * 1e3, 2)}
+    net = agent.critic.net
+    hs = [l.weight.shape[0] for l in net.layers[:-1]]
+    din = net.dim_in
+    rows = N * T if spec["kind"] == "tce" else N
+    flops = 6.0 * (din * hs[0] + hs[0] * hs[1] + hs[1]) * rows
+    f64 = spec["dtype"] == "float64"
+    peak = F64_MFMA_PEAK_TF if f64 else F32_MFMA_PEAK_TF
+    if spec["kind"] == "tce":
+        us = crit / steps / E * 1e6
+        out["policy_updates_per_sec"] = round(E * steps / pol, 2)
+        out["critic_ms_per_step"] = round(crit / steps * 1e3, 2)
+        out["policy_ms_per_step"] = round(pol / steps * 1e3, 2)
+        out["roofline"] = {
+            "kernel": "critic epoch %d -> %d -> %d -> 1 (%s), %d rows"
+                      % (din, hs[0], hs[1], getattr(
+                          agent, "_critic_runner", None).__class__.__name__,
+                         rows),
+            "bound": "mfma", "achieved": round(flops / us / 1e6, 2),
+            "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / us / 1e6 / peak, 4),
+            "us_per_launch": round(us, 1), "algorithmic_flops": flops,
+            "traffic": None,
+            "measured": "HIP events around the %d critic epochs of every "
+                        "timed step, policy epochs on a second stream" % E}
+    else:
+        # the black-box agent's step: 2 x E epochs on 4096 rows of 32-wide nets
+        # are latency-bound (56 MFLOP per epoch); the HBM work is the rollout
+        upd = res.get("update_time", 0.0)
+        out["update_ms_last_step"] = round(upd * 1e3, 2)
+        out["policy_updates_per_sec"] = round(
+            E / max(upd, 1e-9), 2) if upd else None
+        out["roofline"] = {
+            "kernel": "critic + policy epochs (%d -> %d -> %d nets, %d rows)"
+                      % (din, hs[0], hs[1], rows),
+            "bound": "latency",
+            "us_per_epoch_pair": round(upd / E * 1e6, 1) if upd else None,
+            "algorithmic_flops_per_epoch": flops,
+            "note": "2 x %d dependent epochs of a few small kernels each: "
+                    "launch / dependency latency, neither HBM nor MFMA" % E}
+    del agent
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline():
@@ -331,11 +484,30 @@ def cpu_baseline():
                       "3 timed steps = %.2f s" % (n, dt)}
 
 
+def _kill_tree(proc):
+    """End the launcher child and everything it started (it runs in its own
+    session, so its process group holds exactly its descendants)."""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            return
+        try:
+            proc.wait(timeout=10)
+            return
+        except Exception:
+            continue
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` from a plain shell (WORLD_SIZE unset): this
     process has not touched the GPU and never will -- it starts the N ranks as
     fresh children through torch.distributed.run (no exec), relays rank 0's
-    JSON line and returns the children's exit code."""
+    JSON line and returns the children's exit code.  The children get
+    ``--launch-timeout`` seconds (default 900: a hung collective must not sit
+    until the driver's limit); past it the whole child tree is killed and the
+    exit code is 124."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -350,22 +522,43 @@ def self_launch(args):
         cmd.append("--no-cpu-baseline")
     if args.with_split_f16:
         cmd.append("--with-split-f16")
+    if getattr(args, "no_configs", False):
+        cmd.append("--no-configs")
+    if getattr(args, "scaling", "weak") != "weak":
+        cmd += ["--scaling", args.scaling]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    limit = float(getattr(args, "launch_timeout", 900.0))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                            start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        print("[bench] the %d ranks did not finish within %.0f s: killing "
+              "the child tree" % (args.gpus, limit), file=sys.stderr)
+        _kill_tree(proc)
+        try:
+            stdout, _ = proc.communicate(timeout=10)
+        except Exception:
+            stdout = b""
+        rc = 124
+    except BaseException:
+        _kill_tree(proc)
+        raise
     line = None
-    for ln in r.stdout.decode(errors="replace").splitlines():
+    for ln in (stdout or b"").decode(errors="replace").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
-    if line is not None:
+    if line is not None and rc == 0:
         print(line, flush=True)
-    elif r.returncode == 0:
+    elif rc == 0:
         print("[bench] no JSON line from rank 0", file=sys.stderr)
         return 1
-    return r.returncode
+    return rc
 
 
 def main():
@@ -380,7 +573,24 @@ def main():
                          "option, not the reported value)")
     ap.add_argument("--no-split-f16", action="store_true",
                     help="accepted for older command lines (the default now)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (the other BASELINE.json "
+                         "configs, a few timed steps each)")
+    ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--config-warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, what the driver's curve uses): 4096 "
+                         "envs per GPU; strong: 4096 envs in total, "
+                         "4096 / N per GPU (SURVEY 8d)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="seconds the self-launched ranks may take")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="seconds a collective may take before the process "
+                         "group aborts (a hang must not sit until the "
+                         "driver's limit)")
     args = ap.parse_args()
+    # before anything initialises the HIP / HSA runtime (dmabuf IPC for RCCL)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # N > 1 without a launcher: become the launcher BEFORE any GPU call
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -415,17 +625,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
     if world > 1 or force:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        tmo = datetime.timedelta(seconds=args.collective_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(
-                "cuda", local_rank))
+            dist.init_process_group("nccl", timeout=tmo,
+                                    device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
-    # the GLOBAL env count: MPExperiment gives every rank NUM_ENV of them and
-    # the env / noise seed `seed + rank`
-    agent, cfg = build_agent(NUM_ENV * world, seed=0)
-    assert agent.sampler.num_env_train == NUM_ENV
+    # the GLOBAL env count: MPExperiment gives every rank its share of them
+    # and the env / noise seed `seed + rank`.  weak: 4096 per GPU; strong:
+    # 4096 in total
+    strong = args.scaling == "strong"
+    if strong and NUM_ENV % world:
+        raise SystemExit("bench.py --scaling strong: %d envs do not divide "
+                         "over %d ranks" % (NUM_ENV, world))
+    envs_per_rank = NUM_ENV // world if strong else NUM_ENV
+    agent, cfg = build_agent(envs_per_rank * world, seed=0)
+    assert agent.sampler.num_env_train == envs_per_rank
     T = agent.sampler.num_times
 
     is_dist = dist.is_initialized()
@@ -445,11 +662,13 @@ def main():
         dist.all_gather_into_tensor(every, tt[None])
         return every.max(0).values.tolist(), every[:, 0].tolist()
 
+    from tce_rl_amd import dist as tdist
     for _ in range(args.warmup):
         agent.step()
     barrier()
     if rank == 0:
         print("[bench] warmup done", file=sys.stderr, flush=True)
+    tdist.reset_stats()
     t0 = time.perf_counter()
     pol_time = crit_time = 0.0
     for _ in range(args.steps):
@@ -458,6 +677,7 @@ def main():
         crit_time += res["update_critic_time"]      # device time (HIP events)
     barrier()
     elapsed = time.perf_counter() - t0
+    coll = dict(tdist.STATS)
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
 
     # the same K steps (after W warm-up steps) with the critic epochs on the
@@ -481,11 +701,11 @@ def main():
         agent.critic_arith = "f32"
 
     if rank == 0:
-        env_steps = world * NUM_ENV * T * args.steps
+        env_steps = world * envs_per_rank * T * args.steps
         print("[bench] timed region: %.3f s" % elapsed, file=sys.stderr,
               flush=True)
         roof, extra = roofline(agent, crit_time / args.steps * 1e3,
-                               args.with_split_f16)
+                               args.with_split_f16, envs_per_rank)
         print("[bench] roofline done", file=sys.stderr, flush=True)
         out = {
             "metric": "env-steps/sec (TCE rollout + update, Metaworld-reach-"
@@ -496,13 +716,14 @@ def main():
             "iterations_per_sec": round(args.steps / elapsed, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: TCE, Metaworld-"
                        "reach-like synthetic env, 4096 envs per GPU, T 500, "
                        "P 24, dof 4, ProDMP 5 basis (K 24), 50 critic + 50 "
                        "policy epochs, KL projection, fp32",
-                       "num_env_per_gpu": NUM_ENV, "num_times": T,
+                       "num_env_per_gpu": envs_per_rank, "num_times": T,
                        "num_basis": NUM_BASIS, "epochs": EPOCHS,
                        "parallelism": "env-shard x%d" % world},
             "backend": (dist.get_backend() if is_dist else None),
@@ -510,6 +731,10 @@ def main():
                            dist.get_backend() == "nccl" else 0),
             "ms_per_step_per_rank": [round(t / args.steps * 1e3, 2)
                                      for t in per_rank],
+            # what this rank put on the wire per step (tce_rl_amd/dist.py
+            # counters over the timed region; all ranks issue the same)
+            "collectives_per_step": round(coll["collectives"] / args.steps, 1),
+            "collective_bytes_per_step": round(coll["bytes"] / args.steps),
             "roofline": roof, "roofline_extra": extra,
         }
         if fast is not None:
@@ -524,6 +749,16 @@ def main():
                 "policy_updates_per_sec": round(
                     EPOCHS * args.steps / fast[1], 2),
                 "roofline": extra["critic_split_f16"]}
+        if world == 1 and not args.no_configs:
+            del agent
+            torch.cuda.empty_cache()
+            out["configs"] = {}
+            for name, spec in OTHER_CONFIGS:
+                out["configs"][name] = run_config(
+                    name, spec, args.config_steps, args.config_warmup)
+                print("[bench] config %s: %.1f ms/step" % (
+                    name, out["configs"][name]["ms_per_step"]),
+                    file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

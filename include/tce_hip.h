@@ -383,6 +383,10 @@ int64_t tce_policy_objective_ws_len(int64_t N, int K, int P);
  * stream and the streams of two RCCL communicators) should say 1: streams that
  * share a hardware queue wait for each other's kernels. */
 int tce_policy_objective_streams(int n);
+/* The library-owned second stream (created on first use): lets a caller order
+ * its own work against it -- the tests stall it to show that the deferred join
+ * of tce_policy_objective_* does not depend on timing. */
+int tce_policy_objective_side_stream(void** stream);
 int tce_policy_objective_f32(
     const float* mean_new, const float* L_new, const float* mean_old, const float* L_old,
     const float* traj, const float* logp_old, const float* adv, const int64_t* pairs,

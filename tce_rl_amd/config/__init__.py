@@ -67,3 +67,55 @@ def tce_config(env="metaworld", num_env=4096, num_basis=8, dtype="float32",
     }
     return {"name": "tce_" + env, "seed": seed, "iterations": iterations,
             "verbose_level": 2, "params": params}
+
+
+def bbrl_config(num_env=4096, dtype="float32", device="cuda", epochs=100,
+                iterations=10000, seed=0, evaluation_interval=0,
+                num_env_test=None, env_id="metaworld_ProDMP/push-v2"):
+    """The black-box baseline on Metaworld (BASELINE.json configs[3]): the
+    ``params`` document of mprl/config/metaworld/bbrl/entire/shared.yaml:26-121
+    (32 x 2 relu nets :61-91, diagonal covariance :69, K = 4 dof x (4 + 1)
+    :52-53, 100 + 100 epochs :38-39, trust_region_coeff 10 :99, set_variance
+    :43, no entropy schedule :101) with the env count as the free parameter.
+    ``env_id``: BASELINE names push-v2, the YAML's default is button-press-v2;
+    both map to the same synthetic stand-in family."""
+    mp = {"type": "prodmp", "args": dict(
+        num_dof=4, num_basis=4, weights_scale=0.1, goal_scale=0.1,
+        relative_goal=True, disable_goal=False, tau=5.0,
+        basis_bandwidth_factor=5, alpha_phase=3, alpha=10, dt=0.0125,
+        dtype=dtype, device=device)}
+    net = dict(avg_neuron=32, num_hidden=2, shape=0.0)
+    params = {
+        "agent": {"type": "BlackBoxAgent", "args": dict(
+            lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0, wd_critic=0.0,
+            clip_critic=0.0, clip_grad_norm=0.0, entropy_penalty_coef=0.0,
+            discount_factor=1, epochs_policy=epochs, epochs_critic=epochs,
+            num_minibatchs=1, norm_advantages=True, clip_advantages=0.0,
+            set_variance=True, balance_check=25,
+            evaluation_interval=evaluation_interval, dtype=dtype,
+            device=device)},
+        "mp": mp,
+        "policy": {"type": "BlackBoxPolicy", "args": dict(
+            mean_net_args=dict(net),
+            variance_net_args=dict(std_only=True, contextual=False),
+            init_method="orthogonal", out_layer_gain=0.01, min_std=1e-5,
+            act_func_hidden="relu", act_func_last=None, dtype=dtype,
+            device=device)},
+        "critic": {"type": "ValueFunction", "args": dict(
+            hidden=dict(net), init_method="orthogonal", out_layer_gain=1,
+            act_func_hidden="relu", act_func_last=None, dtype=dtype,
+            device=device)},
+        "projection": {"type": "KLProjectionLayer", "args": dict(
+            proj_type="kl", mean_bound=0.005, cov_bound=0.0005,
+            trust_region_coeff=10.0, scale_prec=True, entropy_schedule=False,
+            target_entropy=0.0, temperature=0.5, entropy_eq=False,
+            entropy_first=False, do_regression=False, dtype=dtype,
+            device=device)},
+        "sampler": {"type": "BlackBoxSampler", "args": dict(
+            env_id=env_id, num_env_train=num_env,
+            num_env_test=num_env_test or min(num_env, 64),
+            dtype=dtype, device=device, seed=seed,
+            task_specified_metrics=["success"], mp=mp)},
+    }
+    return {"name": "bbrl_metaworld", "seed": seed, "iterations": iterations,
+            "verbose_level": 2, "params": params}

@@ -169,8 +169,19 @@ __global__ __launch_bounds__(64) void env_rollout_kernel(
     for (int j = 0; j < 4; ++j) {
       const int el = 4 * (g + ENV_LPE * j);
       int64_t e0 = (int64_t)blk * BS * A + (el < BS * A ? el : 0);
-      e0 = e0 + 3 < total ? e0 : total - 4;
-      b.v[j] = *reinterpret_cast<const ld4*>(act + e0);
+      // a chunk that would run past the episode loads its last 4 elements and
+      // is SHIFTED so that element e0 + k stays in slot k (T * A = 2 mod 4 --
+      // odd T with an odd dof -- ends in a half chunk; a plain clamp put
+      // act[total - 4 ..] into the slots of act[total - 2 ..])
+      const int64_t ec = e0 + 3 < total ? e0 : total - 4;
+      const int sh = (int)(e0 - ec) < 3 ? (int)(e0 - ec) : 3;
+      const ld4 v = *reinterpret_cast<const ld4*>(act + ec);
+      ld4 w;
+      w[0] = sh == 0 ? v[0] : sh == 1 ? v[1] : sh == 2 ? v[2] : v[3];
+      w[1] = sh == 0 ? v[1] : sh == 1 ? v[2] : v[3];
+      w[2] = sh == 0 ? v[2] : v[3];
+      w[3] = v[3];
+      b.v[j] = w;
     }
   };
   auto park_block = [&](int buf, const Blk& b) {
@@ -434,6 +445,7 @@ extern "C" {
     TCE_CHECK_ARG(d_task >= 2 * dof + 6 && d_task + 1 + 2 * dof <= 64,             \
                   "env_rollout: 2 dof + 6 <= d_task and D <= 64");                 \
     TCE_CHECK_ARG(N < (1ll << 31), "env_rollout: too many envs");                  \
+    TCE_CHECK_ARG((int64_t)T * 2 * dof >= 4, "env_rollout: T * 2 dof >= 4");       \
     const int need = (16 * (d_task + 1 + 2 * dof) + 63) / 64;                      \
     const dim3 grid((unsigned)((N + ENV_EPW - 1) / ENV_EPW));                      \
     hipStream_t st = (hipStream_t)stream;                                          \

@@ -255,7 +255,7 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
 // ---------------------------------------------------------------------------
 struct ObjSide {
   hipStream_t side = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 int g_obj_streams = 2;            // tce_policy_objective_streams: 1 = everything on the caller's stream
@@ -266,7 +266,7 @@ inline ObjSide* obj_side() {
   if (!tried) {
     tried = true;
     ok = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 5; ++i)
+    for (int i = 0; ok && i < 6; ++i)
       ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
   }
   return ok ? &s : nullptr;
@@ -384,6 +384,9 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
   OBJ_TRY(kl_shared<real>(mean_new, mean_old, pm, L_new, L_old, pL, N, K, tr_coeff,
                           tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd));
+  // grad_mean (written by kl_shared_env_kernel on the side stream) is complete
+  // here: the deferred join adds to it on `st` before ev[4] is waited for
+  OBJ_HIP(hipEventRecord(S->ev[5], sd));
   // ---- main: pair log-prob under the projection, surrogate, and back
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
   OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
@@ -409,6 +412,7 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   if (defer_join) {
     // grad_mean is complete after this; grad_L lacks the projection's part until
     // tce_policy_objective_end_* joins the side stream
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
     hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st,
                        grad_mean, gm_p, n1, grad_L, gL_p, (int64_t)0);
     TCE_LAUNCH_CHECK();
@@ -686,6 +690,14 @@ int64_t tce_bb_policy_objective_ws_len(int64_t N, int K) { return bb_obj_ws_len(
 
 int tce_policy_objective_streams(int n) {
   g_obj_streams = n < 2 ? 1 : 2;
+  return 0;
+}
+
+int tce_policy_objective_side_stream(void** stream) {
+  TCE_CHECK_ARG(stream != nullptr, "policy_objective_side_stream: null output");
+  ObjSide* S = obj_side();
+  TCE_CHECK_ARG(S != nullptr, "policy_objective: could not create the side stream");
+  *stream = reinterpret_cast<void*>(S->side);
   return 0;
 }
 

@@ -18,6 +18,36 @@ import torch
 import torch.distributed as dist
 
 
+# Collectives issued by this process since the last reset (count, payload
+# bytes): bench.py reports them per step so that a reader of the scaling curve
+# can see what the wire carried.
+STATS = {"collectives": 0, "bytes": 0}
+
+
+def reset_stats():
+    STATS["collectives"] = STATS["bytes"] = 0
+
+
+def _count(t):
+    STATS["collectives"] += 1
+    STATS["bytes"] += t.numel() * t.element_size()
+
+
+def all_reduce(t, op=None, group=None):
+    _count(t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op, group=group)
+
+
+def all_gather_into_tensor(out, t, group=None):
+    _count(out)
+    dist.all_gather_into_tensor(out, t, group=group)
+
+
+def broadcast(t, src=0, group=None):
+    _count(t)
+    dist.broadcast(t, src=src, group=group)
+
+
 def active(group=None):
     """True when the sharded code path (collectives included) is to be taken:
     a process group of more than one rank, or -- TCE_FORCE_DIST=1 -- any
@@ -66,7 +96,7 @@ class DistContext:
             flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
             self._flat[key] = flat
         torch.cat([g.reshape(-1) for g in grads], out=flat)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce(flat, group=self.group)
         flat.div_(self.world)
         off = 0
         for g in grads:
@@ -78,8 +108,7 @@ class DistContext:
         gradient buffer."""
         if not self.active:
             return
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM,
-                        group=self.group if group is None else group)
+        all_reduce(flat, group=self.group if group is None else group)
         if average:
             flat.div_(self.world)
 
@@ -87,11 +116,11 @@ class DistContext:
         if not self.active:
             return x
         y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce(y, group=self.group)
         return y / self.world
 
     def broadcast_params(self, params):
         if not self.active:
             return
         for p in params:
-            dist.broadcast(p.data, src=0, group=self.group)
+            broadcast(p.data, src=0, group=self.group)

@@ -66,6 +66,11 @@ def initial_object(task, goal3, hand):
 
 
 class SyntheticTCEEnv:
+    # step(actions, obs_shift=..., want_moments=True) returns the whole
+    # [N, T+1, D] buffer and the column moments of the same pass; the sampler
+    # takes the reference protocol's path for envs without this attribute
+    fused_obs_moments = True
+
     def __init__(self, env_id, num_env, num_dof, dtype=torch.float32,
                  device="cuda", seed=0, num_times=None, dt=None,
                  dim_task_obs=None):

@@ -234,12 +234,14 @@ def load_config(path, exp_name=None):
 def main(argv):
     # under torch.distributed.run (WORLD_SIZE set): one process per GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # before anything initialises the HIP / HSA runtime (the host driver only
+    # supports dmabuf IPC; RCCL's peer-to-peer setup needs it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
         import torch
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(
             os.environ.get("TCE_BACKEND", "nccl"),
             **({"device_id": torch.device("cuda", local)}

@@ -31,12 +31,12 @@ def merge_stats(stats, group=None):
     (exact pooled-moments identity), so that a sharded batch normalises with
     the statistics of the global batch."""
     import torch.distributed as dist
-    from .dist import active
+    from .dist import active, all_gather_into_tensor
     if not active(group):
         return stats
     w = dist.get_world_size(group)
     buf = stats.new_empty(w, 3)
-    dist.all_gather_into_tensor(buf, stats.reshape(1, 3), group=group)
+    all_gather_into_tensor(buf, stats.reshape(1, 3), group=group)
     n = buf[:, 0].sum()
     mean = (buf[:, 0] * buf[:, 1]).sum() / n
     m2 = (buf[:, 2] + buf[:, 0] * (buf[:, 1] - mean) ** 2).sum()
@@ -145,13 +145,13 @@ def segment_advantage(mode, rewards, values, advantages, pred_pairs, gamma,
         # env shards: the reference subtracts the column mean of the WHOLE
         # batch (temporal_correlated_agent.py:311) -> raw sums, all-reduced
         # column sums + row count, second pass with the global means
-        import torch.distributed as dist
+        from .dist import all_reduce
         call("tce_segment_accrew_" + s, ptr(r), ptr(pairs), P, ptr(out), N, T,
              float(gamma), None, 0, stream())
         tot = torch.cat([sum_dim0(out).double(),
                          torch.full((1,), float(N), dtype=torch.float64,
                                     device=r.device)])
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(tot, group=group)
         mean = _c((tot[:P] / tot[P]).to(r.dtype))
         call("tce_segment_accrew_" + s, ptr(r), ptr(pairs), P, ptr(out), N, T,
              float(gamma), ptr(mean), 1, stream())

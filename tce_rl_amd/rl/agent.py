@@ -464,8 +464,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 # critic's first part, the policy's, the critic's rest): agree
                 # on the largest split
                 import torch.distributed as dist
+                from ..dist import all_reduce
                 t = torch.tensor([split], device=self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
+                all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
                 split = int(t.item())
             self._critic_split = split
         return critic_loss_dict, policy_loss_dict, \
@@ -890,13 +891,29 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 self.projection.entropy_schedule_type in (None, False)):
             return None, inputs
         g = opt.param_groups[0]
-        sig = (E, g["lr"], g.get("weight_decay", 0.0), self.clip_grad_norm,
+        pr = self.projection
+        sig = (E, g["lr"], g.get("weight_decay", 0.0), tuple(g["betas"]),
+               g["eps"], self.clip_grad_norm,
                self.clip_critic, self.entropy_penalty_coef, self.set_variance,
+               # scalar kernel arguments of the projection the recording bakes in
+               float(getattr(pr, "mean_bound", 0.0)),
+               float(getattr(pr, "cov_bound", 0.0)),
+               float(getattr(pr, "trust_region_coeff", 0.0)),
                tuple((k, tuple(v.shape), v.dtype,
                       getattr(v, "_tce_base", None) is not None)
                      for k, v in inputs.items()))
         eg = self._epoch_graphs.get(kind)
         if eg is None or eg.sig != sig:
+            if eg is not None:
+                n = self._graph_rerecords = getattr(
+                    self, "_graph_rerecords", 0) + 1
+                if n == 3:
+                    import warnings
+                    warnings.warn(
+                        "BlackBoxAgent: the kept %s epoch graph was re-recorded "
+                        "3 times (a learning-rate schedule or changing bounds "
+                        "invalidate it every iteration): the saving of "
+                        "cache_epoch_graphs is lost" % kind)
             eg = _EpochGraph(sig, inputs, rec_cols, E, self.dtype, self.device)
             self._epoch_graphs[kind] = eg
         return eg, eg.bind(inputs)

@@ -50,7 +50,7 @@ class RunningMeanStd:
         """fold(mean, var, count) -> new count merges the local batch into the
         given running state in place."""
         import torch.distributed as dist
-        from ..dist import active
+        from ..dist import active, all_gather_into_tensor
         if not active():
             self.count = fold(self.mean, self.var, self.count)
             return
@@ -63,7 +63,7 @@ class RunningMeanStd:
         mine = torch.cat([bm.double().reshape(-1), bv.double().reshape(-1),
                           bm.new_full((1,), float(n_loc)).double()])
         allr = mine.new_empty(w, 2 * D + 1)
-        dist.all_gather_into_tensor(allr, mine[None])
+        all_gather_into_tensor(allr, mine[None])
         n = allr[:, -1:]                                   # [w, 1]
         m, v = allr[:, :D], allr[:, D:2 * D]
         n_g = n.sum()
@@ -249,10 +249,9 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
                                   **self.time_pairs_config)
         self.pred_pairs = pairs.to(torch.long).to(self.device)
         # env shards of one job use the SAME segments: rank 0's draw
-        import torch.distributed as dist
-        from ..dist import active
+        from ..dist import active, broadcast
         if active():
-            dist.broadcast(self.pred_pairs, src=0)
+            broadcast(self.pred_pairs, src=0)
         return self.pred_pairs
 
     @staticmethod
@@ -299,20 +298,35 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
             # only updated AND applied during training: evaluation feeds the
             # critic raw states (temporal_correlated_sampler.py:244-249)
             norm = self.norm_step_obs and training
-            if norm:
+            fused_env = getattr(envs, "fused_obs_moments", False)
+            if norm and fused_env:
                 # the env kernel writes the [N, T+1, D] buffer (initial state
                 # in row 0) once and sums the column moments in the same pass
                 next_state, ep_reward, _, infos = envs.step(
                     actions, obs_shift=self.obs_rms.mean, want_moments=True)
             else:
                 next_state, ep_reward, _, infos = envs.step(actions)
-            step_states = infos["step_states_full"]
-            if norm:
+            if "step_states_full" in infos:
+                step_states = infos["step_states_full"]
+                own_buffer = fused_env
+            else:
+                # an env that speaks the reference protocol only: step_states
+                # [N, T, D], the initial state prepended here
+                # (temporal_correlated_sampler.py:233-240)
+                step_states = torch.cat(
+                    [init_state[:, None].to(self.dtype),
+                     infos["step_states"].to(self.dtype)], dim=1)
+                own_buffer = True
+            if norm and fused_env:
                 self.obs_rms.update_from_partials(
                     infos["obs_moment_partials"],
                     rows=step_states.shape[0] * step_states.shape[1])
                 norm_states = self.apply_normalization(
                     step_states, self.obs_rms, inplace=True)
+            elif norm:
+                self.obs_rms.update(step_states.reshape(-1, dim_obs))
+                norm_states = self.apply_normalization(
+                    step_states, self.obs_rms, inplace=own_buffer)
             else:
                 norm_states = step_states
             values = critic.critic(

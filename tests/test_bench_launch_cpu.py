@@ -25,13 +25,21 @@ def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
     seen = {}
     record = {"metric": "env-steps/sec", "value": 1.0, "n_gpus": 4}
 
-    def fake_run(cmd, env=None, stdout=None):
-        seen["cmd"], seen["env"] = cmd, env
-        out = "banner from a library\n" + json.dumps(record) + "\n"
-        return types.SimpleNamespace(returncode=0, stdout=out.encode())
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    class FakePopen:
+        def __init__(self, cmd, env=None, stdout=None, start_new_session=False):
+            seen["cmd"], seen["env"] = cmd, env
+            seen["own_session"] = start_new_session
+            self.returncode, self.pid = 0, 0
+
+        def communicate(self, timeout=None):
+            seen["timeout"] = timeout
+            out = "banner from a library\n" + json.dumps(record) + "\n"
+            return out.encode(), None
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
     args = types.SimpleNamespace(gpus=4, steps=3, warmup=1,
-                                 no_cpu_baseline=True, with_split_f16=False)
+                                 no_cpu_baseline=True, with_split_f16=False,
+                                 no_configs=False, scaling="weak",
+                                 launch_timeout=77.0)
     assert bench.self_launch(args) == 0
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
@@ -43,6 +51,7 @@ def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
     assert cmd[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1",
                                 "--no-cpu-baseline"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["own_session"] and seen["timeout"] == 77.0
     out = capsys.readouterr()
     assert [json.loads(ln) for ln in out.out.splitlines()] == [record]
     assert "banner" in out.err
@@ -50,11 +59,54 @@ def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
 
 def test_self_launch_reports_a_failed_child(monkeypatch):
     bench = _bench()
-    monkeypatch.setattr(subprocess, "run", lambda *a, **k:
-                        types.SimpleNamespace(returncode=3, stdout=b""))
+
+    class FakePopen:
+        returncode, pid = 3, 0
+
+        def __init__(self, *a, **k):
+            pass
+
+        def communicate(self, timeout=None):
+            return b"", None
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
     args = types.SimpleNamespace(gpus=2, steps=1, warmup=0,
                                  no_cpu_baseline=False, with_split_f16=True)
     assert bench.self_launch(args) == 3
+
+
+def test_self_launch_kills_a_hung_child_tree(tmp_path, monkeypatch):
+    """A child that never finishes (a hung collective) is killed together with
+    its own children after --launch-timeout and the launcher exits 124 -- no
+    re-exec, no wait until the driver's limit."""
+    import time
+    bench = _bench()
+    pidfile = tmp_path / "grandchild.pid"
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import subprocess, sys, time\n"
+        "p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+        "open(%r, 'w').write(str(p.pid))\n"
+        "time.sleep(600)\n" % str(pidfile))
+    real_popen = subprocess.Popen
+
+    def popen(cmd, **kw):                   # the launcher command -> the hanging script
+        return real_popen([sys.executable, str(script)], **kw)
+    monkeypatch.setattr(subprocess, "Popen", popen)
+    args = types.SimpleNamespace(gpus=2, steps=1, warmup=0,
+                                 no_cpu_baseline=True, with_split_f16=False,
+                                 launch_timeout=3.0)
+    t = time.time()
+    assert bench.self_launch(args) == 124
+    assert time.time() - t < 30
+    pid = int(pidfile.read_text())
+    for _ in range(50):                     # the grandchild is gone too
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("grandchild %d survived" % pid)
 
 
 def test_plain_shell_multi_gpu_invocation_never_touches_the_gpu():

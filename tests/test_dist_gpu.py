@@ -255,3 +255,92 @@ def test_sharded_equals_single_process(kind, overlap):
     # pure summation noise moves by +-lr either way, hence the absolute term
     # 2 iterations x 3 epochs x lr 3e-4 would allow; observed: ~1e-6)
     np.testing.assert_allclose(w0, ws, rtol=2e-3, atol=2e-5)
+
+
+def _rccl_one_rank_worker(port, q):
+    """A ONE-rank RCCL world with TCE_FORCE_DIST=1: the sharded code path --
+    both communicators, every all-reduce / all-gather / broadcast -- through
+    the nccl backend on the one GPU of the box."""
+    sys.path.insert(0, REPO)
+    os.environ["TCE_FORCE_DIST"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=120),
+                            device_id=torch.device("cuda", 0))
+    from tce_rl_amd import dist as tdist
+    from tce_rl_amd.config import bbrl_config, tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    out = {}
+    for name, cfg in (("tce", tce_config("metaworld", num_env=64, num_basis=5,
+                                         epochs=3, evaluation_interval=0)),
+                      ("bbrl", bbrl_config(num_env=64, epochs=3))):
+        torch.manual_seed(3)
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        assert exp.agent.dist.active and exp.agent.dist.world == 1
+        exp.agent.step()
+        tdist.reset_stats()
+        res = exp.agent.step()
+        flat = torch.cat([p.detach().reshape(-1).cpu() for p in
+                          exp.agent.policy.parameters +
+                          exp.agent.critic.parameters])
+        out[name] = (dict(tdist.STATS), flat.numpy(),
+                     float(res["critic_loss_mean"]), dist.get_backend())
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _plain_worker(q):
+    sys.path.insert(0, REPO)
+    torch.cuda.set_device(0)
+    from tce_rl_amd.config import bbrl_config, tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    out = {}
+    for name, cfg in (("tce", tce_config("metaworld", num_env=64, num_basis=5,
+                                         epochs=3, evaluation_interval=0)),
+                      ("bbrl", bbrl_config(num_env=64, epochs=3))):
+        torch.manual_seed(3)
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        exp.agent.step()
+        exp.agent.step()
+        flat = torch.cat([p.detach().reshape(-1).cpu() for p in
+                          exp.agent.policy.parameters +
+                          exp.agent.critic.parameters])
+        out[name] = flat.numpy()
+    q.put(out)
+
+
+def test_sharded_path_through_a_one_rank_rccl_world():
+    """the nccl-backend code path (communicator creation,
+    the second communicator of the policy stream, gradient all-reduces,
+    statistics gathers, pair broadcast) runs in the GPU test tier, and ends
+    where the un-sharded process ends (one rank: the collectives are
+    identities; the sharded path only un-fuses Adam)."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    p = ctx.Process(target=_plain_worker, args=(q,))
+    p.start()
+    ref = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for name in ("tce", "bbrl"):
+        stats, flat, loss, backend = got[name]
+        assert backend == "nccl"
+        # 3 + 3 gradient all-reduces per step at least, plus statistics
+        assert stats["collectives"] >= 6 and stats["bytes"] > 6 * 4 * 1000
+        assert np.isfinite(flat).all() and np.isfinite(loss)
+        np.testing.assert_allclose(flat, ref[name], rtol=2e-4, atol=2e-6)

@@ -19,6 +19,10 @@ CASES = {
     "table_tennis": ("table_tennis", 7, 21, 350, 0.008),
     "hopper": ("hopper", 3, 17, 250, 0.008),
     "push_odd_obs": ("push", 7, 20, 100, 0.02),       # D = 35: the 4-byte store path
+    # T * 2 dof = 2 mod 4: the desired trajectory ends in a half 16-byte chunk
+    "push_odd_T": ("push", 7, 21, 99, 0.02),
+    "hopper_odd_T": ("hopper", 3, 17, 251, 0.008),
+    "push_short_odd_T": ("push", 5, 21, 17, 0.02),
 }
 
 
@@ -151,3 +155,62 @@ def test_sampler_uses_the_fused_moments(monkeypatch):
                                orig(x, mean, var, 1e-8), rtol=1e-5, atol=1e-5)
     assert ds["step_states"].shape == (24, 350, D)
     assert ds["step_values"].shape == (24, 351)
+
+
+class _ReferenceProtocolEnv:
+    """An env that speaks only what the reference's sampler relies on
+    (temporal_correlated_sampler.py:226-303): ``step(actions)`` -> 4-tuple with
+    ``infos["step_states"]`` [N, T, D]; no fused moments, no whole buffer."""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def __getattr__(self, name):
+        if name == "fused_obs_moments":
+            raise AttributeError(name)
+        return getattr(self._inner, name)
+
+    def reset(self):
+        return self._inner.reset()
+
+    def step(self, actions):
+        nxt, rew, done, infos = self._inner.step(actions)
+        infos = {k: v for k, v in infos.items()
+                 if k not in ("step_states_full", "obs_moment_partials")}
+        infos["step_states"] = infos["step_states"].clone()
+        return nxt, rew, done, infos
+
+
+def test_sampler_accepts_an_env_without_the_fused_capability():
+    """an env following the reference protocol (step(actions) ->
+    step_states only) goes through cat(init_state, step_states) +
+    obs_rms.update + out-of-place normalisation and yields the same dataset
+    and statistics as the fused route."""
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    out = []
+    for generic in (False, True):
+        cfg = tce_config("box_push", num_env=12, num_basis=3, epochs=1,
+                         evaluation_interval=0)
+        torch.manual_seed(5)
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        sampler, agent = exp.sampler, exp.agent
+        if generic:
+            sampler.train_envs = _ReferenceProtocolEnv(sampler.train_envs)
+        eps = torch.randn(12, agent.policy.dim_out,
+                          generator=torch.Generator().manual_seed(1)).cuda()
+        sample = agent.policy.sample
+        agent.policy.sample = lambda **kw: sample(**kw, eps=eps)
+        torch.manual_seed(6)
+        ds, n = sampler.run(training=True, policy=agent.policy,
+                            critic=agent.critic)
+        out.append((ds, n, sampler.obs_rms))
+    (a, na, ra), (b, nb, rb) = out
+    assert na == nb == 12 * 100
+    assert rb.count == pytest.approx(ra.count)
+    torch.testing.assert_close(rb.mean, ra.mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rb.var, ra.var, rtol=1e-5, atol=1e-6)
+    for k in ("step_states", "step_values", "step_rewards", "step_actions",
+              "segment_log_prob_estimate"):
+        torch.testing.assert_close(b[k], a[k], rtol=2e-5, atol=2e-5)
