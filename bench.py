@@ -385,7 +385,8 @@ def run_config(name, spec, steps, warmup):
     of its dominant kernel from the device time (HIP events on the critic's
     stream) of the critic epochs INSIDE those steps."""
     agent = build_config_agent(spec)
-    T = agent.sampler.num_times
+    T = getattr(agent.sampler, "num_times", None) or \
+        agent.sampler.train_envs.num_times
     N = spec["num_env"]
     for _ in range(warmup):
         agent.step()

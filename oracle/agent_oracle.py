@@ -18,10 +18,18 @@ from .prodmp_oracle import ProDMPOracle, pair_log_prob
 
 
 class OracleTCE:
-    def __init__(self, cfg, num_env, seed=0):
+    def __init__(self, cfg, num_env, seed=0, total_iterations=7600):
         """cfg: the ``params`` dict of tce_rl_amd.config.tce_config (same
-        structure as the reference YAML)."""
+        structure as the reference YAML).  Every agent / policy switch of the
+        reference is honoured: ``clip_critic`` / ``clip_advantages`` /
+        ``clip_grad_norm``, the three ``segment_advantage`` modes,
+        ``use_gae``, ``num_minibatchs`` (numpy's global generator, as
+        util_data_structure.py:378-391), ``entropy_penalty_coef``,
+        ``set_variance``, weight decay, the LinearLR schedules, and the
+        ``std_only`` / ``contextual`` covariance heads
+        (abstract_policy.py:65-187)."""
         torch.manual_seed(seed)
+        self.total_iterations = total_iterations
         self.cfg = cfg
         a = cfg["agent"]["args"]
         mpa = dict(cfg["mp"]["args"])
@@ -46,11 +54,27 @@ class OracleTCE:
                        self.p_act)
         self.cnet = mk(ca["hidden"], 1, ca["out_layer_gain"], self.c_act)
         self.min_std = float(pa["min_std"])
-        self.var = torch.nn.Parameter(
-            O.initial_variance_vector(self.K, False, self.dtype))
-        self.p_opt = torch.optim.Adam(list(self.pnet) + [self.var],
-                                      lr=a["lr_policy"])
-        self.c_opt = torch.optim.Adam(list(self.cnet), lr=a["lr_critic"])
+        vna = dict(pa["variance_net_args"])
+        self.std_only = bool(vna.pop("std_only", False))
+        self.contextual = bool(vna.pop("contextual", False))
+        K = self.K
+        n_var = K if self.std_only else K + K * (K - 1) // 2
+        if self.contextual:        # a second MLP (abstract_policy.py:98-109)
+            self.vnet = mk(vna, n_var, pa["out_layer_gain"], self.p_act)
+            self.var = None
+            var_params = list(self.vnet)
+        else:
+            self.vnet = None
+            self.var = torch.nn.Parameter(
+                O.initial_variance_vector(K, self.std_only, self.dtype))
+            var_params = [self.var]
+        self.var_params = var_params
+        self.p_opt = torch.optim.Adam(
+            list(self.pnet) + var_params, lr=a["lr_policy"],
+            weight_decay=float(a.get("wd_policy", 0.0)))
+        self.c_opt = torch.optim.Adam(
+            list(self.cnet), lr=a["lr_critic"],
+            weight_decay=float(a.get("wd_critic", 0.0)))
         self.rms = O.RunningMeanStd((self.D,), self.dtype)
         self.proj = cfg["projection"]["args"]
         self.initial_entropy = None
@@ -67,8 +91,12 @@ class OracleTCE:
 
     def _policy(self, obs):
         mean = self._mlp(self.pnet, obs, self.p_act)
-        L = O.vector_to_cholesky(self.var[None], self.K, self.min_std,
-                                 False).expand(obs.shape[0], -1, -1)
+        if self.contextual:
+            vec = self._mlp(self.vnet, obs, self.p_act)
+            L = O.vector_to_cholesky(vec, self.K, self.min_std, self.std_only)
+        else:
+            L = O.vector_to_cholesky(self.var[None], self.K, self.min_std,
+                                     self.std_only).expand(obs.shape[0], -1, -1)
         return mean, L
 
     def _reset(self):
@@ -162,36 +190,81 @@ class OracleTCE:
                          step_advantages=adv, step_returns=ret,
                          segment_advantage=seg_adv, pred_pairs=pairs,
                          segment_params_mean=mean_old, step_states=nstates)
-        # ---- critic epochs (full batch, num_minibatchs = 1)
+        # ---- critic epochs (temporal_correlated_agent.py:323-379)
+        import numpy as np
         cs = nstates[:, :-1, :-D2].reshape(N * T, -1)
         cr, cv = ret.reshape(-1), values[:, :-1].reshape(-1)
+        clip_gn = float(a.get("clip_grad_norm", 0.0))
+        nmb = int(a.get("num_minibatchs", 1))
         for _ in range(a["epochs_critic"]):
-            v = self._mlp(self.cnet, cs, self.c_act).squeeze(-1)
-            loss = O.value_loss(v, cr, cv, a["clip_critic"])
-            self.c_opt.zero_grad(set_to_none=True)
-            loss.backward()
-            self.c_opt.step()
+            if nmb == 1:        # the permutation does not change a full-batch mean
+                splits = [None]
+            else:               # generate_minibatches: numpy's global generator
+                idx = np.arange(N * T)
+                np.random.shuffle(idx)
+                splits = [torch.as_tensor(x) for x in np.array_split(idx, nmb)]
+            for sel in splits:
+                xs, rs, vs = (cs, cr, cv) if sel is None else \
+                    (cs[sel], cr[sel], cv[sel])
+                v = self._mlp(self.cnet, xs, self.c_act).squeeze(-1)
+                loss = O.value_loss(v, rs, vs, a["clip_critic"])
+                self.c_opt.zero_grad(set_to_none=True)
+                loss.backward()
+                O.grad_norm_clip(clip_gn, [q.grad for q in self.cnet])
+                self.c_opt.step()
         # ---- policy epochs
         if self.initial_entropy is None:
             self.initial_entropy = KO.entropy(L_old).mean()
         p = self.proj
         beta = KO.entropy_schedule(p["entropy_schedule"], self.initial_entropy,
                                    p["target_entropy"], p["temperature"],
-                                   self.it, 7600, self.K)
-        for _ in range(a["epochs_policy"]):
+                                   self.it, self.total_iterations, self.K)
+        ent_coef = float(a.get("entropy_penalty_coef", 0.0))
+        set_var = bool(a.get("set_variance", False))
+        # get_trust_region_loss(..., set_variance): the covariance part is
+        # dropped when the variance is SET from the projection afterwards
+        include_cov = self.contextual or not set_var
+        pparams = list(self.pnet) + self.var_params
+
+        def project():
             mean_new, L_new = self._policy(s0[:, :-D2])
             pm, pL = KO.project(mean_new, L_new, mean_old, L_old,
                                 p["mean_bound"], p["cov_bound"], beta,
-                                contextual_std=False)
+                                contextual_std=self.contextual,
+                                entropy_eq=bool(p.get("entropy_eq", False)),
+                                entropy_first=bool(p.get("entropy_first",
+                                                         False)))
+            return mean_new, L_new, pm, pL
+        for _ in range(a["epochs_policy"]):
+            mean_new, L_new, pm, pL = project()
             lp = pair_log_prob(self.mp, actions, pm, pL, times, t0, y0, v0,
                                pairs)
             s_loss, _ = O.surrogate_loss(seg_adv, lp, lp_old)
+            e_loss = -ent_coef * KO.entropy(pL).mean()     # :741-745
             tr = KO.trust_region_loss(mean_new, L_new, pm, pL,
-                                      p["trust_region_coeff"], True)
-            total = s_loss + tr
+                                      p["trust_region_coeff"], include_cov)
+            total = s_loss + e_loss + tr
             self.p_opt.zero_grad(set_to_none=True)
             total.backward()
+            for q in pparams:              # a parameter the loss does not reach
+                if q.grad is None:
+                    q.grad = torch.zeros_like(q)
+            O.grad_norm_clip(clip_gn, [q.grad for q in pparams])
             self.p_opt.step()
+        if set_var and not self.contextual:                 # :626-637
+            with torch.no_grad():
+                _, _, _, pL = project()
+                self.var.copy_(O.cholesky_to_vector(pL[:1], self.min_std,
+                                                    self.std_only)[0])
+        # LinearLR(1 -> 0.01, total_iterations), stepped once per agent.step()
+        # (abstract_agent.py:91-96, temporal_correlated_agent.py:63-70)
+        for opt, base, on in ((self.c_opt, a["lr_critic"],
+                               a.get("schedule_lr_critic", False)),
+                              (self.p_opt, a["lr_policy"],
+                               a.get("schedule_lr_policy", False))):
+            if on:
+                for g in opt.param_groups:
+                    g["lr"] = O.linear_lr(base, self.it, self.total_iterations)
         return N * T
 
 
