@@ -360,6 +360,19 @@ int tce_kl_shared_f64(const double* mean_new, const double* mean_old, const doub
                       int K, double tr_coeff, int tr_include_cov, double* out16,
                       double* grad_mean, double* grad_L, double* ws, void* stream);
 
+/* The K x K half of tce_kl_shared alone: the caller supplies the sums over
+ * the envs of the three squared Mahalanobis terms |L_old^-1 (new - old)|^2,
+ * |L_proj^-1 (new - proj)|^2, |L_old^-1 (proj - old)|^2 (partials: double
+ * [nparts][3], added in order). */
+int tce_kl_shared_mat_f32(const float* L_new, const float* L_old, const float* L_proj,
+                          int64_t N, int K, float tr_coeff, int tr_include_cov,
+                          const double* partials, int nparts, float* out16, float* grad_L,
+                          void* stream);
+int tce_kl_shared_mat_f64(const double* L_new, const double* L_old, const double* L_proj,
+                          int64_t N, int K, double tr_coeff, int tr_include_cov,
+                          const double* partials, int nparts, double* out16, double* grad_L,
+                          void* stream);
+
 /* The whole objective of one TCE policy epoch and its gradient in ONE call
  * (shared covariance, KL projection; mprl/rl/agent/temporal_correlated_agent.py:
  * 523-612): mean projection -> covariance projection -> pair log-prob ->
@@ -597,6 +610,65 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
                          int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                          float* adam_state, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float adam_step, void* stream);
+
+/* ---- small two-hidden-layer networks (black-box agent) ----------------------
+ * D_in <= 64 -> H -> H -> D_out (H in {32, 64}, D_out <= 64), fp32, torch
+ * Linear layout, parameters FLAT in the order W1 [H][D_in] | b1 | W2 [H][H] |
+ * b2 | W3 [D_out][H] | b3 (the order of MLP.parameters(),
+ * mprl/util/util_nn.py:75-160): the networks of
+ * mprl/config/metaworld/bbrl/entire/shared.yaml:61-91.  act: 0 tanh, 1 relu,
+ * 2 leaky_relu, 3 softplus (mprl/util/util_nn.py:16-25).  head: 0 forward,
+ * 1 value loss, 2 black-box policy objective (what must fit the LDS).
+ * ws: ZEROED ONCE by the caller, float [tce_smlp_ws_len(N, din, H, dout)]
+ * (gradient slabs + ticket, re-armed by every launch).
+ *
+ * tce_smlp_forward: out [N][dout] = MLP(x) (MLP.forward, util_nn.py:225-246).
+ *
+ * tce_smlp_critic_epochs: `epochs` full-batch critic epochs of
+ * BlackBoxAgent.update_critic (mprl/rl/agent/black_box_agent.py:105-157), ONE
+ * launch each: forward, value loss (clip_critic > 0: the clipped form of
+ * :391-419), backward, gradient into `grad` [P], then -- do_adam -- grad-norm
+ * clip (mprl/util/util_numerical.py:244-275) and the Adam step of
+ * torch.optim.Adam(lr, weight_decay) (mprl/rl/agent/abstract_agent.py:62-82)
+ * on param / m / v [P] with opt_state = {step, |g|, |g| clipped, factor} as in
+ * tce_adam_flat.  do_adam == 0 (env shards: the caller all-reduces `grad`
+ * first) requires epochs == 1.  rec [epochs][3] = {loss, |g|, |g| clipped}.
+ *
+ * tce_bb_policy_epochs: `epochs` policy epochs of BlackBoxAgent.update_policy
+ * (black_box_agent.py:159-389) for a shared (non-contextual) covariance, six
+ * launches each: Cholesky head (tce_chol_build_fwd on the variance vector
+ * param + P, nvec entries), covariance projection, ONE row kernel (mean net
+ * forward, mean projection, log-prob of `actions` under the projected
+ * Gaussian, surrogate, trust region loss, their gradients, mean net backward),
+ * tce_kl_shared_mat, tce_kl_cov_proj_bwd, finish (Cholesky head backward into
+ * grad [P, P + nvec), clip, Adam on all P + nvec entries, record).  rec
+ * [epochs][7] = {surrogate, entropy loss, trust region loss, total, entropy,
+ * |g|, |g| clipped}.  mats: float [tce_bb_policy_mats_len(K)], holds after
+ * the call L_new | L_proj | (scratch) in [K,K] blocks of pitch (K*K rounded up
+ * to 4); mean_new_out / proj_mean_out (nullable) [N,K]: the last epoch's means. */
+int tce_smlp_supported(int din, int H, int dout, int head);
+int64_t tce_smlp_num_params(int din, int H, int dout);
+int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout);
+int64_t tce_bb_policy_mats_len(int K);
+int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, int H, int dout,
+                         int act, const float* param, float* out, void* stream);
+int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* returns,
+                               const float* old_values, int64_t N, int din, int H, int act,
+                               float clip_critic, float* param, float* grad, float* m, float* v,
+                               float* opt_state, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float clip_grad, float grad_scale, int do_adam,
+                               int epochs, float* ws, float* rec, void* stream);
+int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* actions,
+                             const float* logp_old, const float* adv, const float* mean_old,
+                             const float* L_old, int64_t N, int din, int H, int K, int act,
+                             int nvec, float min_std, float eps_mean, double eps_cov,
+                             const float* beta, int entropy_eq, float tr_coeff,
+                             int tr_include_cov, float ent_coef, float* param, float* grad,
+                             float* m, float* v, float* opt_state, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float clip_grad,
+                             float grad_scale, int do_adam, int epochs, double* proj_ctx,
+                             float* ws, float* mats, float* rec, float* mean_new_out,
+                             float* proj_mean_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -765,6 +765,29 @@ int tce_out_layer_grad_f64(const double* grad_out, const double* hidden, double*
   return out_layer_grad<double>(grad_out, hidden, grad_W, grad_b, ws, N, K, H,
                                 (hipStream_t)stream);
 }
+// The K x K half of tce_kl_shared alone: the caller supplies the sums of the
+// three Mahalanobis terms (partials: double [nparts][3], added in order).
+#define DEFINE_KL_SHARED_MAT(SFX, REAL)                                                     \
+  int tce_kl_shared_mat_##SFX(const REAL* L_new, const REAL* L_old, const REAL* L_proj,      \
+                              int64_t N, int K, REAL tr_coeff, int tr_include_cov,          \
+                              const double* partials, int nparts, REAL* out16,              \
+                              REAL* grad_L, void* stream) {                                 \
+    TCE_CHECK_ARG(L_new && L_old && L_proj && partials && out16 && N > 0 && K > 0 &&        \
+                      K <= 64 && nparts > 0,                                                \
+                  "kl_shared_mat: bad arguments (K <= 64)");                                \
+    const int par = (size_t)6 * K * sm_pitch(K) * sizeof(double) <= 150 * 1024;             \
+    const size_t lds_m = (size_t)(par ? 6 : 4) * K * sm_pitch(K) * sizeof(double);          \
+    if (lds_m > 48 * 1024)                                                                  \
+      tce_lds_limit(reinterpret_cast<const void*>(kl_shared_mat_kernel<REAL>), lds_m);      \
+    hipLaunchKernelGGL(kl_shared_mat_kernel<REAL>, dim3(1), dim3(SM_BT), lds_m,             \
+                       (hipStream_t)stream, L_new, L_old, L_proj, N, K, tr_coeff,           \
+                       tr_include_cov, partials, nparts, out16, grad_L, par);               \
+    TCE_LAUNCH_CHECK();                                                                     \
+    return 0;                                                                               \
+  }
+DEFINE_KL_SHARED_MAT(f32, float)
+DEFINE_KL_SHARED_MAT(f64, double)
+
 int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
                           float ent_coef, float* row19, void* stream) {
   TCE_CHECK_ARG(sur2 && out16 && norms2 && row19, "policy_record: null buffer");

@@ -1,0 +1,957 @@
+// Small two-hidden-layer networks (D_in <= 64 -> H -> H -> D_out, H in {32, 64},
+// fp32) of the black-box agent, one workgroup per 64 rows:
+//
+//   tce_smlp_forward_f32        values / means of a rollout
+//                               (mprl/util/util_nn.py:225-246)
+//   tce_smlp_critic_epochs_f32  E full-batch critic epochs, ONE launch each:
+//                               forward + (clipped) value loss + backward +
+//                               gradient reduction + grad-norm clip + Adam
+//                               (mprl/rl/agent/black_box_agent.py:105-157,
+//                               value_loss :391-419, grad_norm_clip
+//                               mprl/util/util_numerical.py:244-275, Adam
+//                               mprl/rl/agent/abstract_agent.py:62-82)
+//   tce_bb_policy_epochs_f32    E policy epochs of the black-box agent with a
+//                               shared (non-contextual) covariance, SIX launches
+//                               each (black_box_agent.py:159-389): Cholesky head,
+//                               covariance projection, the row kernel below,
+//                               K x K KL parts, covariance projection backward,
+//                               finish (Cholesky head backward + clip + Adam +
+//                               record row).
+//
+// Row kernel.  Lane = row, the four waves of the workgroup split the hidden
+// units (wave w owns units [w H/4, (w+1) H/4)): a layer is, per input unit, one
+// broadcast read of the weights of the wave's output units from the LDS image
+// and H/4 FMAs; activations pass between the layers through row-major LDS
+// tiles (pitch 4 x odd: a lane's 16-byte pieces are conflict free).  These
+// nets are far too small for the matrix cores to matter (56 MFLOP per epoch at
+// 4096 rows; the exact-fp32 MFMA rate equals the packed VALU rate): what counts
+// is the length of the dependent chain, so the whole epoch is one launch.
+// Between forward and backward wave 0 runs the "head" per row: the value loss,
+// or -- policy -- mean projection, log-prob of the sampled parameters under the
+// projected Gaussian, surrogate gradient, trust-region gradient and the way
+// back through the mean projection (triangular solves against the K x K
+// factors held in LDS, vectors in [k][lane] layout).  Weight gradients are
+// sums of outer products over the 64 rows: thread = 4 x 4 block of a weight
+// matrix, operands read as 16-byte pieces of the row-major tiles.  Every
+// workgroup writes its gradient slab; the workgroup that takes the last ticket
+// adds the slabs in a fixed order (deterministic), and -- critic -- applies the
+// clip factor and the Adam step at once.
+#include "mlp_shared.h"
+#include "../../include/tce_hip.h"
+
+namespace {
+
+constexpr int SR = 64;                  // rows per workgroup
+constexpr int SBT = 256;                // threads per workgroup
+constexpr int SNW = SBT / 64;
+constexpr float S_HALF_LOG_2PI = 0.9189385332046727f;
+constexpr size_t S_LDS_MAX = 160 * 1024;
+constexpr int S_MAX_GRID = 1024;
+
+__host__ __device__ inline int s_up4(int n) { return (n + 3) & ~3; }
+// pitch (floats) of a row-major [64][w] tile: 4 x odd, so that the 16-byte
+// pieces of 16 consecutive rows fall into 16 different bank groups
+__host__ __device__ inline int s_pitch(int w) { return 4 * (((w + 3) / 4) | 1); }
+__host__ __device__ inline int s_nparams(int din, int H, int dout) {
+  return H * din + H + H * H + H + dout * H + dout;
+}
+
+enum { HEAD_NONE = 0, HEAD_VALUE = 1, HEAD_BB_POLICY = 2 };
+
+// LDS map (offsets in floats, all multiples of 4)
+struct SLds {
+  int w1t, w2, w2t, w3, b1, b2, b3;      // weight images
+  int xs, h1s, h2s, d1s, d2s, g3s;       // row-major tiles [64][pitch]
+  int ys, gus;                           // policy: y and g u (row-major [64][gp])
+  int vec;                               // policy: 6 vectors [doutp][64]; value head: 2 x [64]
+  int lo, lp, rdo, rdp;                  // policy: L_old, L_proj [K][K], 1 / diagonals
+  int red;                               // scratch
+  int total;
+  int xp, hp, gp, dinp, doutp;
+};
+__host__ __device__ inline SLds s_lds(int din, int H, int dout, int head) {
+  SLds L;
+  L.dinp = s_up4(din);
+  L.doutp = s_up4(dout);
+  L.xp = s_pitch(din);
+  L.hp = s_pitch(H);
+  L.gp = s_pitch(dout);
+  int o = 0;
+  L.w1t = o; o += L.dinp * H;
+  L.w2 = o; o += H * H;
+  L.w2t = o; o += H * H;
+  L.w3 = o; o += L.doutp * H;
+  L.b1 = o; o += H;
+  L.b2 = o; o += H;
+  L.b3 = o; o += L.doutp;
+  L.xs = o; o += SR * L.xp;
+  L.h1s = o; o += SR * L.hp;
+  L.h2s = o; o += SR * L.hp;
+  const bool bwd = head != HEAD_NONE;
+  L.d1s = o; o += bwd ? SR * L.hp : 0;
+  L.d2s = o; o += bwd ? SR * L.hp : 0;
+  L.g3s = o; o += bwd ? SR * L.gp : 0;
+  const bool pol = head == HEAD_BB_POLICY;
+  L.ys = o; o += pol ? SR * L.gp : 0;
+  L.gus = o; o += pol ? SR * L.gp : 0;
+  L.vec = o; o += pol ? 6 * L.doutp * SR : 2 * SR;
+  const int kk = s_up4(dout * dout);
+  L.lo = o; o += pol ? kk : 0;
+  L.lp = o; o += pol ? kk : 0;
+  L.rdo = o; o += pol ? L.doutp : 0;
+  L.rdp = o; o += pol ? L.doutp : 0;
+  L.red = o; o += 16;
+  L.total = o;
+  return L;
+}
+
+struct SNet {
+  const float* x;            // rows: x + r * x_stride
+  int64_t x_stride;
+  int64_t N;
+  int din, dout;
+  const float* param;        // flat: W1 [H][din] | b1 | W2 [H][H] | b2 | W3 [dout][H] | b3
+};
+
+struct SValueHead {
+  const float* ret;
+  const float* old_v;        // nullable unless clip > 0
+  float clip;
+};
+
+struct SPolicyHead {
+  const float *actions, *logp_old, *adv, *mean_old;   // [N,K], [N], [N], [N,K]
+  const float *L_old, *L_proj;                        // [K,K] each (shared)
+  float eps_mean, tr_coeff, ent_coef;
+  float *mean_out, *pmean_out;                        // nullable [N,K]
+};
+
+struct SReduce {
+  float* slabs;              // [grid][PS]
+  double* dpart;             // [grid][8]
+  unsigned* ticket;
+  int PS;                    // slab pitch
+  int P;                     // network parameters
+  float* grad;               // flat gradient [>= P]
+  // value head: Adam fused into the last workgroup
+  float *param, *m, *v, *state;
+  float lr, b1, b2, eps, wd, clip_grad, gscale;
+  int do_adam;
+  float* rec;                // value: {loss, |g|, |g| clipped}
+  // policy head outputs of the last workgroup
+  float* g_pL;               // [K,K]
+  float* sur2;               // {surrogate, mean ratio}
+  double* dsum;              // {m1, m2, m3}: sums of the three Mahalanobis terms
+};
+
+// ---------------------------------------------------------------------------
+template <int H>
+__device__ inline void s_load_weights(const SLds& L, float* S, const SNet& n) {
+  const float* W1 = n.param;
+  const float* B1 = W1 + H * n.din;
+  const float* W2 = B1 + H;
+  const float* B2 = W2 + H * H;
+  const float* W3 = B2 + H;
+  const float* B3 = W3 + n.dout * H;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < L.dinp * H; e += SBT) {
+    const int i = e / H, j = e - i * H;
+    S[L.w1t + e] = i < n.din ? W1[j * n.din + i] : 0.f;
+  }
+  for (int e = tid; e < H * H; e += SBT) {
+    const float w = W2[e];
+    const int j = e / H, i = e - j * H;
+    S[L.w2 + e] = w;
+    S[L.w2t + i * H + j] = w;
+  }
+  for (int e = tid; e < L.doutp * H; e += SBT) S[L.w3 + e] = e < n.dout * H ? W3[e] : 0.f;
+  for (int e = tid; e < H; e += SBT) {
+    S[L.b1 + e] = B1[e];
+    S[L.b2 + e] = B2[e];
+  }
+  for (int e = tid; e < L.doutp; e += SBT) S[L.b3 + e] = e < n.dout ? B3[e] : 0.f;
+}
+
+__device__ inline void s_load_x(const SLds& L, float* S, const SNet& n, int64_t r0) {
+  for (int e = threadIdx.x; e < SR * L.dinp; e += SBT) {
+    const int r = e / L.dinp, c = e - r * L.dinp;
+    const int64_t row = r0 + r;
+    float v = 0.f;
+    if (c < n.din && row < n.N) v = n.x[row * n.x_stride + c];
+    S[L.xs + r * L.xp + c] = v;
+  }
+}
+
+// forward of the 64 rows of the tile: h1 / h2 (this wave's H/4 units of its
+// lane's row, after the activation) stay in registers for the backward pass,
+// the output goes to out[o * 64 + lane] (LDS, [dout][64])
+template <int H, int ACT>
+__device__ inline void s_forward(const SLds& L, float* S, int dout, int lane, int wave,
+                                 float (&h1)[H / SNW], float (&h2)[H / SNW], float* out) {
+  constexpr int US = H / SNW;
+  const int u0 = wave * US;
+  float acc[US];
+#pragma unroll
+  for (int u = 0; u < US; ++u) acc[u] = S[L.b1 + u0 + u];
+  for (int i0 = 0; i0 < L.dinp; i0 += 4) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(S + L.xs + lane * L.xp + i0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* wr = S + L.w1t + (i0 + t) * H + u0;
+#pragma unroll
+      for (int u = 0; u < US; u += 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[u + q] += wv[q] * xv[t];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < US; ++u) h1[u] = act_f<ACT>(acc[u]);
+#pragma unroll
+  for (int u = 0; u < US; u += 4)
+    *reinterpret_cast<f32x4*>(S + L.h1s + lane * L.hp + u0 + u) =
+        f32x4{h1[u], h1[u + 1], h1[u + 2], h1[u + 3]};
+  __syncthreads();
+  float hin[H];
+#pragma unroll
+  for (int q = 0; q < H; q += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(S + L.h1s + lane * L.hp + q);
+    hin[q] = t[0]; hin[q + 1] = t[1]; hin[q + 2] = t[2]; hin[q + 3] = t[3];
+  }
+#pragma unroll
+  for (int u = 0; u < US; ++u) acc[u] = S[L.b2 + u0 + u];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float* wr = S + L.w2t + i * H + u0;
+#pragma unroll
+    for (int u = 0; u < US; u += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[u + q] += wv[q] * hin[i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < US; ++u) h2[u] = act_f<ACT>(acc[u]);
+#pragma unroll
+  for (int u = 0; u < US; u += 4)
+    *reinterpret_cast<f32x4*>(S + L.h2s + lane * L.hp + u0 + u) =
+        f32x4{h2[u], h2[u + 1], h2[u + 2], h2[u + 3]};
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < H; q += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(S + L.h2s + lane * L.hp + q);
+    hin[q] = t[0]; hin[q + 1] = t[1]; hin[q + 2] = t[2]; hin[q + 3] = t[3];
+  }
+  for (int o = wave; o < dout; o += SNW) {
+    const float* wr = S + L.w3 + o * H;
+    float p[4] = {S[L.b3 + o], 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < H; j += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[q] += wv[q] * hin[j + q];
+    }
+    out[o * SR + lane] = (p[0] + p[1]) + (p[2] + p[3]);
+  }
+  __syncthreads();
+}
+
+// backward of the tile from g[o * 64 + lane] = dLoss / d out: the dY2 / dY1 tiles
+template <int H, int ACT>
+__device__ inline void s_backward(const SLds& L, float* S, int dout, int lane, int wave,
+                                  const float (&h1)[H / SNW], const float (&h2)[H / SNW],
+                                  const float* g) {
+  constexpr int US = H / SNW;
+  const int u0 = wave * US;
+  float acc[US];
+#pragma unroll
+  for (int u = 0; u < US; ++u) acc[u] = 0.f;
+  for (int o = 0; o < dout; ++o) {
+    const float gv = g[o * SR + lane];
+    const float* wr = S + L.w3 + o * H + u0;
+#pragma unroll
+    for (int u = 0; u < US; u += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[u + q] += wv[q] * gv;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < US; u += 4) {
+    f32x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * act_d<ACT>(h2[u + q]);
+    *reinterpret_cast<f32x4*>(S + L.d2s + lane * L.hp + u0 + u) = t;
+  }
+  __syncthreads();
+  float din_[H];
+#pragma unroll
+  for (int q = 0; q < H; q += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(S + L.d2s + lane * L.hp + q);
+    din_[q] = t[0]; din_[q + 1] = t[1]; din_[q + 2] = t[2]; din_[q + 3] = t[3];
+  }
+#pragma unroll
+  for (int u = 0; u < US; ++u) acc[u] = 0.f;
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const float* wr = S + L.w2 + j * H + u0;
+#pragma unroll
+    for (int u = 0; u < US; u += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[u + q] += wv[q] * din_[j];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < US; u += 4) {
+    f32x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * act_d<ACT>(h1[u + q]);
+    *reinterpret_cast<f32x4*>(S + L.d1s + lane * L.hp + u0 + u) = t;
+  }
+  __syncthreads();
+}
+
+// out[(4 bi + u) * ldo + 4 bj + v] (+)= sum over the 64 rows of A[r][4 bi + u] B[r][4 bj + v]
+// for the 4 x 4 block `blk` of an M x N matrix (A: [64][pa], B: [64][pb])
+__device__ inline void s_outer_block(const float* A, int pa, const float* B, int pb, int M, int N,
+                                     int blk, float* out, bool accumulate) {
+  const int nbj = (N + 3) / 4;
+  const int bi = blk / nbj, bj = blk - bi * nbj;
+  float acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
+  const float* a = A + 4 * bi;
+  const float* b = B + 4 * bj;
+#pragma unroll 4
+  for (int r = 0; r < SR; ++r) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * pa);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + r * pb);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = 4 * bi + u, j = 4 * bj + v;
+      if (i < M && j < N) {
+        float* dst = out + i * N + j;
+        *dst = accumulate ? *dst + acc[u][v] : acc[u][v];
+      }
+    }
+}
+
+// the weight / bias gradients of the tile into `slab` (accumulate: a later
+// tile of the same workgroup adds to it)
+template <int H>
+__device__ inline void s_param_grads(const SLds& L, const float* S, int din, int dout, float* slab,
+                                     bool accumulate) {
+  const int nb1 = (H / 4) * (L.dinp / 4), nb2 = (H / 4) * (H / 4), nb3 = (L.doutp / 4) * (H / 4);
+  float* gW1 = slab;
+  float* gB1 = gW1 + H * din;
+  float* gW2 = gB1 + H;
+  float* gB2 = gW2 + H * H;
+  float* gW3 = gB2 + H;
+  float* gB3 = gW3 + dout * H;
+  for (int t = threadIdx.x; t < nb1 + nb2 + nb3; t += SBT) {
+    if (t < nb1)
+      s_outer_block(S + L.d1s, L.hp, S + L.xs, L.xp, H, din, t, gW1, accumulate);
+    else if (t < nb1 + nb2)
+      s_outer_block(S + L.d2s, L.hp, S + L.h1s, L.hp, H, H, t - nb1, gW2, accumulate);
+    else
+      s_outer_block(S + L.g3s, L.gp, S + L.h2s, L.hp, dout, H, t - nb1 - nb2, gW3, accumulate);
+  }
+  for (int t = threadIdx.x; t < 2 * H + dout; t += SBT) {
+    const float* src;
+    int p;
+    float* dst;
+    if (t < H) { src = S + L.d1s + t; p = L.hp; dst = gB1 + t; }
+    else if (t < 2 * H) { src = S + L.d2s + (t - H); p = L.hp; dst = gB2 + (t - H); }
+    else { src = S + L.g3s + (t - 2 * H); p = L.gp; dst = gB3 + (t - 2 * H); }
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < SR; ++r) s += src[r * p];
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// value head (wave 0): loss and dLoss / dv of the tile's rows
+// (black_box_agent.py:391-419 / temporal_correlated_agent.py:688-716)
+__device__ inline double s_value_head(const SLds& L, float* S, const SValueHead& h, int64_t r0,
+                                      int64_t N, int lane, const float* out, float* g) {
+  const int64_t row = r0 + lane;
+  const bool rok = row < N;
+  const int64_t rc = rok ? row : N - 1;
+  const float v = out[lane], rt = h.ret[rc];
+  const float e = v - rt;
+  float l = e * e, d = 2.f * e;
+  if (h.clip > 0.f) {
+    const float ov = h.old_v[rc];
+    const float dlt = v - ov;
+    const float cl = fminf(fmaxf(dlt, -h.clip), h.clip);
+    const float e2 = ov + cl - rt;
+    if (e2 * e2 > l) { l = e2 * e2; d = (dlt > -h.clip && dlt < h.clip) ? 2.f * e2 : 0.f; }
+  }
+  if (!rok) { l = 0.f; d = 0.f; }
+  const float dv = d / (float)N;
+  g[lane] = dv;
+  S[L.g3s + lane * L.gp] = dv;
+  return wave_sum_f64((double)l);
+}
+
+// policy head of the black-box agent (wave 0), per row: mean projection
+// (third-party KL projection layer, oracle/kl_oracle.py mean_projection),
+// log N(action; proj_mean, L_proj L_proj^T) (black_box_policy.py:95-128),
+// surrogate gradient (black_box_agent.py:421-443), the mean part of the trust
+// region loss and its gradient, and back through the mean projection.
+// vec: MU | MO | AC | Z | Y | W, each [doutp][64].  Returns this wave's sums in
+// `sums`: {sum ratio adv, sum ratio, m1, m2, m3}.
+__device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead& h, int64_t r0,
+                                     int64_t N, int K, int lane, float logdet_p,
+                                     double (&sums)[5]) {
+  const int VS = L.doutp * SR;
+  float* MU = S + L.vec;
+  float* MO = MU + VS;
+  float* AC = MO + VS;
+  float* Z = AC + VS;
+  float* Y = Z + VS;
+  float* W = Y + VS;
+  const float* Lo = S + L.lo;
+  const float* Lp = S + L.lp;
+  const float* rdo = S + L.rdo;
+  const float* rdp = S + L.rdp;
+  const int64_t row = r0 + lane;
+  const bool rok = row < N;
+  const int64_t rc = rok ? row : N - 1;
+  // z = L_old^-1 (mu - mu_old)
+  float quad = 0.f;
+  for (int r = 0; r < K; ++r) {
+    float v = MU[r * SR + lane] - MO[r * SR + lane];
+    for (int k = 0; k < r; ++k) v -= Lo[r * K + k] * Z[k * SR + lane];
+    v *= rdo[r];
+    Z[r * SR + lane] = v;
+    quad += v * v;
+  }
+  const float m = 0.5f * quad;
+  const bool active = m > h.eps_mean;
+  const float sc = active ? sqrtf(m / h.eps_mean) : 1.f;
+  const float om = sc - 1.f;
+  const float den = 1.f + om + 1e-16f;
+  // y = L_proj^-1 (a - proj_mean), proj_mean = (mu + om mu_old) / (1 + om)
+  float quady = 0.f;
+  for (int r = 0; r < K; ++r) {
+    const float mu = MU[r * SR + lane];
+    const float pm = active ? (mu + om * MO[r * SR + lane]) / den : mu;
+    if (h.pmean_out && rok) h.pmean_out[row * K + r] = pm;
+    if (h.mean_out && rok) h.mean_out[row * K + r] = mu;
+    float v = AC[r * SR + lane] - pm;
+    for (int k = 0; k < r; ++k) v -= Lp[r * K + k] * Y[k * SR + lane];
+    v *= rdp[r];
+    Y[r * SR + lane] = v;
+    quady += v * v;
+    // w (below) starts from mu - proj_mean
+    W[r * SR + lane] = mu - pm;
+  }
+  const float logp = -0.5f * quady - logdet_p - S_HALF_LOG_2PI * (float)K;
+  const float ratio = expf(logp - h.logp_old[rc]);
+  const float ra = ratio * h.adv[rc];
+  const float g = rok ? -ra / (float)N : 0.f;          // d surrogate / d logp
+  for (int r = 0; r < K; ++r) S[L.ys + lane * L.gp + r] = Y[r * SR + lane];
+  // u = L_proj^-T y (in place), d logp / d proj_mean = u
+  for (int r = K - 1; r >= 0; --r) {
+    float v = Y[r * SR + lane];
+    for (int k = r + 1; k < K; ++k) v -= Lp[k * K + r] * Y[k * SR + lane];
+    Y[r * SR + lane] = v * rdp[r];
+  }
+  for (int r = 0; r < K; ++r) S[L.gus + lane * L.gp + r] = g * Y[r * SR + lane];
+  // w = L_proj^-1 (mu - proj_mean), q = L_proj^-T w (in place)
+  float maha2 = 0.f;
+  for (int r = 0; r < K; ++r) {
+    float v = W[r * SR + lane];
+    for (int k = 0; k < r; ++k) v -= Lp[r * K + k] * W[k * SR + lane];
+    v *= rdp[r];
+    W[r * SR + lane] = v;
+    maha2 += v * v;
+  }
+  for (int r = K - 1; r >= 0; --r) {
+    float v = W[r * SR + lane];
+    for (int k = r + 1; k < K; ++k) v -= Lp[k * K + r] * W[k * SR + lane];
+    W[r * SR + lane] = v * rdp[r];
+  }
+  // back through the mean projection: t = L_old^-T z (in place)
+  float gd = 0.f;
+  for (int r = 0; r < K; ++r) gd += g * Y[r * SR + lane] * (MU[r * SR + lane] - MO[r * SR + lane]);
+  if (active) {                                          // lanes of inactive rows skip the solve
+    for (int r = K - 1; r >= 0; --r) {
+      float v = Z[r * SR + lane];
+      for (int k = r + 1; k < K; ++k) v -= Lo[k * K + r] * Z[k * SR + lane];
+      Z[r * SR + lane] = v * rdo[r];
+    }
+  }
+  const float coef = active ? gd / (2.f * h.eps_mean * sc * sc * sc) : 0.f;
+  const float trc = rok ? h.tr_coeff / (float)N : 0.f;
+  // total gradient w.r.t. the mean net's output -> AC ([k][64]) and G3S (row-major)
+  for (int r = 0; r < K; ++r) {
+    const float gp = g * Y[r * SR + lane];
+    float gm = active ? gp / sc - coef * Z[r * SR + lane] : gp;
+    gm += trc * W[r * SR + lane];
+    AC[r * SR + lane] = gm;
+    S[L.g3s + lane * L.gp + r] = gm;
+  }
+  const double f = rok ? 1.0 : 0.0;
+  sums[0] = wave_sum_f64(f * (double)ra);
+  sums[1] = wave_sum_f64(f * (double)ratio);
+  sums[2] = wave_sum_f64(f * (double)quad);
+  sums[3] = wave_sum_f64(f * (double)maha2);
+  sums[4] = wave_sum_f64(f * (double)quad / ((double)den * (double)den));
+}
+
+// ---------------------------------------------------------------------------
+template <int H, int ACT>
+__global__ __launch_bounds__(SBT) void smlp_forward_kernel(SNet n, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const SLds L = s_lds(n.din, H, n.dout, HEAD_NONE);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ov = S + L.vec;                 // needs doutp * 64 floats: see s_forward_lds
+  s_load_weights<H>(L, S, n);
+  for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < n.N; r0 += (int64_t)gridDim.x * SR) {
+    __syncthreads();
+    s_load_x(L, S, n, r0);
+    __syncthreads();
+    float h1[H / SNW], h2[H / SNW];
+    s_forward<H, ACT>(L, S, n.dout, lane, wave, h1, h2, ov);
+    for (int e = threadIdx.x; e < SR * n.dout; e += SBT) {
+      const int r = e / n.dout, o = e - r * n.dout;
+      if (r0 + r < n.N) out[(r0 + r) * n.dout + o] = ov[o * SR + r];
+    }
+  }
+}
+// the forward kernel keeps its outputs where the heads keep their vectors
+__host__ __device__ inline int s_forward_lds_floats(int din, int H, int dout) {
+  const SLds L = s_lds(din, H, dout, HEAD_NONE);
+  return L.vec + s_up4(dout) * SR + 16;
+}
+
+template <int H, int ACT, int HEAD>
+__global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, SPolicyHead ph,
+                                                        SReduce rd) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  __shared__ bool last;
+  __shared__ double dred[SNW];
+  const SLds L = s_lds(n.din, H, n.dout, HEAD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = n.dout;
+  s_load_weights<H>(L, S, n);
+  float logdet_p = 0.f;
+  if (HEAD == HEAD_BB_POLICY) {
+    for (int e = tid; e < K * K; e += SBT) {
+      S[L.lo + e] = ph.L_old[e];
+      S[L.lp + e] = ph.L_proj[e];
+    }
+    for (int e = tid; e < K; e += SBT) {
+      S[L.rdo + e] = 1.f / ph.L_old[e * K + e];
+      S[L.rdp + e] = 1.f / ph.L_proj[e * K + e];
+    }
+    logdet_p = wave_sum(lane < K ? logf(ph.L_proj[lane * K + lane]) : 0.f);
+  }
+  float* slab = rd.slabs + (int64_t)blockIdx.x * rd.PS;
+  double acc_d[5] = {0, 0, 0, 0, 0};
+  bool first = true;
+  float* vecs = S + L.vec;
+  for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < n.N; r0 += (int64_t)gridDim.x * SR) {
+    __syncthreads();
+    s_load_x(L, S, n, r0);
+    if (HEAD == HEAD_BB_POLICY) {
+      const int VS = L.doutp * SR;
+      for (int e = tid; e < SR * K; e += SBT) {
+        const int r = e / K, k = e - r * K;
+        const int64_t row = r0 + r < n.N ? r0 + r : n.N - 1;
+        vecs[VS + k * SR + r] = ph.mean_old[row * K + k];
+        vecs[2 * VS + k * SR + r] = ph.actions[row * K + k];
+      }
+    }
+    __syncthreads();
+    float h1[H / SNW], h2[H / SNW];
+    s_forward<H, ACT>(L, S, K, lane, wave, h1, h2, vecs);
+    const float* g;
+    if (HEAD == HEAD_VALUE) {
+      if (wave == 0) acc_d[0] += s_value_head(L, S, vh, r0, n.N, lane, vecs, vecs + SR);
+      g = vecs + SR;
+    } else {
+      if (wave == 0) {
+        double s5[5];
+        s_policy_head(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc_d[i] += s5[i];
+      }
+      g = vecs + 2 * L.doutp * SR;                     // AC slot
+    }
+    __syncthreads();
+    s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g);
+    s_param_grads<H>(L, S, n.din, K, slab, !first);
+    if (HEAD == HEAD_BB_POLICY) {
+      // d logp / d L_proj summed over the rows: sum g u y^T (lower triangle used)
+      float* gpl = slab + rd.P;
+      const int nb = (L.doutp / 4) * (L.doutp / 4);
+      for (int t = tid; t < nb; t += SBT)
+        s_outer_block(S + L.gus, L.gp, S + L.ys, L.gp, K, K, t, gpl, !first);
+    }
+    first = false;
+  }
+  (void)dred;
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) rd.dpart[blockIdx.x * 8 + i] = acc_d[i];
+    __threadfence();
+  }
+  __syncthreads();
+  __threadfence();
+  if (tid == 0) last = atomicAdd(rd.ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // ---- the last workgroup: slabs -> gradient, in slab order
+  const int nblk = gridDim.x;
+  const int tot = HEAD == HEAD_BB_POLICY ? rd.P + K * K : rd.P;
+  float sq = 0.f;
+  for (int p = tid; p < tot; p += SBT) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += __builtin_nontemporal_load(rd.slabs + (int64_t)b * rd.PS + p);
+    if (p < rd.P) {
+      rd.grad[p] = s;
+      sq += s * s;
+    } else {
+      S[p - rd.P] = s;                                  // g_pL, finished below
+    }
+  }
+  double ds[5] = {0, 0, 0, 0, 0};
+  if (tid < 5)
+    for (int b = 0; b < nblk; ++b) ds[0] += __builtin_nontemporal_load(rd.dpart + b * 8 + tid);
+  if (HEAD == HEAD_VALUE) {
+    float* red = S + L.red;
+    sq = block_sum(sq, red);
+    __shared__ float coef_s, step_s;
+    if (tid == 0) {
+      const float before = sqrtf(sq) * rd.gscale;
+      float coef = 1.f;
+      if (rd.clip_grad > 0.f) coef = fminf(rd.clip_grad / (before + 1e-6f), 1.f);
+      const float loss = (float)(ds[0] / (double)n.N);
+      rd.rec[0] = loss;
+      rd.rec[1] = before;
+      rd.rec[2] = before * coef;
+      if (rd.do_adam) {
+        const float step = rd.state[0] + 1.f;
+        rd.state[0] = step;
+        rd.state[1] = before;
+        rd.state[2] = before * coef;
+        rd.state[3] = coef * rd.gscale;
+        step_s = step;
+      }
+      coef_s = coef * rd.gscale;
+    }
+    __syncthreads();
+    if (rd.do_adam) {
+      const float step = step_s, coef = coef_s;
+      const float bc1 = 1.f - powf(rd.b1, step), bc2s = sqrtf(1.f - powf(rd.b2, step));
+      const float step_size = rd.lr / bc1;
+      for (int p = tid; p < rd.P; p += SBT) {
+        float gr = rd.grad[p] * coef;
+        const float w = rd.param[p];
+        if (rd.wd != 0.f) gr += rd.wd * w;
+        const float mi = rd.b1 * rd.m[p] + (1.f - rd.b1) * gr;
+        const float vi = rd.b2 * rd.v[p] + (1.f - rd.b2) * gr * gr;
+        rd.m[p] = mi;
+        rd.v[p] = vi;
+        rd.param[p] = w - step_size * mi / (sqrtf(vi) / bc2s + rd.eps);
+      }
+    }
+  } else {
+    // sum g = -(sum ratio adv) / N: the diagonal terms of d logp / d L_proj and
+    // of the entropy bonus; surrogate and the Mahalanobis sums for the K x K part
+    __shared__ double dsh[5];
+    if (tid < 5) dsh[tid] = ds[0];
+    __syncthreads();
+    const float sum_g = (float)(-dsh[0] / (double)n.N);
+    for (int e = tid; e < K * K; e += SBT) {
+      const int i = e / K, j = e - i * K;
+      float v = 0.f;
+      if (j <= i) {
+        v = S[e];
+        if (i == j) v -= (sum_g + ph.ent_coef) / ph.L_proj[e];
+      }
+      rd.g_pL[e] = v;
+    }
+    if (tid == 0) {
+      rd.sur2[0] = (float)(-dsh[0] / (double)n.N);
+      rd.sur2[1] = (float)(dsh[1] / (double)n.N);
+      rd.dsum[0] = dsh[2];
+      rd.dsum[1] = dsh[3];
+      rd.dsum[2] = dsh[4];
+    }
+  }
+  if (tid == 0) *rd.ticket = 0;
+}
+
+// ---------------------------------------------------------------------------
+// finish of a black-box policy epoch (one workgroup): g_L = dTR/dL_new +
+// projection backward, Cholesky head backward into the variance slots of the
+// flat gradient, global norm, clip factor, Adam, record row
+// {surrogate, entropy loss, trust region loss, total, entropy, |g|, |g| clipped}
+__global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
+    const float* __restrict__ gL_tr, const float* __restrict__ gL_p, int K, int nvec, int P,
+    float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
+    float* __restrict__ v, float* __restrict__ state, float lr, float b1, float b2, float eps,
+    float wd, float clip_grad, float gscale, int do_adam, const float* __restrict__ sur2,
+    const float* __restrict__ out16, float ent_coef, float* __restrict__ rec) {
+  __shared__ float red[SNW];
+  __shared__ float coef_s, step_s;
+  const int tid = threadIdx.x;
+  const float* var = param + P;
+  for (int i = tid; i < nvec; i += SBT) {
+    float gv;
+    if (i < K) {
+      const float x = var[i];
+      const float sig = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+      gv = (gL_tr[i * K + i] + gL_p[i * K + i]) * sig;
+    } else {
+      const int t = i - K;
+      int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+      while (r * (r - 1) / 2 > t) --r;
+      while ((r + 1) * r / 2 <= t) ++r;
+      const int c = t - r * (r - 1) / 2;
+      gv = gL_tr[r * K + c] + gL_p[r * K + c];
+    }
+    grad[P + i] = gv;
+  }
+  __syncthreads();
+  const int n = P + nvec;
+  float sq = 0.f;
+  for (int p = tid; p < n; p += SBT) sq += grad[p] * grad[p];
+  sq = block_sum(sq, red);
+  if (tid == 0) {
+    const float before = sqrtf(sq) * gscale;
+    float coef = 1.f;
+    if (clip_grad > 0.f) coef = fminf(clip_grad / (before + 1e-6f), 1.f);
+    if (do_adam) {
+      const float step = state[0] + 1.f;
+      state[0] = step;
+      state[1] = before;
+      state[2] = before * coef;
+      state[3] = coef * gscale;
+      step_s = step;
+    }
+    coef_s = coef * gscale;
+    const float entl = ent_coef == 0.f ? 0.f : -ent_coef * out16[12];
+    rec[0] = sur2[0];
+    rec[1] = entl;
+    rec[2] = out16[13];
+    rec[3] = ent_coef == 0.f ? sur2[0] + out16[13] : sur2[0] + out16[13] + entl;
+    rec[4] = out16[12];
+    rec[5] = before;
+    rec[6] = before * coef;
+  }
+  __syncthreads();
+  if (!do_adam) return;
+  const float step = step_s, coef = coef_s;
+  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
+  const float step_size = lr / bc1;
+  for (int p = tid; p < n; p += SBT) {
+    float gr = grad[p] * coef;
+    const float w = param[p];
+    if (wd != 0.f) gr += wd * w;
+    const float mi = b1 * m[p] + (1.f - b1) * gr;
+    const float vi = b2 * v[p] + (1.f - b2) * gr * gr;
+    m[p] = mi;
+    v[p] = vi;
+    param[p] = w - step_size * mi / (sqrtf(vi) / bc2s + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------
+inline bool s_shape_ok(int din, int H, int dout) {
+  return din >= 1 && din <= 64 && (H == 32 || H == 64) && dout >= 1 && dout <= 64;
+}
+inline size_t s_lds_bytes(int din, int H, int dout, int head) {
+  if (head == HEAD_NONE) return sizeof(float) * (size_t)s_forward_lds_floats(din, H, dout);
+  return sizeof(float) * (size_t)s_lds(din, H, dout, head).total;
+}
+inline int s_grid(int64_t N) { return (int)tmin<int64_t>(ceil_div(N, SR), S_MAX_GRID); }
+
+template <int H, int ACT, int HEAD>
+int s_launch_epoch(const SNet& n, const SValueHead& vh, const SPolicyHead& ph, const SReduce& rd,
+                   hipStream_t st) {
+  const size_t lds = s_lds_bytes(n.din, H, n.dout, HEAD);
+  tce_lds_limit(reinterpret_cast<const void*>(smlp_epoch_kernel<H, ACT, HEAD>), lds);
+  hipLaunchKernelGGL((smlp_epoch_kernel<H, ACT, HEAD>), dim3(s_grid(n.N)), dim3(SBT), lds, st, n,
+                     vh, ph, rd);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+template <int HEAD>
+int s_dispatch_epoch(int H, int act, const SNet& n, const SValueHead& vh, const SPolicyHead& ph,
+                     const SReduce& rd, hipStream_t st) {
+#define S_CASE(HH, AA) \
+  if (H == HH && act == AA) return s_launch_epoch<HH, AA, HEAD>(n, vh, ph, rd, st);
+  S_CASE(32, ACT_TANH) S_CASE(32, ACT_RELU) S_CASE(32, ACT_LEAKY) S_CASE(32, ACT_SOFTPLUS)
+  S_CASE(64, ACT_TANH) S_CASE(64, ACT_RELU) S_CASE(64, ACT_LEAKY) S_CASE(64, ACT_SOFTPLUS)
+#undef S_CASE
+  tce_set_error("smlp: unsupported hidden width / activation");
+  return 1;
+}
+
+template <int H, int ACT>
+int s_launch_forward(const SNet& n, float* out, hipStream_t st) {
+  const size_t lds = s_lds_bytes(n.din, H, n.dout, HEAD_NONE);
+  tce_lds_limit(reinterpret_cast<const void*>(smlp_forward_kernel<H, ACT>), lds);
+  hipLaunchKernelGGL((smlp_forward_kernel<H, ACT>), dim3(s_grid(n.N)), dim3(SBT), lds, st, n, out);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tce_smlp_supported(int din, int H, int dout, int head) {
+  if (!s_shape_ok(din, H, dout) || head < 0 || head > 2) return 0;
+  return s_lds_bytes(din, H, dout, head) <= S_LDS_MAX ? 1 : 0;
+}
+
+int64_t tce_smlp_num_params(int din, int H, int dout) { return s_nparams(din, H, dout); }
+
+// floats: gradient slabs [grid][P + dout^2 (+ pad)], then doubles [grid][8], then the ticket
+int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout) {
+  const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
+  const int64_t g = s_grid(N);
+  return g * PS + 2 * (g * 8) + 8;
+}
+
+int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, int H, int dout,
+                         int act, const float* param, float* out, void* stream) {
+  TCE_CHECK_ARG(x && param && out && N > 0, "smlp_forward: null buffer / empty batch");
+  TCE_CHECK_ARG(tce_smlp_supported(din, H, dout, HEAD_NONE), "smlp_forward: unsupported shape");
+  TCE_CHECK_ARG(x_stride >= din, "smlp_forward: row stride < din");
+  const SNet n{x, x_stride, N, din, dout, param};
+  hipStream_t st = (hipStream_t)stream;
+#define S_CASE(HH, AA) \
+  if (H == HH && act == AA) return s_launch_forward<HH, AA>(n, out, st);
+  S_CASE(32, ACT_TANH) S_CASE(32, ACT_RELU) S_CASE(32, ACT_LEAKY) S_CASE(32, ACT_SOFTPLUS)
+  S_CASE(64, ACT_TANH) S_CASE(64, ACT_RELU) S_CASE(64, ACT_LEAKY) S_CASE(64, ACT_SOFTPLUS)
+#undef S_CASE
+  tce_set_error("smlp_forward: unsupported hidden width / activation");
+  return 1;
+}
+
+static void s_reduce_ws(float* ws, int64_t N, int din, int H, int dout, SReduce& rd) {
+  const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
+  const int64_t g = s_grid(N);
+  rd.slabs = ws;
+  rd.dpart = reinterpret_cast<double*>(ws + g * PS);
+  rd.ticket = reinterpret_cast<unsigned*>(ws + g * PS + 2 * (g * 8));
+  rd.PS = (int)PS;
+  rd.P = s_nparams(din, H, dout);
+}
+
+int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* returns,
+                               const float* old_values, int64_t N, int din, int H, int act,
+                               float clip_critic, float* param, float* grad, float* m, float* v,
+                               float* opt_state, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float clip_grad, float grad_scale, int do_adam,
+                               int epochs, float* ws, float* rec, void* stream) {
+  TCE_CHECK_ARG(x && returns && param && grad && ws && rec && N > 0 && epochs > 0,
+                "smlp_critic_epochs: null buffer / empty batch");
+  TCE_CHECK_ARG(!(clip_critic > 0.f) || old_values, "smlp_critic_epochs: old values missing");
+  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "smlp_critic_epochs: optimizer state missing");
+  TCE_CHECK_ARG(tce_smlp_supported(din, H, 1, HEAD_VALUE), "smlp_critic_epochs: unsupported shape");
+  TCE_CHECK_ARG(x_stride >= din, "smlp_critic_epochs: row stride < din");
+  TCE_CHECK_ARG(do_adam || epochs == 1, "smlp_critic_epochs: epochs > 1 needs the fused Adam step");
+  const SNet n{x, x_stride, N, din, 1, param};
+  const SValueHead vh{returns, old_values, clip_critic};
+  const SPolicyHead ph{};
+  SReduce rd{};
+  s_reduce_ws(ws, N, din, H, 1, rd);
+  rd.grad = grad;
+  rd.param = param; rd.m = m; rd.v = v; rd.state = opt_state;
+  rd.lr = lr; rd.b1 = beta1; rd.b2 = beta2; rd.eps = eps; rd.wd = weight_decay;
+  rd.clip_grad = clip_grad; rd.gscale = grad_scale; rd.do_adam = do_adam;
+  for (int e = 0; e < epochs; ++e) {
+    rd.rec = rec + 3 * e;
+    const int rc = s_dispatch_epoch<HEAD_VALUE>(H, act, n, vh, ph, rd, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* actions,
+                             const float* logp_old, const float* adv, const float* mean_old,
+                             const float* L_old, int64_t N, int din, int H, int K, int act,
+                             int nvec, float min_std, float eps_mean, double eps_cov,
+                             const float* beta, int entropy_eq, float tr_coeff,
+                             int tr_include_cov, float ent_coef, float* param, float* grad,
+                             float* m, float* v, float* opt_state, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float clip_grad,
+                             float grad_scale, int do_adam, int epochs, double* proj_ctx,
+                             float* ws, float* mats, float* rec, float* mean_new_out,
+                             float* proj_mean_out, void* stream) {
+  TCE_CHECK_ARG(x && actions && logp_old && adv && mean_old && L_old && param && grad &&
+                    proj_ctx && ws && mats && rec && N > 0 && epochs > 0,
+                "bb_policy_epochs: null buffer / empty batch");
+  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "bb_policy_epochs: optimizer state missing");
+  TCE_CHECK_ARG(tce_smlp_supported(din, H, K, HEAD_BB_POLICY), "bb_policy_epochs: unsupported shape");
+  TCE_CHECK_ARG(nvec == K || nvec == K + K * (K - 1) / 2, "bb_policy_epochs: bad variance vector");
+  TCE_CHECK_ARG(x_stride >= din, "bb_policy_epochs: row stride < din");
+  TCE_CHECK_ARG(do_adam || epochs == 1, "bb_policy_epochs: epochs > 1 needs the fused Adam step");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = s_nparams(din, H, K);
+  const int KK = s_up4(K * K);
+  // mats: L_new | L_proj | g_pL | gL_tr | gL_p  [K,K] each, then sur2 [2] | out16 [16],
+  // then (8-byte aligned) dsum double[3]
+  float* L_new = mats;
+  float* L_proj = L_new + KK;
+  float* g_pL = L_proj + KK;
+  float* gL_tr = g_pL + KK;
+  float* gL_p = gL_tr + KK;
+  float* sur2 = gL_p + KK;
+  float* out16 = sur2 + 4;
+  double* dsum = reinterpret_cast<double*>(out16 + 16);
+  SNet n{x, x_stride, N, din, K, param};
+  const SValueHead vh{};
+  SReduce rd{};
+  s_reduce_ws(ws, N, din, H, K, rd);
+  rd.grad = grad;
+  rd.g_pL = g_pL; rd.sur2 = sur2; rd.dsum = dsum;
+  for (int e = 0; e < epochs; ++e) {
+    const bool lastep = e == epochs - 1;
+    int rc = tce_chol_build_fwd_f32(param + P, L_new, 1, K, nvec, min_std, stream);
+    if (rc) return rc;
+    rc = tce_kl_cov_proj_fwd_f32(L_new, L_old, 0, eps_cov, beta, entropy_eq, L_proj, proj_ctx, 1,
+                                 K, 1, stream);
+    if (rc) return rc;
+    const SPolicyHead ph{actions, logp_old, adv, mean_old, L_old, L_proj, eps_mean, tr_coeff,
+                         ent_coef, lastep ? mean_new_out : nullptr,
+                         lastep ? proj_mean_out : nullptr};
+    rc = s_dispatch_epoch<HEAD_BB_POLICY>(H, act, n, vh, ph, rd, st);
+    if (rc) return rc;
+    rc = tce_kl_shared_mat_f32(L_new, L_old, L_proj, N, K, tr_coeff, tr_include_cov, dsum, 1,
+                               out16, gL_tr, stream);
+    if (rc) return rc;
+    rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, gL_tr, gL_p, K, nvec, P,
+                       param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,
+                       grad_scale, do_adam, sur2, out16, ent_coef, rec + 7 * e);
+    TCE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int64_t tce_bb_policy_mats_len(int K) { return 5 * (int64_t)s_up4(K * K) + 4 + 16 + 8; }
+
+}  // extern "C"

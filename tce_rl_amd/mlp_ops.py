@@ -49,10 +49,13 @@ class _Linear(torch.autograd.Function):
 def forward(mlp, x):
     if not x.is_cuda:
         raise RuntimeError("tce_rl_amd MLPs run on a HIP device only")
-    from . import critic_ops
+    from . import critic_ops, smlp_ops
     if not torch.is_grad_enabled() and critic_ops.supported(mlp) \
             and x.numel() >= 4096 * mlp.dim_in:
         return critic_ops.forward(mlp, x)         # fused MFMA forward
+    if not torch.is_grad_enabled() and smlp_ops.supported(mlp) \
+            and x.shape[-1] == mlp.dim_in:
+        return smlp_ops.forward(mlp, x)           # csrc/smlp.hip row kernel
     layers = mlp.layers
     if critic_ops.hidden_supported(mlp, x) and not x.requires_grad \
             and mlp.act_func_last_type is None:

@@ -878,6 +878,10 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # (its K x K kernels are single workgroups): 24 vs 27 ms per step
         self.fused_policy_objective = kwargs.get("fused_policy_objective",
                                                  False)
+        # the hand-written row kernels for nets up to 64 wide (csrc/smlp.hip):
+        # one launch per critic epoch, six per policy epoch, no autograd, no
+        # library GEMM, no graph.  Off: the op-by-op / graph paths below.
+        self.small_net_kernels = kwargs.get("small_net_kernels", True)
         self._epoch_graphs = {}
 
     def _epoch_graph(self, kind, E, opt, inputs, rec_cols):
@@ -950,7 +954,10 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             {k: v for k, v in dataset.items()
              if k not in ("segment_params_L", "segment_state")}, "exploration")
         util.run_time_test(lock=True, key="update")
-        if self.overlap_updates and self.graph_epochs and \
+        from .. import smlp_ops
+        small = self.small_net_kernels and smlp_ops.critic_supported(self) \
+            and smlp_ops.policy_supported(self, dataset["segment_params_L"])
+        if self.overlap_updates and (self.graph_epochs or small) and \
                 self.num_minibatchs == 1 and not self.dist.active:
             # the two updates are independent chains of ~100 small launches per
             # epoch, replayed from HIP graphs: side by side on two streams
@@ -1002,6 +1009,12 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             **util.generate_stats(host[0], "critic_loss"),
             **util.generate_stats(host[1], "critic_grad_norm"),
             **util.generate_stats(host[2], "clipped_critic_grad_norm")}
+        from .. import smlp_ops
+        if self.small_net_kernels and smlp_ops.critic_supported(self):
+            # E launches, each a whole epoch incl. the Adam step (csrc/smlp.hip)
+            rec = smlp_ops.critic_update(self, states, returns, old_values)
+            fin = lambda: stats(rec.cpu().numpy().T)
+            return fin if defer else fin()
         if self.num_minibatchs == 1:
             eg, st = self._epoch_graph(
                 "critic", E, self.critic_optimizer,
@@ -1066,6 +1079,9 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             ent0 = self.policy.entropy([mean_old, L_old]).mean()
             self.projection.initial_entropy = self.dist.mean_scalar(ent0)
         E = self.epochs_policy
+        from .. import smlp_ops
+        if self.small_net_kernels and smlp_ops.policy_supported(self, L_old):
+            return self._update_policy_small(dataset)
         eg, st = self._epoch_graph(
             "policy", E, self.policy_optimizer,
             dict(states=states, actions=actions, log_probs_old=log_probs_old,
@@ -1149,13 +1165,45 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         else:
             self._run_epochs(epoch, E, self.policy_optimizer,
                              self.graph_epochs)
+        return self._finish_policy_update(rec, last["t"], states, mean_old,
+                                          L_old)
+
+    def _update_policy_small(self, dataset):
+        """update_policy on the row kernels of csrc/smlp.hip: per epoch the
+        Cholesky head, the covariance projection, ONE kernel for everything
+        per env (mean net forward, mean projection, log-prob, surrogate, trust
+        region, their gradients, mean net backward), the K x K KL parts, the
+        projection's backward and a finish kernel (Cholesky head backward,
+        clip, Adam, record row)."""
+        from .. import smlp_ops
+        states = dataset["segment_state"]
+        mean_old, L_old = dataset["segment_params_mean"], \
+            dataset["segment_params_L"]
+        sched = self.projection.entropy_schedule_type
+        beta = None if sched in (None, False) else \
+            self.projection.entropy_schedule(
+                self.projection.initial_entropy,
+                self.projection.target_entropy, self.projection.temperature,
+                self.num_iterations)
+        if beta is not None and not torch.is_tensor(beta):
+            beta = torch.as_tensor(float(beta), device=self.device)
+        rec, mean_new, L_new, proj_mean, proj_L = smlp_ops.policy_update(
+            self, states, dataset["segment_action"],
+            dataset["segment_log_prob"], dataset["segment_advantage"],
+            mean_old, L_old, beta)
+        N = states.shape[0]
+        last = (mean_new, ops.expand_shared(L_new, N), proj_mean,
+                ops.expand_shared(proj_L, N))
+        return self._finish_policy_update(rec, last, states, mean_old, L_old)
+
+    def _finish_policy_update(self, rec, last, states, mean_old, L_old):
         host = rec.cpu().numpy()                          # ONE copy
         for name, bad in zip(("surrogate_loss", "entropy_loss",
                               "trust_region_loss"),
                              np.isnan(host[:, :3]).any(axis=0)):
             if bad:
                 raise Exception("NAN %s detected" % name)
-        mean_new, L_new, proj_mean, proj_L = last["t"]
+        mean_new, L_new, proj_mean, proj_L = last
         names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
                  "policy_loss", "entropy", "policy_grad_norm",
                  "clipped_policy_grad_norm")

@@ -1,0 +1,192 @@
+"""Small two-hidden-layer networks of the black-box agent on the hand-written
+row kernels of csrc/smlp.hip (D_in <= 64 -> H -> H -> D_out, H in {32, 64},
+float32): rollout forward, the critic update and the policy update of
+``BlackBoxAgent`` (mprl/rl/agent/black_box_agent.py:105-389) without autograd
+and without library GEMMs -- one launch per critic epoch, six per policy epoch.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_ACT = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
+HEAD_NONE, HEAD_VALUE, HEAD_BB_POLICY = 0, 1, 2
+
+
+def supported(mlp, head=HEAD_NONE):
+    hl = list(mlp.hidden_layers)
+    if not (mlp.dtype == torch.float32 and len(hl) == 2 and hl[0] == hl[1]
+            and mlp.act_func_last_type is None
+            and mlp.act_func_hidden_type in _ACT):
+        return False
+    if head == HEAD_VALUE and mlp.dim_out != 1:
+        return False
+    return bool(_lib.load().tce_smlp_supported(mlp.dim_in, hl[0], mlp.dim_out,
+                                               head))
+
+
+def flat_params(mlp):
+    """The parameters as ONE flat buffer in the order W1 | b1 | W2 | b2 | W3 |
+    b3: the tensors themselves when they already lie back to back (views of a
+    FlatAdam buffer), a copy otherwise."""
+    ps = list(mlp.parameters())
+    ok = all(p.is_contiguous() for p in ps)
+    if ok:
+        for a, b in zip(ps[:-1], ps[1:]):
+            if b.data_ptr() != a.data_ptr() + a.numel() * a.element_size():
+                ok = False
+                break
+    if ok:
+        n = sum(p.numel() for p in ps)
+        return ps[0].detach().as_strided((n,), (1,))
+    return torch.cat([p.detach().reshape(-1) for p in ps])
+
+
+def _rows2d(x, din):
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    assert x2.shape[1] >= din
+    return x2
+
+
+def forward(mlp, x):
+    """MLP.forward without autograd (rollouts, evaluation)."""
+    x2 = _rows2d(x, mlp.dim_in)
+    N = x2.shape[0]
+    out = torch.empty(N, mlp.dim_out, dtype=torch.float32, device=x.device)
+    call("tce_smlp_forward_f32", ptr(x2), x2.stride(0), N, mlp.dim_in,
+         mlp.hidden_layers[0], mlp.dim_out, _ACT[mlp.act_func_hidden_type],
+         ptr(flat_params(mlp)), ptr(out), stream())
+    return out.reshape(*x.shape[:-1], mlp.dim_out)
+
+
+def _opt_matches(opt, params):
+    from .optim import FlatAdam
+    return isinstance(opt, FlatAdam) and len(opt._params) == len(params) and \
+        all(a is b for a, b in zip(opt._params, params))
+
+
+def _workspace(owner, key, n, dtype=torch.float32):
+    """A zero-initialised scratch buffer kept on `owner` (the kernels re-arm
+    their ticket themselves, so it is zeroed once)."""
+    cache = owner.__dict__.setdefault("_tce_smlp_ws", {})
+    buf = cache.get(key)
+    if buf is None or buf.numel() < n:
+        dev = next(owner.parameters()).device
+        buf = torch.zeros(n, dtype=dtype, device=dev)
+        cache[key] = buf
+    return buf
+
+
+def critic_supported(agent):
+    net = agent.critic.net
+    return supported(net, HEAD_VALUE) and agent.num_minibatchs == 1 and \
+        _opt_matches(agent.critic_optimizer, list(net.parameters()))
+
+
+def critic_update(agent, states, returns, old_values):
+    """E critic epochs -> rec [E, 3] = {loss, |g|, |g| clipped} (device)."""
+    net, opt = agent.critic.net, agent.critic_optimizer
+    lib = _lib.load()
+    x = _rows2d(states, net.dim_in)
+    N, E = x.shape[0], agent.epochs_critic
+    H = net.hidden_layers[0]
+    ret = returns.reshape(-1).contiguous()
+    old = old_values.reshape(-1).contiguous() if agent.clip_critic > 0 \
+        else None
+    ws = _workspace(net, ("ws", N), lib.tce_smlp_ws_len(N, net.dim_in, H, 1))
+    rec = torch.zeros(E, 3, dtype=torch.float32, device=x.device)
+    g = opt.param_groups[0]
+    opt.bind_grads()
+
+    def launch(epochs, do_adam, rec_rows, scale):
+        call("tce_smlp_critic_epochs_f32", ptr(x), x.stride(0), ptr(ret),
+             ptr(old), N, net.dim_in, H, _ACT[net.act_func_hidden_type],
+             float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
+             ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+             float(g["weight_decay"]), float(agent.clip_grad_norm), scale,
+             int(do_adam), epochs, ptr(ws), ptr(rec_rows), stream())
+    if not agent.dist.active:
+        launch(E, True, rec, 1.0)
+        opt.host_step += E
+    else:
+        for e in range(E):
+            launch(1, False, rec[e], 1.0)
+            agent.dist.allreduce_flat(opt.flat_grad, average=False)
+            opt.step(agent.clip_grad_norm, grad_scale=1.0 / agent.dist.world)
+            rec[e, 1:3].copy_(opt.dev_state[1:3])
+    return rec
+
+
+def policy_supported(agent, L_old):
+    from . import ops
+    from .rl.projection import KLProjectionLayer
+    pol, proj = agent.policy, agent.projection
+    net = pol.mean_net
+    return (supported(net, HEAD_BB_POLICY) and not pol.contextual_cov
+            and type(proj) is KLProjectionLayer and not proj.entropy_first
+            and ops.split_L(L_old)[1] == 0 and agent.num_minibatchs == 1
+            and _opt_matches(agent.policy_optimizer,
+                             list(net.parameters()) +
+                             [pol.variance_net.variable]))
+
+
+def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
+                  beta):
+    """E policy epochs -> (rec [E, 7], mean_new, L_new [K,K], proj_mean,
+    proj_L [K,K]) with the last epoch's distributions."""
+    from . import ops
+    pol, proj, opt = agent.policy, agent.projection, agent.policy_optimizer
+    net, lib = pol.mean_net, _lib.load()
+    x = _rows2d(states, net.dim_in)
+    N, E, K = x.shape[0], agent.epochs_policy, pol.dim_out
+    H = net.hidden_layers[0]
+    dev = x.device
+    c = lambda t: t if t.is_contiguous() else t.contiguous()
+    actions, logp_old, adv, mean_old = c(actions), c(logp_old), c(adv), \
+        c(mean_old)
+    L_old = c(ops.split_L(L_old)[0].detach())
+    var = pol.variance_net.variable
+    ws = _workspace(net, ("ws", N), lib.tce_smlp_ws_len(N, net.dim_in, H, K))
+    mats = _workspace(net, ("mats", K), lib.tce_bb_policy_mats_len(K))
+    ctx = torch.zeros(lib.tce_kl_cov_proj_ctx_len(K), dtype=torch.float64,
+                      device=dev)
+    rec = torch.zeros(E, 7, dtype=torch.float32, device=dev)
+    mean_new = torch.empty(N, K, dtype=torch.float32, device=dev)
+    proj_mean = torch.empty(N, K, dtype=torch.float32, device=dev)
+    beta_t = None if beta is None else \
+        c(beta.detach().to(torch.float32).reshape(1))
+    include_cov = int(pol.contextual_std or not agent.set_variance)
+    g = opt.param_groups[0]
+    opt.bind_grads()
+
+    def launch(epochs, do_adam, rec_rows):
+        call("tce_bb_policy_epochs_f32", ptr(x), x.stride(0), ptr(actions),
+             ptr(logp_old), ptr(adv), ptr(mean_old), ptr(L_old), N,
+             net.dim_in, H, K, _ACT[net.act_func_hidden_type], var.numel(),
+             float(pol.min_std), float(proj.mean_bound), float(proj.cov_bound),
+             ptr(beta_t), int(bool(proj.entropy_eq)),
+             float(proj.trust_region_coeff), include_cov,
+             float(agent.entropy_penalty_coef), ptr(opt.flat_param),
+             ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v), ptr(opt.dev_state),
+             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+             float(g["eps"]), float(g["weight_decay"]),
+             float(agent.clip_grad_norm), 1.0, int(do_adam), epochs, ptr(ctx),
+             ptr(ws), ptr(mats), ptr(rec_rows), ptr(mean_new), ptr(proj_mean),
+             stream())
+    if not agent.dist.active:
+        launch(E, True, rec)
+        opt.host_step += E
+    else:
+        for e in range(E):
+            launch(1, False, rec[e])
+            agent.dist.allreduce_flat(opt.flat_grad, agent._policy_group,
+                                      average=False)
+            opt.step(agent.clip_grad_norm, grad_scale=1.0 / agent.dist.world)
+            rec[e, 5:7].copy_(opt.dev_state[1:3])
+    KK = (K * K + 3) // 4 * 4
+    L_new = mats[:K * K].view(K, K).clone()
+    proj_L = mats[KK:KK + K * K].view(K, K).clone()
+    return rec, mean_new, L_new, proj_mean, proj_L

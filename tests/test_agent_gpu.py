@@ -425,6 +425,7 @@ def test_bbrl_graph_epochs_equal_eager_epochs():
     for graph in (True, False):
         torch.manual_seed(0)
         agent, _ = build_bbrl(64, 5)
+        agent.small_net_kernels = False         # the op-by-op epochs
         agent.graph_epochs = graph
         agent.evaluation_interval = 0
         torch.manual_seed(1)
@@ -450,6 +451,7 @@ def test_bbrl_kept_graphs_equal_fresh_graphs_over_iterations():
                dict(graph_epochs=False, overlap_updates=False)):
         torch.manual_seed(0)
         agent, _ = build_bbrl(96, 6)
+        agent.small_net_kernels = False         # the op-by-op epochs
         for k, v in kw.items():
             setattr(agent, k, v)
         agent.evaluation_interval = 0
@@ -469,15 +471,25 @@ def test_bbrl_kept_graphs_equal_fresh_graphs_over_iterations():
             assert abs(res[k] - out[2][0][k]) <= 1e-6 * abs(out[2][0][k]) + 1e-8
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_bbrl_step_matches_cpu_oracle(fused):
+@pytest.mark.parametrize("mode", ["small", "op_by_op", "fused"])
+def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
     """One BlackBoxAgent.step() (a16) against the CPU oracle step on the same
-    weights, env state and parameter noise."""
+    weights, env state and parameter noise: on the hand-written row kernels of
+    csrc/smlp.hip (the default), op by op under autograd, and with the
+    objective as one autograd node."""
     from oracle.agent_oracle import OracleBBRL
+    from tce_rl_amd import smlp_ops
     N, EPOCHS = 24, 3
     agent, d_in = build_bbrl(N, EPOCHS)
     agent.evaluation_interval = 0
-    agent.fused_policy_objective = fused      # tce_bb_policy_objective_* / op by op
+    agent.small_net_kernels = mode == "small"
+    agent.fused_policy_objective = mode == "fused"   # tce_bb_policy_objective_*
+    calls = {"c": 0, "p": 0}
+    cu, pu = smlp_ops.critic_update, smlp_ops.policy_update
+    monkeypatch.setattr(smlp_ops, "critic_update", lambda *a, **k: (
+        calls.__setitem__("c", calls["c"] + 1), cu(*a, **k))[1])
+    monkeypatch.setattr(smlp_ops, "policy_update", lambda *a, **k: (
+        calls.__setitem__("p", calls["p"] + 1), pu(*a, **k))[1])
     oracle = OracleBBRL(BB_MP, N, d_in, [32, 32], [32, 32], "relu", True, 1e-5,
                         0.01, 3e-4, EPOCHS, 0.005, 0.0005, 1.0, True)
     with torch.no_grad():
@@ -530,6 +542,7 @@ def test_bbrl_step_matches_cpu_oracle(fused):
         _close("policy", pg.detach().cpu(), po.detach(), 3e-6)
     _close("variance", agent.policy.variance_net.variable.detach().cpu(),
            oracle.var.detach(), 3e-6)
+    assert (calls["c"], calls["p"]) == ((1, 1) if mode == "small" else (0, 0))
 
 
 @pytest.mark.parametrize("ent_coef", [0.0, 0.01])
