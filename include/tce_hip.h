@@ -625,27 +625,34 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
  * tce_smlp_forward: out [N][dout] = MLP(x) (MLP.forward, util_nn.py:225-246).
  *
  * tce_smlp_critic_epochs: `epochs` full-batch critic epochs of
- * BlackBoxAgent.update_critic (mprl/rl/agent/black_box_agent.py:105-157), ONE
- * launch each: forward, value loss (clip_critic > 0: the clipped form of
- * :391-419), backward, gradient into `grad` [P], then -- do_adam -- grad-norm
- * clip (mprl/util/util_numerical.py:244-275) and the Adam step of
- * torch.optim.Adam(lr, weight_decay) (mprl/rl/agent/abstract_agent.py:62-82)
- * on param / m / v [P] with opt_state = {step, |g|, |g| clipped, factor} as in
- * tce_adam_flat.  do_adam == 0 (env shards: the caller all-reduces `grad`
- * first) requires epochs == 1.  rec [epochs][3] = {loss, |g|, |g| clipped}.
+ * BlackBoxAgent.update_critic (mprl/rl/agent/black_box_agent.py:105-157), TWO
+ * launches each: the row kernel (forward, value loss -- clip_critic > 0: the
+ * clipped form of :391-419 --, backward, per-workgroup gradient slabs) and the
+ * slab reduction into `grad` [P], which -- do_adam and clip_grad <= 0 -- also
+ * applies the Adam step of torch.optim.Adam(lr, weight_decay)
+ * (mprl/rl/agent/abstract_agent.py:62-82) on param / m / v [P] (opt_state[0] =
+ * step count; first_step = count INCLUDING the first of these epochs); with
+ * clip_grad > 0 (mprl/util/util_numerical.py:244-275) tce_adam_flat follows
+ * instead.  do_adam == 0 (env shards: the caller all-reduces `grad` first)
+ * requires epochs == 1.  rec [epochs][3], ZEROED by the caller, receives
+ * {mean loss, |grad|^2, -}.
  *
  * tce_bb_policy_epochs: `epochs` policy epochs of BlackBoxAgent.update_policy
- * (black_box_agent.py:159-389) for a shared (non-contextual) covariance, six
- * launches each: Cholesky head (tce_chol_build_fwd on the variance vector
- * param + P, nvec entries), covariance projection, ONE row kernel (mean net
+ * (black_box_agent.py:159-389) for a shared (non-contextual) covariance:
+ * Cholesky head (tce_chol_build_fwd on the variance vector param + P, nvec
+ * entries), covariance projection, K x K KL parts, ONE row kernel (mean net
  * forward, mean projection, log-prob of `actions` under the projected
  * Gaussian, surrogate, trust region loss, their gradients, mean net backward),
- * tce_kl_shared_mat, tce_kl_cov_proj_bwd, finish (Cholesky head backward into
- * grad [P, P + nvec), clip, Adam on all P + nvec entries, record).  rec
+ * slab reduction, tce_kl_cov_proj_bwd, finish (Cholesky head backward into
+ * grad [P, P + nvec), clip, Adam on all P + nvec entries, record) -- seven
+ * launches; diag != 0 (std_only factors, beta == NULL: every shipped BBRL
+ * config): the K x K steps collapse into K-vector steps, four launches.  rec
  * [epochs][7] = {surrogate, entropy loss, trust region loss, total, entropy,
  * |g|, |g| clipped}.  mats: float [tce_bb_policy_mats_len(K)], holds after
  * the call L_new | L_proj | (scratch) in [K,K] blocks of pitch (K*K rounded up
- * to 4); mean_new_out / proj_mean_out (nullable) [N,K]: the last epoch's means. */
+ * to 4); proj_ctx: double [tce_kl_cov_proj_ctx_len(K)], zeroed by the caller
+ * once per update; mean_new_out / proj_mean_out (nullable) [N,K]: the last
+ * epoch's means. */
 int tce_smlp_supported(int din, int H, int dout, int head);
 int64_t tce_smlp_num_params(int din, int H, int dout);
 int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout);
@@ -657,7 +664,7 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
                                float clip_critic, float* param, float* grad, float* m, float* v,
                                float* opt_state, float lr, float beta1, float beta2, float eps,
                                float weight_decay, float clip_grad, float grad_scale, int do_adam,
-                               int epochs, float* ws, float* rec, void* stream);
+                               int first_step, int epochs, float* ws, float* rec, void* stream);
 int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* actions,
                              const float* logp_old, const float* adv, const float* mean_old,
                              const float* L_old, int64_t N, int din, int H, int K, int act,
@@ -666,9 +673,9 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              int tr_include_cov, float ent_coef, float* param, float* grad,
                              float* m, float* v, float* opt_state, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float clip_grad,
-                             float grad_scale, int do_adam, int epochs, double* proj_ctx,
-                             float* ws, float* mats, float* rec, float* mean_new_out,
-                             float* proj_mean_out, void* stream);
+                             float grad_scale, int do_adam, int diag, int epochs,
+                             double* proj_ctx, float* ws, float* mats, float* rec,
+                             float* mean_new_out, float* proj_mean_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,9 +33,17 @@
 // factors held in LDS, vectors in [k][lane] layout).  Weight gradients are
 // sums of outer products over the 64 rows: thread = 4 x 4 block of a weight
 // matrix, operands read as 16-byte pieces of the row-major tiles.  Every
-// workgroup writes its gradient slab; the workgroup that takes the last ticket
-// adds the slabs in a fixed order (deterministic), and -- critic -- applies the
-// clip factor and the Adam step at once.
+// workgroup writes its gradient slab; a second, wide launch adds the slabs in a
+// fixed order (deterministic) and -- critic without clipping -- applies the Adam
+// step in the same pass.  (One workgroup adding 64 slabs after the last ticket
+// took 250 us: 600 dependent-latency loads per thread; 38 workgroups x 1024
+// threads need one round trip.)
+//
+// Diagonal covariances (std_only: the reference's BBRL configuration) make
+// every K x K step a K-vector step: one small kernel does Cholesky head,
+// covariance projection, KL parts and the trust region gradient, and the
+// finish kernel does the projection's backward -- four launches per epoch
+// instead of seven.
 #include "mlp_shared.h"
 #include "../../include/tce_hip.h"
 
@@ -127,21 +135,25 @@ struct SPolicyHead {
 };
 
 struct SReduce {
-  float* slabs;              // [grid][PS]
-  double* dpart;             // [grid][8]
-  unsigned* ticket;
+  float* slabs;              // [grid][PS]: network gradient | (policy) sum g u y^T [K][K]
+  double* dpart;             // [grid][8]: value {loss sum}; policy {sum ratio adv, sum ratio, m1, m2, m3}
   int PS;                    // slab pitch
   int P;                     // network parameters
-  float* grad;               // flat gradient [>= P]
-  // value head: Adam fused into the last workgroup
+};
+
+// arguments of the slab reduction (smlp_reduce_kernel)
+struct SFinish {
+  const float* slabs;
+  const double* dpart;
+  int nparts, PS, P, KK;     // KK: extra columns behind the network's (policy: K * K)
+  int64_t N;
+  float* grad;               // [P]
+  float* extra;              // [KK] (policy: raw sum g u y^T)
+  double* dsum;              // [8] sums of dpart over the workgroups
+  float* stats;              // {mean loss (value head), |grad|^2 (+= : zeroed by the caller)}
+  // Adam fused into the reduction (value head without clipping); param == nullptr: gradient only
   float *param, *m, *v, *state;
-  float lr, b1, b2, eps, wd, clip_grad, gscale;
-  int do_adam;
-  float* rec;                // value: {loss, |g|, |g| clipped}
-  // policy head outputs of the last workgroup
-  float* g_pL;               // [K,K]
-  float* sur2;               // {surrogate, mean ratio}
-  double* dsum;              // {m1, m2, m3}: sums of the three Mahalanobis terms
+  float lr, b1, b2, eps, wd, step, gscale;
 };
 
 // ---------------------------------------------------------------------------
@@ -543,8 +555,6 @@ template <int H, int ACT, int HEAD>
 __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, SPolicyHead ph,
                                                         SReduce rd) {
   extern __shared__ __attribute__((aligned(16))) float S[];
-  __shared__ bool last;
-  __shared__ double dred[SNW];
   const SLds L = s_lds(n.din, H, n.dout, HEAD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = n.dout;
@@ -605,121 +615,245 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
     }
     first = false;
   }
-  (void)dred;
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) rd.dpart[blockIdx.x * 8 + i] = acc_d[i];
-    __threadfence();
   }
-  __syncthreads();
-  __threadfence();
-  if (tid == 0) last = atomicAdd(rd.ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  // ---- the last workgroup: slabs -> gradient, in slab order
-  const int nblk = gridDim.x;
-  const int tot = HEAD == HEAD_BB_POLICY ? rd.P + K * K : rd.P;
-  float sq = 0.f;
-  for (int p = tid; p < tot; p += SBT) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += __builtin_nontemporal_load(rd.slabs + (int64_t)b * rd.PS + p);
-    if (p < rd.P) {
-      rd.grad[p] = s;
-      sq += s * s;
-    } else {
-      S[p - rd.P] = s;                                  // g_pL, finished below
-    }
-  }
-  double ds[5] = {0, 0, 0, 0, 0};
-  if (tid < 5)
-    for (int b = 0; b < nblk; ++b) ds[0] += __builtin_nontemporal_load(rd.dpart + b * 8 + tid);
-  if (HEAD == HEAD_VALUE) {
-    float* red = S + L.red;
-    sq = block_sum(sq, red);
-    __shared__ float coef_s, step_s;
-    if (tid == 0) {
-      const float before = sqrtf(sq) * rd.gscale;
-      float coef = 1.f;
-      if (rd.clip_grad > 0.f) coef = fminf(rd.clip_grad / (before + 1e-6f), 1.f);
-      const float loss = (float)(ds[0] / (double)n.N);
-      rd.rec[0] = loss;
-      rd.rec[1] = before;
-      rd.rec[2] = before * coef;
-      if (rd.do_adam) {
-        const float step = rd.state[0] + 1.f;
-        rd.state[0] = step;
-        rd.state[1] = before;
-        rd.state[2] = before * coef;
-        rd.state[3] = coef * rd.gscale;
-        step_s = step;
-      }
-      coef_s = coef * rd.gscale;
-    }
-    __syncthreads();
-    if (rd.do_adam) {
-      const float step = step_s, coef = coef_s;
-      const float bc1 = 1.f - powf(rd.b1, step), bc2s = sqrtf(1.f - powf(rd.b2, step));
-      const float step_size = rd.lr / bc1;
-      for (int p = tid; p < rd.P; p += SBT) {
-        float gr = rd.grad[p] * coef;
-        const float w = rd.param[p];
-        if (rd.wd != 0.f) gr += rd.wd * w;
-        const float mi = rd.b1 * rd.m[p] + (1.f - rd.b1) * gr;
-        const float vi = rd.b2 * rd.v[p] + (1.f - rd.b2) * gr * gr;
-        rd.m[p] = mi;
-        rd.v[p] = vi;
-        rd.param[p] = w - step_size * mi / (sqrtf(vi) / bc2s + rd.eps);
-      }
-    }
-  } else {
-    // sum g = -(sum ratio adv) / N: the diagonal terms of d logp / d L_proj and
-    // of the entropy bonus; surrogate and the Mahalanobis sums for the K x K part
-    __shared__ double dsh[5];
-    if (tid < 5) dsh[tid] = ds[0];
-    __syncthreads();
-    const float sum_g = (float)(-dsh[0] / (double)n.N);
-    for (int e = tid; e < K * K; e += SBT) {
-      const int i = e / K, j = e - i * K;
-      float v = 0.f;
-      if (j <= i) {
-        v = S[e];
-        if (i == j) v -= (sum_g + ph.ent_coef) / ph.L_proj[e];
-      }
-      rd.g_pL[e] = v;
-    }
-    if (tid == 0) {
-      rd.sur2[0] = (float)(-dsh[0] / (double)n.N);
-      rd.sur2[1] = (float)(dsh[1] / (double)n.N);
-      rd.dsum[0] = dsh[2];
-      rd.dsum[1] = dsh[3];
-      rd.dsum[2] = dsh[4];
-    }
-  }
-  if (tid == 0) *rd.ticket = 0;
 }
 
 // ---------------------------------------------------------------------------
-// finish of a black-box policy epoch (one workgroup): g_L = dTR/dL_new +
-// projection backward, Cholesky head backward into the variance slots of the
-// flat gradient, global norm, clip factor, Adam, record row
-// {surrogate, entropy loss, trust region loss, total, entropy, |g|, |g| clipped}
+// column sums of the slabs in a fixed order: FIN_GROUPS interleaved groups of
+// slabs in parallel, then the groups (as mlp_finish_kernel).  Columns [0, P):
+// the network's gradient (+ the Adam update of torch.optim.Adam when f.param);
+// columns [P, P + KK): f.extra.  Workgroup 0 also adds the per-workgroup
+// double sums.
+__global__ __launch_bounds__(64 * FIN_GROUPS) void smlp_reduce_kernel(SFinish f) {
+  __shared__ float part[FIN_GROUPS][64];
+  __shared__ float red[FIN_GROUPS];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + col;
+  const int tot = f.P + f.KK;
+  float s = 0.f;
+  if (p < tot) {
+    const float* src = f.slabs + p;
+#pragma unroll 4
+    for (int i = grp; i < f.nparts; i += FIN_GROUPS) s += src[(int64_t)i * f.PS];
+  }
+  part[grp][col] = s;
+  __syncthreads();
+  float sq = 0.f;
+  if (grp == 0 && p < tot) {
+    float g0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < FIN_GROUPS; ++k) g0 += part[k][col];   // fixed order
+    if (p < f.P) {
+      f.grad[p] = g0;
+      sq = g0 * g0;
+      if (f.param) {
+        const float w = f.param[p];
+        float g = g0 * f.gscale;
+        if (f.wd != 0.f) g += f.wd * w;
+        const float mi = f.b1 * f.m[p] + (1.f - f.b1) * g;
+        const float vi = f.b2 * f.v[p] + (1.f - f.b2) * g * g;
+        f.m[p] = mi;
+        f.v[p] = vi;
+        const float bc1 = 1.f - powf(f.b1, f.step), bc2s = sqrtf(1.f - powf(f.b2, f.step));
+        f.param[p] = w - (f.lr / bc1) * mi / (sqrtf(vi) / bc2s + f.eps);
+      }
+    } else {
+      f.extra[p - f.P] = g0;
+    }
+  }
+  const float tot_sq = block_sum(sq, red);
+  if (threadIdx.x == 0 && f.stats) atomicAdd(&f.stats[1], tot_sq);
+  if (blockIdx.x == 0) {
+    // per-workgroup double sums, 8 columns, slab order
+    __shared__ double dsh[FIN_GROUPS][8];
+    const int c = threadIdx.x & 7, gq = threadIdx.x >> 3;        // 128 groups of 8 columns
+    double d = 0;
+    if (gq < FIN_GROUPS)
+      for (int i = gq; i < f.nparts; i += FIN_GROUPS) d += f.dpart[i * 8 + c];
+    if (gq < FIN_GROUPS) dsh[gq][c] = d;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < FIN_GROUPS; ++k) t += dsh[k][threadIdx.x];
+      f.dsum[threadIdx.x] = t;
+      if (threadIdx.x == 0 && f.stats) f.stats[0] = (float)(t / (double)f.N);
+      if (threadIdx.x == 0 && f.param) f.state[0] = f.step;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Matrix side of a black-box policy epoch for DIAGONAL factors (std_only):
+// Cholesky head, KL covariance projection (oracle/kl_oracle.py cov_projection
+// restricted to diagonal matrices: lambda_k = (sigma_k / sigma_old_k)^2, eta
+// the root of 1/2 sum (mu_k - 1 - log mu_k) = eps, mu_k = (eta + 1) lambda_k /
+// (eta lambda_k + 1)), the covariance halves of the three KL terms, the
+// entropy of the projected policy and the trust region gradient w.r.t. the new
+// factor.  One wave.  dctx (double): [lambda K | mu K | eta, active, -, -].
+__global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
+    const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
+    double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
+    float* __restrict__ L_proj, float* __restrict__ gL_tr, float* __restrict__ out16,
+    double* __restrict__ dctx) {
+  const int k = threadIdx.x;
+  const bool live = k < K;
+  double sig = 1, so = 1;
+  if (live) {
+    const float x = var[k];
+    sig = (double)((x > 20.f ? x : log1pf(expf(x))) + min_std);
+    so = (double)L_old[k * K + k];
+  }
+  const double a = sig / so, lam = a * a;
+  const double kl0 = 0.5 * wave_sum_f64(live ? lam - 1.0 - log(lam) : 0.0);
+  const bool active = kl0 > eps_cov;
+  double eta = 0, mu = lam;
+  if (active) {
+    auto hfun = [&](double e) {
+      double t = 0;
+      if (live) {
+        const double m_ = (e + 1.0) * lam / (e * lam + 1.0);
+        t = m_ - 1.0 - log(m_);
+      }
+      return 0.5 * wave_sum_f64(t);
+    };
+    double lo = 0.0, hi = 1.0;
+    for (int i = 0; i < 200 && hfun(hi) > eps_cov; ++i) { lo = hi; hi *= 2.0; }
+    double eta_n = lo;
+    for (int i = 0; i < 60; ++i) {
+      double t = 0, dt = 0;
+      if (live) {
+        const double w = 1.0 / (eta_n * lam + 1.0);
+        const double m_ = (eta_n + 1.0) * lam * w;
+        t = m_ - 1.0 - log(m_);
+        dt = (1.0 - 1.0 / m_) * lam * (1.0 - lam) * w * w;
+      }
+      const double hv = 0.5 * wave_sum_f64(t) - eps_cov;
+      const double dh = 0.5 * wave_sum_f64(dt);
+      if (hv > 0) lo = eta_n; else hi = eta_n;
+      double nxt = eta_n - hv / dh;
+      if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+      if (fabs(nxt - eta_n) <= 1e-15 * fabs(nxt)) { eta_n = nxt; break; }
+      eta_n = nxt;
+    }
+    eta = eta_n;
+    mu = (eta + 1.0) * lam / (eta * lam + 1.0);
+  }
+  const double pl = active ? so * sqrt(mu) : sig;
+  // the matrices (diagonal; everything else zero)
+  __shared__ float dg[3][64];
+  dg[0][k] = (float)sig;
+  dg[1][k] = (float)pl;
+  dg[2][k] = include_cov ? (float)((double)tr_coeff * (sig / (pl * pl) - 1.0 / sig)) : 0.f;
+  __syncthreads();
+  for (int e = k; e < K * K; e += 64) {
+    const int i = e / K, j = e - i * K;
+    L_new[e] = i == j ? dg[0][i] : 0.f;
+    L_proj[e] = i == j ? dg[1][i] : 0.f;
+    gL_tr[e] = i == j ? dg[2][i] : 0.f;
+  }
+  if (live) {
+    dctx[k] = lam;
+    dctx[K + k] = mu;
+  }
+  // covariance halves of (new || old), (new || proj), (proj || old)
+  const double r0 = sig / so, r1 = sig / pl, r2 = pl / so;
+  const double f0 = wave_sum_f64(live ? r0 * r0 : 0.0), l0 = wave_sum_f64(live ? log(r0) : 0.0);
+  const double f1 = wave_sum_f64(live ? r1 * r1 : 0.0), l1 = wave_sum_f64(live ? log(r1) : 0.0);
+  const double f2 = wave_sum_f64(live ? r2 * r2 : 0.0), l2 = wave_sum_f64(live ? log(r2) : 0.0);
+  const double lpld = wave_sum_f64(live ? log(pl) : 0.0);
+  if (k == 0) {
+    const double f[3] = {f0, f1, f2}, l[3] = {l0, l1, l2};
+    for (int q = 0; q < 3; ++q) {
+      const double shape = 0.5 * (f[q] - (double)K), volume = -l[q];
+      out16[4 * q + 0] = 0.f;                            // mean part: the finish kernel
+      out16[4 * q + 1] = (float)(shape + volume);
+      out16[4 * q + 2] = (float)shape;
+      out16[4 * q + 3] = (float)volume;
+    }
+    out16[12] = (float)(0.5 * (double)K * (1.0 + 1.8378770664093453) + lpld);
+    out16[13] = 0.f;
+    out16[14] = 0.f;
+    out16[15] = 0.f;
+    dctx[2 * K] = eta;
+    dctx[2 * K + 1] = active ? 1.0 : 0.0;
+  }
+}
+
+// finish of a black-box policy epoch (one workgroup): the mean parts of the KL
+// terms and the trust region loss from the Mahalanobis sums, the corrections
+// on the diagonal of d / d L_proj, -- diagonal factors -- the covariance
+// projection's backward, g_L = dTR/dL_new + projection backward, Cholesky head
+// backward into the variance slots of the flat gradient, global norm, clip
+// factor, Adam, record row {surrogate, entropy loss, trust region loss, total,
+// entropy, |g|, |g| clipped}.
+// phase 0 (general factors): only the corrections of g_pL (before
+//   tce_kl_cov_proj_bwd); phase 1: everything else; diag != 0: both at once.
 __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
-    const float* __restrict__ gL_tr, const float* __restrict__ gL_p, int K, int nvec, int P,
-    float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
-    float* __restrict__ v, float* __restrict__ state, float lr, float b1, float b2, float eps,
-    float wd, float clip_grad, float gscale, int do_adam, const float* __restrict__ sur2,
-    const float* __restrict__ out16, float ent_coef, float* __restrict__ rec) {
+    int phase, int diag, float* __restrict__ g_pL, const float* __restrict__ gL_tr,
+    const float* __restrict__ gL_p, const float* __restrict__ L_proj,
+    const float* __restrict__ L_old, const double* __restrict__ dctx,
+    const double* __restrict__ dsum, int64_t N, int K, int nvec, int P, float tr_coeff,
+    int include_cov, float ent_coef, float* __restrict__ param, float* __restrict__ grad,
+    float* __restrict__ m, float* __restrict__ v, float* __restrict__ state, float lr, float b1,
+    float b2, float eps, float wd, float clip_grad, float gscale, int do_adam,
+    float* __restrict__ out16, float* __restrict__ rec) {
   __shared__ float red[SNW];
   __shared__ float coef_s, step_s;
+  __shared__ double gsh[64];
   const int tid = threadIdx.x;
+  const double invN = 1.0 / (double)N;
+  const float sum_g = (float)(-dsum[0] * invN);          // sum over rows of d surrogate / d logp
+  if (phase == 0 || diag) {
+    for (int e = tid; e < K * K; e += SBT) {
+      const int i = e / K, j = e - i * K;
+      float x = j <= i ? g_pL[e] : 0.f;
+      if (i == j) x -= (sum_g + ent_coef) / L_proj[e];
+      g_pL[e] = x;
+    }
+    if (phase == 0 && !diag) return;
+    __syncthreads();
+  }
   const float* var = param + P;
+  if (diag) {
+    // covariance projection backward on the diagonal
+    const double eta = dctx[2 * K];
+    const bool active = dctx[2 * K + 1] != 0.0;
+    if (tid < 64) {                                      // wave 0, all lanes take part in the sums
+      const int k = tid;
+      const bool live = k < K;
+      double gp = 0, gmu = 0, dl = 0, de = 0, hm = 0, scale = 0;
+      if (live) {
+        gp = (double)g_pL[k * K + k];
+        if (active) {
+          const double lam = dctx[k], mu = dctx[K + k];
+          const double so = (double)L_old[k * K + k], pl = (double)L_proj[k * K + k];
+          const double w = 1.0 / (eta * lam + 1.0);
+          gmu = gp * pl / (2.0 * mu);                    // d / d mu_k
+          dl = (eta + 1.0) * w * w;                      // d mu_k / d lambda_k
+          de = lam * (1.0 - lam) * w * w;                // d mu_k / d eta
+          hm = 0.5 * (1.0 - 1.0 / mu);                   // d h / d mu_k
+          scale = 2.0 * sqrt(lam) / so;                  // d lambda_k / d sigma_k
+        }
+      }
+      const double h_eta = wave_sum_f64(hm * de);
+      const double gde = wave_sum_f64(gmu * de);
+      double gs = gp;
+      if (active) gs = (gmu * dl - gde * (hm * dl) / h_eta) * scale;
+      gsh[k] = live ? gs : 0.0;
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < nvec; i += SBT) {
     float gv;
     if (i < K) {
       const float x = var[i];
       const float sig = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
-      gv = (gL_tr[i * K + i] + gL_p[i * K + i]) * sig;
+      const float gl = diag ? (float)gsh[i] : gL_p[i * K + i];
+      gv = (gL_tr[i * K + i] + gl) * sig;
     } else {
       const int t = i - K;
       int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
@@ -748,11 +882,20 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
       step_s = step;
     }
     coef_s = coef * gscale;
+    // mean parts of the KL terms (new || old), (new || proj), (proj || old)
+    double mp[3];
+    for (int q = 0; q < 3; ++q) {
+      mp[q] = 0.5 * dsum[2 + q] * invN;
+      out16[4 * q] = (float)mp[q];
+    }
+    const double tr = (double)tr_coeff * (mp[1] + (include_cov ? (double)out16[5] : 0.0));
+    out16[13] = (float)tr;
+    const float sur = (float)(-dsum[0] * invN);
     const float entl = ent_coef == 0.f ? 0.f : -ent_coef * out16[12];
-    rec[0] = sur2[0];
+    rec[0] = sur;
     rec[1] = entl;
-    rec[2] = out16[13];
-    rec[3] = ent_coef == 0.f ? sur2[0] + out16[13] : sur2[0] + out16[13] + entl;
+    rec[2] = (float)tr;
+    rec[3] = ent_coef == 0.f ? sur + (float)tr : sur + (float)tr + entl;
     rec[4] = out16[12];
     rec[5] = before;
     rec[6] = before * coef;
@@ -815,6 +958,22 @@ int s_launch_forward(const SNet& n, float* out, hipStream_t st) {
   return 0;
 }
 
+inline void s_reduce_ws(float* ws, int64_t N, int din, int H, int dout, SReduce& rd) {
+  const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
+  const int64_t g = s_grid(N);
+  rd.slabs = ws;
+  rd.dpart = reinterpret_cast<double*>(ws + g * PS);
+  rd.PS = (int)PS;
+  rd.P = s_nparams(din, H, dout);
+}
+
+inline int s_launch_reduce(const SFinish& f, hipStream_t st) {
+  const unsigned grid = (unsigned)ceil_div(f.P + f.KK, 64);
+  hipLaunchKernelGGL(smlp_reduce_kernel, dim3(grid), dim3(64 * FIN_GROUPS), 0, st, f);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -826,11 +985,11 @@ int tce_smlp_supported(int din, int H, int dout, int head) {
 
 int64_t tce_smlp_num_params(int din, int H, int dout) { return s_nparams(din, H, dout); }
 
-// floats: gradient slabs [grid][P + dout^2 (+ pad)], then doubles [grid][8], then the ticket
+// floats: gradient slabs [grid][P + dout^2 (+ pad)], then doubles [grid][8] and 8 more
 int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout) {
   const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
   const int64_t g = s_grid(N);
-  return g * PS + 2 * (g * 8) + 8;
+  return g * PS + 2 * (g * 8) + 2 * 8 + 8;
 }
 
 int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, int H, int dout,
@@ -849,42 +1008,47 @@ int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, i
   return 1;
 }
 
-static void s_reduce_ws(float* ws, int64_t N, int din, int H, int dout, SReduce& rd) {
-  const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
-  const int64_t g = s_grid(N);
-  rd.slabs = ws;
-  rd.dpart = reinterpret_cast<double*>(ws + g * PS);
-  rd.ticket = reinterpret_cast<unsigned*>(ws + g * PS + 2 * (g * 8));
-  rd.PS = (int)PS;
-  rd.P = s_nparams(din, H, dout);
-}
-
 int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* returns,
                                const float* old_values, int64_t N, int din, int H, int act,
                                float clip_critic, float* param, float* grad, float* m, float* v,
                                float* opt_state, float lr, float beta1, float beta2, float eps,
                                float weight_decay, float clip_grad, float grad_scale, int do_adam,
-                               int epochs, float* ws, float* rec, void* stream) {
+                               int first_step, int epochs, float* ws, float* rec, void* stream) {
   TCE_CHECK_ARG(x && returns && param && grad && ws && rec && N > 0 && epochs > 0,
                 "smlp_critic_epochs: null buffer / empty batch");
   TCE_CHECK_ARG(!(clip_critic > 0.f) || old_values, "smlp_critic_epochs: old values missing");
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "smlp_critic_epochs: optimizer state missing");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, 1, HEAD_VALUE), "smlp_critic_epochs: unsupported shape");
   TCE_CHECK_ARG(x_stride >= din, "smlp_critic_epochs: row stride < din");
-  TCE_CHECK_ARG(do_adam || epochs == 1, "smlp_critic_epochs: epochs > 1 needs the fused Adam step");
+  TCE_CHECK_ARG(do_adam || epochs == 1, "smlp_critic_epochs: epochs > 1 needs the Adam step");
+  hipStream_t st = (hipStream_t)stream;
   const SNet n{x, x_stride, N, din, 1, param};
   const SValueHead vh{returns, old_values, clip_critic};
   const SPolicyHead ph{};
   SReduce rd{};
   s_reduce_ws(ws, N, din, H, 1, rd);
-  rd.grad = grad;
-  rd.param = param; rd.m = m; rd.v = v; rd.state = opt_state;
-  rd.lr = lr; rd.b1 = beta1; rd.b2 = beta2; rd.eps = eps; rd.wd = weight_decay;
-  rd.clip_grad = clip_grad; rd.gscale = grad_scale; rd.do_adam = do_adam;
+  const int g = s_grid(N);
+  double* dsum = rd.dpart + (int64_t)g * 8;
+  // the Adam step rides on the slab reduction unless the clip factor needs the norm first
+  const bool fuse = do_adam && !(clip_grad > 0.f);
   for (int e = 0; e < epochs; ++e) {
-    rd.rec = rec + 3 * e;
-    const int rc = s_dispatch_epoch<HEAD_VALUE>(H, act, n, vh, ph, rd, (hipStream_t)stream);
+    int rc = s_dispatch_epoch<HEAD_VALUE>(H, act, n, vh, ph, rd, st);
     if (rc) return rc;
+    SFinish f{};
+    f.slabs = rd.slabs; f.dpart = rd.dpart; f.nparts = g; f.PS = rd.PS; f.P = rd.P; f.KK = 0;
+    f.N = N; f.grad = grad; f.extra = nullptr; f.dsum = dsum; f.stats = rec + 3 * e;
+    if (fuse) {
+      f.param = param; f.m = m; f.v = v; f.state = opt_state;
+      f.lr = lr; f.b1 = beta1; f.b2 = beta2; f.eps = eps; f.wd = weight_decay;
+      f.step = (float)(first_step + e); f.gscale = grad_scale;
+    }
+    rc = s_launch_reduce(f, st);
+    if (rc) return rc;
+    if (do_adam && !fuse) {
+      rc = tce_adam_flat_f32(param, grad, m, v, rd.P, opt_state, rec + 3 * e + 1, lr, beta1, beta2,
+                             eps, weight_decay, clip_grad, grad_scale, stream);
+      if (rc) return rc;
+    }
   }
   return 0;
 }
@@ -897,61 +1061,81 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              int tr_include_cov, float ent_coef, float* param, float* grad,
                              float* m, float* v, float* opt_state, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float clip_grad,
-                             float grad_scale, int do_adam, int epochs, double* proj_ctx,
-                             float* ws, float* mats, float* rec, float* mean_new_out,
-                             float* proj_mean_out, void* stream) {
+                             float grad_scale, int do_adam, int diag, int epochs,
+                             double* proj_ctx, float* ws, float* mats, float* rec,
+                             float* mean_new_out, float* proj_mean_out, void* stream) {
   TCE_CHECK_ARG(x && actions && logp_old && adv && mean_old && L_old && param && grad &&
                     proj_ctx && ws && mats && rec && N > 0 && epochs > 0,
                 "bb_policy_epochs: null buffer / empty batch");
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "bb_policy_epochs: optimizer state missing");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, K, HEAD_BB_POLICY), "bb_policy_epochs: unsupported shape");
   TCE_CHECK_ARG(nvec == K || nvec == K + K * (K - 1) / 2, "bb_policy_epochs: bad variance vector");
+  TCE_CHECK_ARG(!diag || (nvec == K && beta == nullptr),
+                "bb_policy_epochs: the diagonal path needs std_only and no entropy bound");
   TCE_CHECK_ARG(x_stride >= din, "bb_policy_epochs: row stride < din");
-  TCE_CHECK_ARG(do_adam || epochs == 1, "bb_policy_epochs: epochs > 1 needs the fused Adam step");
+  TCE_CHECK_ARG(do_adam || epochs == 1, "bb_policy_epochs: epochs > 1 needs the Adam step");
   hipStream_t st = (hipStream_t)stream;
   const int P = s_nparams(din, H, K);
   const int KK = s_up4(K * K);
-  // mats: L_new | L_proj | g_pL | gL_tr | gL_p  [K,K] each, then sur2 [2] | out16 [16],
-  // then (8-byte aligned) dsum double[3]
+  // mats: L_new | L_proj | g_pL | gL_tr | gL_p  [K,K] each, then out16 [16]
   float* L_new = mats;
   float* L_proj = L_new + KK;
   float* g_pL = L_proj + KK;
   float* gL_tr = g_pL + KK;
   float* gL_p = gL_tr + KK;
-  float* sur2 = gL_p + KK;
-  float* out16 = sur2 + 4;
-  double* dsum = reinterpret_cast<double*>(out16 + 16);
+  float* out16 = gL_p + KK;
   SNet n{x, x_stride, N, din, K, param};
   const SValueHead vh{};
   SReduce rd{};
   s_reduce_ws(ws, N, din, H, K, rd);
-  rd.grad = grad;
-  rd.g_pL = g_pL; rd.sur2 = sur2; rd.dsum = dsum;
+  const int g = s_grid(N);
+  double* dsum = rd.dpart + (int64_t)g * 8;
+  double* zero3 = dsum + 8;                       // stays zero: the K x K parts without the mean sums
   for (int e = 0; e < epochs; ++e) {
     const bool lastep = e == epochs - 1;
-    int rc = tce_chol_build_fwd_f32(param + P, L_new, 1, K, nvec, min_std, stream);
-    if (rc) return rc;
-    rc = tce_kl_cov_proj_fwd_f32(L_new, L_old, 0, eps_cov, beta, entropy_eq, L_proj, proj_ctx, 1,
-                                 K, 1, stream);
-    if (rc) return rc;
+    int rc;
+    if (diag) {
+      hipLaunchKernelGGL(bb_diag_fwd_kernel, dim3(1), dim3(64), 0, st, param + P, min_std, L_old, K,
+                         eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, gL_tr, out16, proj_ctx);
+      TCE_LAUNCH_CHECK();
+    } else {
+      rc = tce_chol_build_fwd_f32(param + P, L_new, 1, K, nvec, min_std, stream);
+      if (rc) return rc;
+      rc = tce_kl_cov_proj_fwd_f32(L_new, L_old, 0, eps_cov, beta, entropy_eq, L_proj, proj_ctx,
+                                   1, K, 1, stream);
+      if (rc) return rc;
+      rc = tce_kl_shared_mat_f32(L_new, L_old, L_proj, N, K, tr_coeff, tr_include_cov, zero3, 1,
+                                 out16, gL_tr, stream);
+      if (rc) return rc;
+    }
     const SPolicyHead ph{actions, logp_old, adv, mean_old, L_old, L_proj, eps_mean, tr_coeff,
                          ent_coef, lastep ? mean_new_out : nullptr,
                          lastep ? proj_mean_out : nullptr};
     rc = s_dispatch_epoch<HEAD_BB_POLICY>(H, act, n, vh, ph, rd, st);
     if (rc) return rc;
-    rc = tce_kl_shared_mat_f32(L_new, L_old, L_proj, N, K, tr_coeff, tr_include_cov, dsum, 1,
-                               out16, gL_tr, stream);
+    SFinish f{};
+    f.slabs = rd.slabs; f.dpart = rd.dpart; f.nparts = g; f.PS = rd.PS; f.P = P; f.KK = K * K;
+    f.N = N; f.grad = grad; f.extra = g_pL; f.dsum = dsum; f.stats = nullptr;
+    rc = s_launch_reduce(f, st);
     if (rc) return rc;
-    rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, gL_tr, gL_p, K, nvec, P,
-                       param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,
-                       grad_scale, do_adam, sur2, out16, ent_coef, rec + 7 * e);
+    if (!diag) {
+      hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 0, 0, g_pL, gL_tr,
+                         gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff,
+                         tr_include_cov, ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2,
+                         eps, weight_decay, clip_grad, grad_scale, do_adam, out16, rec + 7 * e);
+      TCE_LAUNCH_CHECK();
+      rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 1, diag, g_pL, gL_tr,
+                       gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff, tr_include_cov,
+                       ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,
+                       clip_grad, grad_scale, do_adam, out16, rec + 7 * e);
     TCE_LAUNCH_CHECK();
   }
   return 0;
 }
 
-int64_t tce_bb_policy_mats_len(int K) { return 5 * (int64_t)s_up4(K * K) + 4 + 16 + 8; }
+int64_t tce_bb_policy_mats_len(int K) { return 5 * (int64_t)s_up4(K * K) + 16; }
 
 }  // extern "C"

@@ -2,7 +2,8 @@
 row kernels of csrc/smlp.hip (D_in <= 64 -> H -> H -> D_out, H in {32, 64},
 float32): rollout forward, the critic update and the policy update of
 ``BlackBoxAgent`` (mprl/rl/agent/black_box_agent.py:105-389) without autograd
-and without library GEMMs -- one launch per critic epoch, six per policy epoch.
+and without library GEMMs -- two launches per critic epoch, four (diagonal
+covariance, the reference's BBRL configuration) or seven per policy epoch.
 """
 import torch
 
@@ -107,10 +108,18 @@ def critic_update(agent, states, returns, old_values):
              ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
              float(g["weight_decay"]), float(agent.clip_grad_norm), scale,
-             int(do_adam), epochs, ptr(ws), ptr(rec_rows), stream())
+             int(do_adam), opt.host_step + 1, epochs, ptr(ws), ptr(rec_rows),
+             stream())
     if not agent.dist.active:
         launch(E, True, rec, 1.0)
         opt.host_step += E
+        # the kernels leave |g|^2: the two norms of grad_norm_clip from it
+        before = rec[:, 1].sqrt()
+        after = before
+        if agent.clip_grad_norm > 0:
+            after = before * torch.clamp(
+                agent.clip_grad_norm / (before + 1e-6), max=1.0)
+        rec[:, 1], rec[:, 2] = before, after
     else:
         for e in range(E):
             launch(1, False, rec[e], 1.0)
@@ -159,6 +168,11 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     beta_t = None if beta is None else \
         c(beta.detach().to(torch.float32).reshape(1))
     include_cov = int(pol.contextual_std or not agent.set_variance)
+    # diagonal factors (std_only) without an entropy bound: K-vector kernels
+    # instead of the K x K ones (TCE_BB_DIAG=0: the general kernels, for tests)
+    import os
+    diag = int(pol.std_only and beta_t is None and
+               os.environ.get("TCE_BB_DIAG", "1") != "0")
     g = opt.param_groups[0]
     opt.bind_grads()
 
@@ -173,9 +187,9 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
              ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v), ptr(opt.dev_state),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
              float(g["eps"]), float(g["weight_decay"]),
-             float(agent.clip_grad_norm), 1.0, int(do_adam), epochs, ptr(ctx),
-             ptr(ws), ptr(mats), ptr(rec_rows), ptr(mean_new), ptr(proj_mean),
-             stream())
+             float(agent.clip_grad_norm), 1.0, int(do_adam), diag, epochs,
+             ptr(ctx), ptr(ws), ptr(mats), ptr(rec_rows), ptr(mean_new),
+             ptr(proj_mean), stream())
     if not agent.dist.active:
         launch(E, True, rec)
         opt.host_step += E

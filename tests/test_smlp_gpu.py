@@ -134,11 +134,14 @@ def test_critic_epochs_are_deterministic():
     assert torch.equal(*outs)
 
 
-@pytest.mark.parametrize("std_only,K,H,N,ent,set_var", [
-    (True, 20, 32, 300, 0.0, True), (False, 12, 32, 130, 0.01, False),
-    (False, 20, 64, 64, 0.0, False), (True, 6, 32, 4096, 0.0, False)])
-def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, N, ent,
-                                               set_var):
+@pytest.mark.parametrize("std_only,K,H,din,N,ent,set_var", [
+    (True, 20, 32, 39, 300, 0.0, True), (False, 12, 32, 39, 130, 0.01, False),
+    (False, 12, 64, 16, 64, 0.0, False), (True, 6, 32, 9, 4096, 0.0, False),
+    (False, 33, 32, 39, 77, 0.0, False)])
+@pytest.mark.parametrize("diag_kernels", [True, False])
+def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
+                                               set_var, diag_kernels,
+                                               monkeypatch):
     """E policy epochs on the row kernels == E epochs built from the CPU
     oracle's pieces (oracle/kl_oracle.py project / trust_region_loss,
     oracle/tce_oracle.py mvn_log_prob / surrogate_loss) with torch autograd
@@ -149,7 +152,11 @@ def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, N, ent,
     from tce_rl_amd.optim import FlatAdam
     from tce_rl_amd.rl.policy import BlackBoxPolicy
     from tce_rl_amd.rl import projection_factory
-    din, E, act = 39, 3, "relu"
+    E, act = 3, "relu"
+    if not diag_kernels:
+        if not std_only:
+            pytest.skip("full factors always take the K x K kernels")
+        monkeypatch.setenv("TCE_BB_DIAG", "0")    # std_only on the general kernels
     torch.manual_seed(4)
     pol = BlackBoxPolicy(
         dim_in=din, dim_out=K,
