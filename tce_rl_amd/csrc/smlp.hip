@@ -66,6 +66,30 @@ __host__ __device__ inline int s_nparams(int din, int H, int dout) {
 
 enum { HEAD_NONE = 0, HEAD_VALUE = 1, HEAD_BB_POLICY = 2 };
 
+// ACT_RT: the activation is a kernel argument (the policy kernels, which come
+// in one variant per padded K instead of one per activation)
+constexpr int ACT_RT = 4;
+template <int ACT>
+__device__ inline float s_actf(float y, int rt) {
+  if (ACT != ACT_RT) return act_f < ACT == ACT_RT ? 0 : ACT > (y);
+  switch (rt) {
+    case ACT_TANH: return act_f<ACT_TANH>(y);
+    case ACT_RELU: return act_f<ACT_RELU>(y);
+    case ACT_LEAKY: return act_f<ACT_LEAKY>(y);
+    default: return act_f<ACT_SOFTPLUS>(y);
+  }
+}
+template <int ACT>
+__device__ inline float s_actd(float h, int rt) {
+  if (ACT != ACT_RT) return act_d < ACT == ACT_RT ? 0 : ACT > (h);
+  switch (rt) {
+    case ACT_TANH: return act_d<ACT_TANH>(h);
+    case ACT_RELU: return act_d<ACT_RELU>(h);
+    case ACT_LEAKY: return act_d<ACT_LEAKY>(h);
+    default: return act_d<ACT_SOFTPLUS>(h);
+  }
+}
+
 // LDS map (offsets in floats, all multiples of 4)
 struct SLds {
   int w1t, w2, w2t, w3, b1, b2, b3;      // weight images
@@ -119,6 +143,7 @@ struct SNet {
   int64_t N;
   int din, dout;
   const float* param;        // flat: W1 [H][din] | b1 | W2 [H][H] | b2 | W3 [dout][H] | b3
+  int act;                   // activation (read by the ACT_RT variants)
 };
 
 struct SValueHead {
@@ -199,7 +224,8 @@ __device__ inline void s_load_x(const SLds& L, float* S, const SNet& n, int64_t 
 // the output goes to out[o * 64 + lane] (LDS, [dout][64])
 template <int H, int ACT>
 __device__ inline void s_forward(const SLds& L, float* S, int dout, int lane, int wave,
-                                 float (&h1)[H / SNW], float (&h2)[H / SNW], float* out) {
+                                 float (&h1)[H / SNW], float (&h2)[H / SNW], float* out,
+                                 int rt_act) {
   constexpr int US = H / SNW;
   const int u0 = wave * US;
   float acc[US];
@@ -219,7 +245,7 @@ __device__ inline void s_forward(const SLds& L, float* S, int dout, int lane, in
     }
   }
 #pragma unroll
-  for (int u = 0; u < US; ++u) h1[u] = act_f<ACT>(acc[u]);
+  for (int u = 0; u < US; ++u) h1[u] = s_actf<ACT>(acc[u], rt_act);
 #pragma unroll
   for (int u = 0; u < US; u += 4)
     *reinterpret_cast<f32x4*>(S + L.h1s + lane * L.hp + u0 + u) =
@@ -244,7 +270,7 @@ __device__ inline void s_forward(const SLds& L, float* S, int dout, int lane, in
     }
   }
 #pragma unroll
-  for (int u = 0; u < US; ++u) h2[u] = act_f<ACT>(acc[u]);
+  for (int u = 0; u < US; ++u) h2[u] = s_actf<ACT>(acc[u], rt_act);
 #pragma unroll
   for (int u = 0; u < US; u += 4)
     *reinterpret_cast<f32x4*>(S + L.h2s + lane * L.hp + u0 + u) =
@@ -273,7 +299,7 @@ __device__ inline void s_forward(const SLds& L, float* S, int dout, int lane, in
 template <int H, int ACT>
 __device__ inline void s_backward(const SLds& L, float* S, int dout, int lane, int wave,
                                   const float (&h1)[H / SNW], const float (&h2)[H / SNW],
-                                  const float* g) {
+                                  const float* g, int rt_act) {
   constexpr int US = H / SNW;
   const int u0 = wave * US;
   float acc[US];
@@ -293,7 +319,7 @@ __device__ inline void s_backward(const SLds& L, float* S, int dout, int lane, i
   for (int u = 0; u < US; u += 4) {
     f32x4 t;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * act_d<ACT>(h2[u + q]);
+    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * s_actd<ACT>(h2[u + q], rt_act);
     *reinterpret_cast<f32x4*>(S + L.d2s + lane * L.hp + u0 + u) = t;
   }
   __syncthreads();
@@ -319,7 +345,7 @@ __device__ inline void s_backward(const SLds& L, float* S, int dout, int lane, i
   for (int u = 0; u < US; u += 4) {
     f32x4 t;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * act_d<ACT>(h1[u + q]);
+    for (int q = 0; q < 4; ++q) t[q] = acc[u + q] * s_actd<ACT>(h1[u + q], rt_act);
     *reinterpret_cast<f32x4*>(S + L.d1s + lane * L.hp + u0 + u) = t;
   }
   __syncthreads();
@@ -525,6 +551,166 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
   sums[4] = wave_sum_f64(f * (double)quad / ((double)den * (double)den));
 }
 
+// The same head with the K-vectors in REGISTERS (K <= KP <= 32, loops unrolled
+// over the padded length, rows / columns past K skipped by uniform branches):
+// the [k][lane] LDS vectors above make every step of a triangular solve two
+// dependent LDS round trips -- 60 of the row kernel's 80 us at K = 20.
+template <int KP>
+__device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyHead& h,
+                                         int64_t r0, int64_t N, int K, int lane, float logdet_p,
+                                         double (&sums)[5]) {
+  const int VS = L.doutp * SR;
+  const float* MU = S + L.vec;
+  const float* MO = MU + VS;
+  float* AC = S + L.vec + 2 * VS;
+  const float* Lo = S + L.lo;
+  const float* Lp = S + L.lp;
+  const float* rdo = S + L.rdo;
+  const float* rdp = S + L.rdp;
+  const int64_t row = r0 + lane;
+  const bool rok = row < N;
+  const int64_t rc = rok ? row : N - 1;
+  float mu[KP], mo[KP], z[KP], y[KP], w[KP];
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    const int rr = r < K ? r : K - 1;
+    mu[r] = MU[rr * SR + lane];
+    mo[r] = MO[rr * SR + lane];
+    if (r >= K) { mu[r] = 0.f; mo[r] = 0.f; }
+  }
+  // z = L_old^-1 (mu - mu_old)
+  float quad = 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    z[r] = 0.f;
+    if (r < K) {
+      float a0 = mu[r] - mo[r], a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k + 1 < r; k += 2) {
+        a0 -= Lo[r * K + k] * z[k];
+        a1 -= Lo[r * K + k + 1] * z[k + 1];
+      }
+      if (r & 1) a0 -= Lo[r * K + r - 1] * z[r - 1];
+      z[r] = (a0 + a1) * rdo[r];
+      quad += z[r] * z[r];
+    }
+  }
+  const float m = 0.5f * quad;
+  const bool active = m > h.eps_mean;
+  const float sc = active ? sqrtf(m / h.eps_mean) : 1.f;
+  const float om = sc - 1.f;
+  const float den = 1.f + om + 1e-16f;
+  // y = L_proj^-1 (a - proj_mean); w starts as mu - proj_mean
+  float quady = 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    y[r] = 0.f;
+    w[r] = 0.f;
+    if (r < K) {
+      const float pm = active ? (mu[r] + om * mo[r]) / den : mu[r];
+      if (h.pmean_out && rok) h.pmean_out[row * K + r] = pm;
+      if (h.mean_out && rok) h.mean_out[row * K + r] = mu[r];
+      float a0 = AC[r * SR + lane] - pm, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k + 1 < r; k += 2) {
+        a0 -= Lp[r * K + k] * y[k];
+        a1 -= Lp[r * K + k + 1] * y[k + 1];
+      }
+      if (r & 1) a0 -= Lp[r * K + r - 1] * y[r - 1];
+      y[r] = (a0 + a1) * rdp[r];
+      quady += y[r] * y[r];
+      w[r] = mu[r] - pm;
+    }
+  }
+  const float logp = -0.5f * quady - logdet_p - S_HALF_LOG_2PI * (float)K;
+  const float ratio = expf(logp - h.logp_old[rc]);
+  const float ra = ratio * h.adv[rc];
+  const float g = rok ? -ra / (float)N : 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r)
+    if (r < K) S[L.ys + lane * L.gp + r] = y[r];
+  // u = L_proj^-T y (in place)
+#pragma unroll
+  for (int r = KP - 1; r >= 0; --r) {
+    if (r < K) {
+      float a0 = y[r], a1 = 0.f;
+#pragma unroll
+      for (int k = r + 1; k < KP; ++k) {
+        const int kk = k < K ? k : K - 1;             // y[k] = 0 past K
+        if ((k - r) & 1) a0 -= Lp[kk * K + r] * y[k]; else a1 -= Lp[kk * K + r] * y[k];
+      }
+      y[r] = (a0 + a1) * rdp[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KP; ++r)
+    if (r < K) S[L.gus + lane * L.gp + r] = g * y[r];
+  // w = L_proj^-1 (mu - proj_mean), then q = L_proj^-T w (in place)
+  float maha2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    if (r < K) {
+      float a0 = w[r], a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k + 1 < r; k += 2) {
+        a0 -= Lp[r * K + k] * w[k];
+        a1 -= Lp[r * K + k + 1] * w[k + 1];
+      }
+      if (r & 1) a0 -= Lp[r * K + r - 1] * w[r - 1];
+      w[r] = (a0 + a1) * rdp[r];
+      maha2 += w[r] * w[r];
+    }
+  }
+#pragma unroll
+  for (int r = KP - 1; r >= 0; --r) {
+    if (r < K) {
+      float a0 = w[r], a1 = 0.f;
+#pragma unroll
+      for (int k = r + 1; k < KP; ++k) {
+        const int kk = k < K ? k : K - 1;
+        if ((k - r) & 1) a0 -= Lp[kk * K + r] * w[k]; else a1 -= Lp[kk * K + r] * w[k];
+      }
+      w[r] = (a0 + a1) * rdp[r];
+    }
+  }
+  // back through the mean projection: t = L_old^-T z (in place)
+  float gd = 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) gd += g * y[r] * (mu[r] - mo[r]);
+  if (__builtin_amdgcn_ballot_w64(active) != 0) {      // no row of the wave is projected: skip
+#pragma unroll
+    for (int r = KP - 1; r >= 0; --r) {
+      if (r < K) {
+        float a0 = z[r], a1 = 0.f;
+#pragma unroll
+        for (int k = r + 1; k < KP; ++k) {
+          const int kk = k < K ? k : K - 1;
+          if ((k - r) & 1) a0 -= Lo[kk * K + r] * z[k]; else a1 -= Lo[kk * K + r] * z[k];
+        }
+        z[r] = (a0 + a1) * rdo[r];
+      }
+    }
+  }
+  const float coef = active ? gd / (2.f * h.eps_mean * sc * sc * sc) : 0.f;
+  const float trc = rok ? h.tr_coeff / (float)N : 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    if (r < K) {
+      const float gp = g * y[r];
+      float gm = active ? gp / sc - coef * z[r] : gp;
+      gm += trc * w[r];
+      AC[r * SR + lane] = gm;
+      S[L.g3s + lane * L.gp + r] = gm;
+    }
+  }
+  const double f = rok ? 1.0 : 0.0;
+  sums[0] = wave_sum_f64(f * (double)ra);
+  sums[1] = wave_sum_f64(f * (double)ratio);
+  sums[2] = wave_sum_f64(f * (double)quad);
+  sums[3] = wave_sum_f64(f * (double)maha2);
+  sums[4] = wave_sum_f64(f * (double)quad / ((double)den * (double)den));
+}
+
 // ---------------------------------------------------------------------------
 template <int H, int ACT>
 __global__ __launch_bounds__(SBT) void smlp_forward_kernel(SNet n, float* __restrict__ out) {
@@ -538,7 +724,7 @@ __global__ __launch_bounds__(SBT) void smlp_forward_kernel(SNet n, float* __rest
     s_load_x(L, S, n, r0);
     __syncthreads();
     float h1[H / SNW], h2[H / SNW];
-    s_forward<H, ACT>(L, S, n.dout, lane, wave, h1, h2, ov);
+    s_forward<H, ACT>(L, S, n.dout, lane, wave, h1, h2, ov, n.act);
     for (int e = threadIdx.x; e < SR * n.dout; e += SBT) {
       const int r = e / n.dout, o = e - r * n.dout;
       if (r0 + r < n.N) out[(r0 + r) * n.dout + o] = ov[o * SR + r];
@@ -551,7 +737,7 @@ __host__ __device__ inline int s_forward_lds_floats(int din, int H, int dout) {
   return L.vec + s_up4(dout) * SR + 16;
 }
 
-template <int H, int ACT, int HEAD>
+template <int H, int ACT, int HEAD, int KP>
 __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, SPolicyHead ph,
                                                         SReduce rd) {
   extern __shared__ __attribute__((aligned(16))) float S[];
@@ -589,7 +775,7 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
     }
     __syncthreads();
     float h1[H / SNW], h2[H / SNW];
-    s_forward<H, ACT>(L, S, K, lane, wave, h1, h2, vecs);
+    s_forward<H, ACT>(L, S, K, lane, wave, h1, h2, vecs, n.act);
     const float* g;
     if (HEAD == HEAD_VALUE) {
       if (wave == 0) acc_d[0] += s_value_head(L, S, vh, r0, n.N, lane, vecs, vecs + SR);
@@ -597,14 +783,15 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
     } else {
       if (wave == 0) {
         double s5[5];
-        s_policy_head(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
+        if (KP > 0) s_policy_head_reg<(KP > 0 ? KP : 4)>(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
+        else s_policy_head(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
 #pragma unroll
         for (int i = 0; i < 5; ++i) acc_d[i] += s5[i];
       }
       g = vecs + 2 * L.doutp * SR;                     // AC slot
     }
     __syncthreads();
-    s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g);
+    s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g, n.act);
     s_param_grads<H>(L, S, n.din, K, slab, !first);
     if (HEAD == HEAD_BB_POLICY) {
       // d logp / d L_proj summed over the rows: sum g u y^T (lower triangle used)
@@ -927,25 +1114,40 @@ inline size_t s_lds_bytes(int din, int H, int dout, int head) {
 }
 inline int s_grid(int64_t N) { return (int)tmin<int64_t>(ceil_div(N, SR), S_MAX_GRID); }
 
-template <int H, int ACT, int HEAD>
+template <int H, int ACT, int HEAD, int KP>
 int s_launch_epoch(const SNet& n, const SValueHead& vh, const SPolicyHead& ph, const SReduce& rd,
                    hipStream_t st) {
   const size_t lds = s_lds_bytes(n.din, H, n.dout, HEAD);
-  tce_lds_limit(reinterpret_cast<const void*>(smlp_epoch_kernel<H, ACT, HEAD>), lds);
-  hipLaunchKernelGGL((smlp_epoch_kernel<H, ACT, HEAD>), dim3(s_grid(n.N)), dim3(SBT), lds, st, n,
-                     vh, ph, rd);
+  tce_lds_limit(reinterpret_cast<const void*>(smlp_epoch_kernel<H, ACT, HEAD, KP>), lds);
+  hipLaunchKernelGGL((smlp_epoch_kernel<H, ACT, HEAD, KP>), dim3(s_grid(n.N)), dim3(SBT), lds, st,
+                     n, vh, ph, rd);
   TCE_LAUNCH_CHECK();
   return 0;
 }
-template <int HEAD>
-int s_dispatch_epoch(int H, int act, const SNet& n, const SValueHead& vh, const SPolicyHead& ph,
-                     const SReduce& rd, hipStream_t st) {
+// value head: one variant per (H, activation); policy head: one per (H, padded
+// K) with the activation as a kernel argument
+int s_dispatch_value(int H, int act, const SNet& n, const SValueHead& vh, const SReduce& rd,
+                     hipStream_t st) {
+  const SPolicyHead ph{};
 #define S_CASE(HH, AA) \
-  if (H == HH && act == AA) return s_launch_epoch<HH, AA, HEAD>(n, vh, ph, rd, st);
+  if (H == HH && act == AA) return s_launch_epoch<HH, AA, HEAD_VALUE, 0>(n, vh, ph, rd, st);
   S_CASE(32, ACT_TANH) S_CASE(32, ACT_RELU) S_CASE(32, ACT_LEAKY) S_CASE(32, ACT_SOFTPLUS)
   S_CASE(64, ACT_TANH) S_CASE(64, ACT_RELU) S_CASE(64, ACT_LEAKY) S_CASE(64, ACT_SOFTPLUS)
 #undef S_CASE
   tce_set_error("smlp: unsupported hidden width / activation");
+  return 1;
+}
+int s_dispatch_policy(int H, const SNet& n, const SPolicyHead& ph, const SReduce& rd,
+                      hipStream_t st) {
+  const SValueHead vh{};
+  const int K = n.dout;
+  const int kp = K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : K <= 32 ? 32 : 0;
+#define S_CASE(HH, KK) \
+  if (H == HH && kp == KK) return s_launch_epoch<HH, ACT_RT, HEAD_BB_POLICY, KK>(n, vh, ph, rd, st);
+  S_CASE(32, 8) S_CASE(32, 16) S_CASE(32, 24) S_CASE(32, 32) S_CASE(32, 0)
+  S_CASE(64, 8) S_CASE(64, 16) S_CASE(64, 24) S_CASE(64, 32) S_CASE(64, 0)
+#undef S_CASE
+  tce_set_error("smlp: unsupported hidden width");
   return 1;
 }
 
@@ -997,7 +1199,7 @@ int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, i
   TCE_CHECK_ARG(x && param && out && N > 0, "smlp_forward: null buffer / empty batch");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, dout, HEAD_NONE), "smlp_forward: unsupported shape");
   TCE_CHECK_ARG(x_stride >= din, "smlp_forward: row stride < din");
-  const SNet n{x, x_stride, N, din, dout, param};
+  const SNet n{x, x_stride, N, din, dout, param, act};
   hipStream_t st = (hipStream_t)stream;
 #define S_CASE(HH, AA) \
   if (H == HH && act == AA) return s_launch_forward<HH, AA>(n, out, st);
@@ -1022,9 +1224,8 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
   TCE_CHECK_ARG(x_stride >= din, "smlp_critic_epochs: row stride < din");
   TCE_CHECK_ARG(do_adam || epochs == 1, "smlp_critic_epochs: epochs > 1 needs the Adam step");
   hipStream_t st = (hipStream_t)stream;
-  const SNet n{x, x_stride, N, din, 1, param};
+  const SNet n{x, x_stride, N, din, 1, param, act};
   const SValueHead vh{returns, old_values, clip_critic};
-  const SPolicyHead ph{};
   SReduce rd{};
   s_reduce_ws(ws, N, din, H, 1, rd);
   const int g = s_grid(N);
@@ -1032,7 +1233,7 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
   // the Adam step rides on the slab reduction unless the clip factor needs the norm first
   const bool fuse = do_adam && !(clip_grad > 0.f);
   for (int e = 0; e < epochs; ++e) {
-    int rc = s_dispatch_epoch<HEAD_VALUE>(H, act, n, vh, ph, rd, st);
+    int rc = s_dispatch_value(H, act, n, vh, rd, st);
     if (rc) return rc;
     SFinish f{};
     f.slabs = rd.slabs; f.dpart = rd.dpart; f.nparts = g; f.PS = rd.PS; f.P = rd.P; f.KK = 0;
@@ -1084,8 +1285,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   float* gL_tr = g_pL + KK;
   float* gL_p = gL_tr + KK;
   float* out16 = gL_p + KK;
-  SNet n{x, x_stride, N, din, K, param};
-  const SValueHead vh{};
+  TCE_CHECK_ARG(act >= 0 && act <= 3, "bb_policy_epochs: unknown activation");
+  SNet n{x, x_stride, N, din, K, param, act};
   SReduce rd{};
   s_reduce_ws(ws, N, din, H, K, rd);
   const int g = s_grid(N);
@@ -1111,7 +1312,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
     const SPolicyHead ph{actions, logp_old, adv, mean_old, L_old, L_proj, eps_mean, tr_coeff,
                          ent_coef, lastep ? mean_new_out : nullptr,
                          lastep ? proj_mean_out : nullptr};
-    rc = s_dispatch_epoch<HEAD_BB_POLICY>(H, act, n, vh, ph, rd, st);
+    rc = s_dispatch_policy(H, n, ph, rd, st);
     if (rc) return rc;
     SFinish f{};
     f.slabs = rd.slabs; f.dpart = rd.dpart; f.nparts = g; f.PS = rd.PS; f.P = P; f.KK = K * K;
