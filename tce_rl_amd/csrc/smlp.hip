@@ -45,6 +45,7 @@
 // finish kernel does the projection's backward -- four launches per epoch
 // instead of seven.
 #include "mlp_shared.h"
+#include "smallmat.h"
 #include "../../include/tce_hip.h"
 
 namespace {
@@ -60,6 +61,11 @@ __host__ __device__ inline int s_up4(int n) { return (n + 3) & ~3; }
 // pitch (floats) of a row-major [64][w] tile: 4 x odd, so that the 16-byte
 // pieces of 16 consecutive rows fall into 16 different bank groups
 __host__ __device__ inline int s_pitch(int w) { return 4 * (((w + 3) / 4) | 1); }
+// pitch of the K x K factor images in LDS: K padded to the length the register
+// head is unrolled over (rows / columns past K are zero, so no bounds tests)
+__host__ __device__ inline int s_kpad(int K) {
+  return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : K <= 32 ? 32 : s_up4(K);
+}
 __host__ __device__ inline int s_nparams(int din, int H, int dout) {
   return H * din + H + H * H + H + dout * H + dout;
 }
@@ -96,7 +102,8 @@ struct SLds {
   int xs, h1s, h2s, d1s, d2s, g3s;       // row-major tiles [64][pitch]
   int ys, gus;                           // policy: y and g u (row-major [64][gp])
   int vec;                               // policy: 6 vectors [doutp][64]; value head: 2 x [64]
-  int lo, lp, rdo, rdp;                  // policy: L_old, L_proj [K][K], 1 / diagonals
+  int lo, lp, rdo, rdp;                  // policy: L_old, L_proj [kp][kp], 1 / diagonals
+  int lio, liot, lip, lipt;              // policy: L_old^-1, its transpose, L_proj^-1, transpose
   int red;                               // scratch
   int total;
   int xp, hp, gp, dinp, doutp;
@@ -127,11 +134,17 @@ __host__ __device__ inline SLds s_lds(int din, int H, int dout, int head) {
   L.ys = o; o += pol ? SR * L.gp : 0;
   L.gus = o; o += pol ? SR * L.gp : 0;
   L.vec = o; o += pol ? 6 * L.doutp * SR : 2 * SR;
-  const int kk = s_up4(dout * dout);
+  const int kp = s_kpad(dout);
+  const int kk = kp * kp;
   L.lo = o; o += pol ? kk : 0;
   L.lp = o; o += pol ? kk : 0;
   L.rdo = o; o += pol ? L.doutp : 0;
   L.rdp = o; o += pol ? L.doutp : 0;
+  const bool inv = pol && kp <= 32;       // the register head (K <= 32) works with the inverses
+  L.lio = o; o += inv ? kk : 0;
+  L.liot = o; o += inv ? kk : 0;
+  L.lip = o; o += inv ? kk : 0;
+  L.lipt = o; o += inv ? kk : 0;
   L.red = o; o += 16;
   L.total = o;
   return L;
@@ -155,6 +168,7 @@ struct SValueHead {
 struct SPolicyHead {
   const float *actions, *logp_old, *adv, *mean_old;   // [N,K], [N], [N], [N,K]
   const float *L_old, *L_proj;                        // [K,K] each (shared)
+  const float *Li_old, *Li_proj;                      // their inverses [K,K]
   float eps_mean, tr_coeff, ent_coef;
   float *mean_out, *pmean_out;                        // nullable [N,K]
 };
@@ -364,7 +378,7 @@ __device__ inline void s_outer_block(const float* A, int pa, const float* B, int
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
   const float* a = A + 4 * bi;
   const float* b = B + 4 * bj;
-#pragma unroll 4
+#pragma unroll 16
   for (int r = 0; r < SR; ++r) {
     const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * pa);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(b + r * pb);
@@ -389,21 +403,27 @@ __device__ inline void s_outer_block(const float* A, int pa, const float* B, int
 // tile of the same workgroup adds to it)
 template <int H>
 __device__ inline void s_param_grads(const SLds& L, const float* S, int din, int dout, float* slab,
-                                     bool accumulate) {
+                                     bool accumulate, float* gpl) {
   const int nb1 = (H / 4) * (L.dinp / 4), nb2 = (H / 4) * (H / 4), nb3 = (L.doutp / 4) * (H / 4);
+  // policy head: d logp / d L_proj summed over the rows, sum g u y^T (gpl; the
+  // lower triangle is used), as further blocks of the same pass
+  const int nb4 = gpl ? (L.doutp / 4) * (L.doutp / 4) : 0;
   float* gW1 = slab;
   float* gB1 = gW1 + H * din;
   float* gW2 = gB1 + H;
   float* gB2 = gW2 + H * H;
   float* gW3 = gB2 + H;
   float* gB3 = gW3 + dout * H;
-  for (int t = threadIdx.x; t < nb1 + nb2 + nb3; t += SBT) {
+  for (int t = threadIdx.x; t < nb1 + nb2 + nb3 + nb4; t += SBT) {
     if (t < nb1)
       s_outer_block(S + L.d1s, L.hp, S + L.xs, L.xp, H, din, t, gW1, accumulate);
     else if (t < nb1 + nb2)
       s_outer_block(S + L.d2s, L.hp, S + L.h1s, L.hp, H, H, t - nb1, gW2, accumulate);
-    else
+    else if (t < nb1 + nb2 + nb3)
       s_outer_block(S + L.g3s, L.gp, S + L.h2s, L.hp, dout, H, t - nb1 - nb2, gW3, accumulate);
+    else
+      s_outer_block(S + L.gus, L.gp, S + L.ys, L.gp, dout, dout, t - nb1 - nb2 - nb3, gpl,
+                    accumulate);
   }
   for (int t = threadIdx.x; t < 2 * H + dout; t += SBT) {
     const float* src;
@@ -468,11 +488,12 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
   const int64_t row = r0 + lane;
   const bool rok = row < N;
   const int64_t rc = rok ? row : N - 1;
+  const int LP = s_kpad(K);
   // z = L_old^-1 (mu - mu_old)
   float quad = 0.f;
   for (int r = 0; r < K; ++r) {
     float v = MU[r * SR + lane] - MO[r * SR + lane];
-    for (int k = 0; k < r; ++k) v -= Lo[r * K + k] * Z[k * SR + lane];
+    for (int k = 0; k < r; ++k) v -= Lo[r * LP + k] * Z[k * SR + lane];
     v *= rdo[r];
     Z[r * SR + lane] = v;
     quad += v * v;
@@ -490,7 +511,7 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
     if (h.pmean_out && rok) h.pmean_out[row * K + r] = pm;
     if (h.mean_out && rok) h.mean_out[row * K + r] = mu;
     float v = AC[r * SR + lane] - pm;
-    for (int k = 0; k < r; ++k) v -= Lp[r * K + k] * Y[k * SR + lane];
+    for (int k = 0; k < r; ++k) v -= Lp[r * LP + k] * Y[k * SR + lane];
     v *= rdp[r];
     Y[r * SR + lane] = v;
     quady += v * v;
@@ -505,7 +526,7 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
   // u = L_proj^-T y (in place), d logp / d proj_mean = u
   for (int r = K - 1; r >= 0; --r) {
     float v = Y[r * SR + lane];
-    for (int k = r + 1; k < K; ++k) v -= Lp[k * K + r] * Y[k * SR + lane];
+    for (int k = r + 1; k < K; ++k) v -= Lp[k * LP + r] * Y[k * SR + lane];
     Y[r * SR + lane] = v * rdp[r];
   }
   for (int r = 0; r < K; ++r) S[L.gus + lane * L.gp + r] = g * Y[r * SR + lane];
@@ -513,14 +534,14 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
   float maha2 = 0.f;
   for (int r = 0; r < K; ++r) {
     float v = W[r * SR + lane];
-    for (int k = 0; k < r; ++k) v -= Lp[r * K + k] * W[k * SR + lane];
+    for (int k = 0; k < r; ++k) v -= Lp[r * LP + k] * W[k * SR + lane];
     v *= rdp[r];
     W[r * SR + lane] = v;
     maha2 += v * v;
   }
   for (int r = K - 1; r >= 0; --r) {
     float v = W[r * SR + lane];
-    for (int k = r + 1; k < K; ++k) v -= Lp[k * K + r] * W[k * SR + lane];
+    for (int k = r + 1; k < K; ++k) v -= Lp[k * LP + r] * W[k * SR + lane];
     W[r * SR + lane] = v * rdp[r];
   }
   // back through the mean projection: t = L_old^-T z (in place)
@@ -529,7 +550,7 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
   if (active) {                                          // lanes of inactive rows skip the solve
     for (int r = K - 1; r >= 0; --r) {
       float v = Z[r * SR + lane];
-      for (int k = r + 1; k < K; ++k) v -= Lo[k * K + r] * Z[k * SR + lane];
+      for (int k = r + 1; k < K; ++k) v -= Lo[k * LP + r] * Z[k * SR + lane];
       Z[r * SR + lane] = v * rdo[r];
     }
   }
@@ -555,6 +576,51 @@ __device__ inline void s_policy_head(const SLds& L, float* S, const SPolicyHead&
 // over the padded length, rows / columns past K skipped by uniform branches):
 // the [k][lane] LDS vectors above make every step of a triangular solve two
 // dependent LDS round trips -- 60 of the row kernel's 80 us at K = 20.
+// lower-triangular solve v <- M^-1 v (s_solve) / v <- M^-T v (s_solve_t) for a
+// vector in registers; M: [KP][KP] LDS image (zero past K), rd: reciprocal
+// diagonal (zero past K).  One row at a time: its entries are fetched
+// (constant offsets), then the dot product; the scheduling barrier keeps the
+// reads of ALL rows from being hoisted to the top.
+// out[s] = T in[s] for NV vectors in registers and a TRIANGULAR matrix T given
+// by the image R = T^T (LOWER: T lower triangular, so R[k][r] = T[r][k] is
+// non-zero for r >= k) or, !LOWER, T upper triangular with R[k][r] = T[r][k]
+// non-zero for r <= k: per input element k one contiguous piece of row k of
+// the image (16-byte reads, constant offsets) and independent FMAs into all
+// outputs -- no dependent chain, unlike a triangular solve, whose every row
+// waits for the rows before it (6 solves of K = 20: 50 000 cycles per tile).
+// The image is [KP][KP] with zeros past K; k >= K is skipped (uniform test,
+// which also keeps each step a basic block of its own: one block of 24 x 24
+// reads made the compiler hoist them all and spill).
+template <int KP, int NV, bool LOWER>
+__device__ __forceinline__ void s_trimv(float (&out)[NV][KP], const float (&in)[NV][KP],
+                                        const float* R, int K) {
+#pragma unroll
+  for (int s = 0; s < NV; ++s)
+#pragma unroll
+    for (int r = 0; r < KP; ++r) out[s][r] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    if (k < K) {
+      constexpr int Q = KP / 4;
+      const int q0 = LOWER ? k / 4 : 0, q1 = LOWER ? Q : k / 4 + 1;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (q >= q0 && q < q1) {                      // compile-time after unrolling
+          const f32x4 t = *reinterpret_cast<const f32x4*>(R + k * KP + 4 * q);
+#pragma unroll
+          for (int s = 0; s < NV; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[s][4 * q + i] += t[i] * in[s][k];
+        }
+      }
+    }
+  }
+}
+
+// The black-box policy head with the K-vectors in registers (K <= KP <= 32)
+// and the triangular solves as products with the explicit inverses of the two
+// shared factors (Li_old = L_old^-1, Li_proj = L_proj^-1, computed once per
+// update / once per epoch in double precision): six small dense layers.
 template <int KP>
 __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyHead& h,
                                          int64_t r0, int64_t N, int K, int lane, float logdet_p,
@@ -563,142 +629,76 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
   const float* MU = S + L.vec;
   const float* MO = MU + VS;
   float* AC = S + L.vec + 2 * VS;
-  const float* Lo = S + L.lo;
-  const float* Lp = S + L.lp;
-  const float* rdo = S + L.rdo;
-  const float* rdp = S + L.rdp;
   const int64_t row = r0 + lane;
   const bool rok = row < N;
   const int64_t rc = rok ? row : N - 1;
-  float mu[KP], mo[KP], z[KP], y[KP], w[KP];
+  const float lpo = h.logp_old[rc], adv = h.adv[rc];   // in flight during the first product
+  float mu[KP], mo[KP], d[1][KP], z[1][KP], ab[2][KP], yw[2][KP], uq[2][KP];
 #pragma unroll
   for (int r = 0; r < KP; ++r) {
     const int rr = r < K ? r : K - 1;
-    mu[r] = MU[rr * SR + lane];
-    mo[r] = MO[rr * SR + lane];
-    if (r >= K) { mu[r] = 0.f; mo[r] = 0.f; }
+    const float live = r < K ? 1.f : 0.f;
+    mu[r] = live * MU[rr * SR + lane];
+    mo[r] = live * MO[rr * SR + lane];
+    ab[0][r] = live * AC[rr * SR + lane];           // the sampled parameters
+    d[0][r] = mu[r] - mo[r];
   }
   // z = L_old^-1 (mu - mu_old)
+  s_trimv<KP, 1, true>(z, d, S + L.liot, K);
   float quad = 0.f;
 #pragma unroll
-  for (int r = 0; r < KP; ++r) {
-    z[r] = 0.f;
-    if (r < K) {
-      float a0 = mu[r] - mo[r], a1 = 0.f;
-#pragma unroll
-      for (int k = 0; k + 1 < r; k += 2) {
-        a0 -= Lo[r * K + k] * z[k];
-        a1 -= Lo[r * K + k + 1] * z[k + 1];
-      }
-      if (r & 1) a0 -= Lo[r * K + r - 1] * z[r - 1];
-      z[r] = (a0 + a1) * rdo[r];
-      quad += z[r] * z[r];
-    }
-  }
+  for (int r = 0; r < KP; ++r) quad += z[0][r] * z[0][r];
   const float m = 0.5f * quad;
   const bool active = m > h.eps_mean;
   const float sc = active ? sqrtf(m / h.eps_mean) : 1.f;
   const float om = sc - 1.f;
   const float den = 1.f + om + 1e-16f;
-  // y = L_proj^-1 (a - proj_mean); w starts as mu - proj_mean
-  float quady = 0.f;
+  // y = L_proj^-1 (a - proj_mean); w = L_proj^-1 (mu - proj_mean)
 #pragma unroll
   for (int r = 0; r < KP; ++r) {
-    y[r] = 0.f;
-    w[r] = 0.f;
+    const float pm = active ? (mu[r] + om * mo[r]) / den : mu[r];
     if (r < K) {
-      const float pm = active ? (mu[r] + om * mo[r]) / den : mu[r];
       if (h.pmean_out && rok) h.pmean_out[row * K + r] = pm;
       if (h.mean_out && rok) h.mean_out[row * K + r] = mu[r];
-      float a0 = AC[r * SR + lane] - pm, a1 = 0.f;
-#pragma unroll
-      for (int k = 0; k + 1 < r; k += 2) {
-        a0 -= Lp[r * K + k] * y[k];
-        a1 -= Lp[r * K + k + 1] * y[k + 1];
-      }
-      if (r & 1) a0 -= Lp[r * K + r - 1] * y[r - 1];
-      y[r] = (a0 + a1) * rdp[r];
-      quady += y[r] * y[r];
-      w[r] = mu[r] - pm;
     }
+    ab[0][r] -= pm;
+    ab[1][r] = mu[r] - pm;
+  }
+  s_trimv<KP, 2, true>(yw, ab, S + L.lipt, K);
+  float quady = 0.f, maha2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < KP; ++r) {
+    quady += yw[0][r] * yw[0][r];
+    maha2 += yw[1][r] * yw[1][r];
   }
   const float logp = -0.5f * quady - logdet_p - S_HALF_LOG_2PI * (float)K;
-  const float ratio = expf(logp - h.logp_old[rc]);
-  const float ra = ratio * h.adv[rc];
+  const float ratio = expf(logp - lpo);
+  const float ra = ratio * adv;
   const float g = rok ? -ra / (float)N : 0.f;
 #pragma unroll
   for (int r = 0; r < KP; ++r)
-    if (r < K) S[L.ys + lane * L.gp + r] = y[r];
-  // u = L_proj^-T y (in place)
-#pragma unroll
-  for (int r = KP - 1; r >= 0; --r) {
-    if (r < K) {
-      float a0 = y[r], a1 = 0.f;
-#pragma unroll
-      for (int k = r + 1; k < KP; ++k) {
-        const int kk = k < K ? k : K - 1;             // y[k] = 0 past K
-        if ((k - r) & 1) a0 -= Lp[kk * K + r] * y[k]; else a1 -= Lp[kk * K + r] * y[k];
-      }
-      y[r] = (a0 + a1) * rdp[r];
-    }
-  }
+    if (r < K) S[L.ys + lane * L.gp + r] = yw[0][r];
+  // u = L_proj^-T y, q = L_proj^-T w; t = L_old^-T z
+  s_trimv<KP, 2, false>(uq, yw, S + L.lip, K);
 #pragma unroll
   for (int r = 0; r < KP; ++r)
-    if (r < K) S[L.gus + lane * L.gp + r] = g * y[r];
-  // w = L_proj^-1 (mu - proj_mean), then q = L_proj^-T w (in place)
-  float maha2 = 0.f;
-#pragma unroll
-  for (int r = 0; r < KP; ++r) {
-    if (r < K) {
-      float a0 = w[r], a1 = 0.f;
-#pragma unroll
-      for (int k = 0; k + 1 < r; k += 2) {
-        a0 -= Lp[r * K + k] * w[k];
-        a1 -= Lp[r * K + k + 1] * w[k + 1];
-      }
-      if (r & 1) a0 -= Lp[r * K + r - 1] * w[r - 1];
-      w[r] = (a0 + a1) * rdp[r];
-      maha2 += w[r] * w[r];
-    }
-  }
-#pragma unroll
-  for (int r = KP - 1; r >= 0; --r) {
-    if (r < K) {
-      float a0 = w[r], a1 = 0.f;
-#pragma unroll
-      for (int k = r + 1; k < KP; ++k) {
-        const int kk = k < K ? k : K - 1;
-        if ((k - r) & 1) a0 -= Lp[kk * K + r] * w[k]; else a1 -= Lp[kk * K + r] * w[k];
-      }
-      w[r] = (a0 + a1) * rdp[r];
-    }
-  }
-  // back through the mean projection: t = L_old^-T z (in place)
+    if (r < K) S[L.gus + lane * L.gp + r] = g * uq[0][r];
   float gd = 0.f;
 #pragma unroll
-  for (int r = 0; r < KP; ++r) gd += g * y[r] * (mu[r] - mo[r]);
-  if (__builtin_amdgcn_ballot_w64(active) != 0) {      // no row of the wave is projected: skip
+  for (int r = 0; r < KP; ++r) gd += g * uq[0][r] * d[0][r];
+  float t[1][KP];
 #pragma unroll
-    for (int r = KP - 1; r >= 0; --r) {
-      if (r < K) {
-        float a0 = z[r], a1 = 0.f;
-#pragma unroll
-        for (int k = r + 1; k < KP; ++k) {
-          const int kk = k < K ? k : K - 1;
-          if ((k - r) & 1) a0 -= Lo[kk * K + r] * z[k]; else a1 -= Lo[kk * K + r] * z[k];
-        }
-        z[r] = (a0 + a1) * rdo[r];
-      }
-    }
-  }
+  for (int r = 0; r < KP; ++r) t[0][r] = 0.f;
+  if (__builtin_amdgcn_ballot_w64(active) != 0)        // no row of the wave projected: skip
+    s_trimv<KP, 1, false>(t, z, S + L.lio, K);
   const float coef = active ? gd / (2.f * h.eps_mean * sc * sc * sc) : 0.f;
   const float trc = rok ? h.tr_coeff / (float)N : 0.f;
 #pragma unroll
   for (int r = 0; r < KP; ++r) {
     if (r < K) {
-      const float gp = g * y[r];
-      float gm = active ? gp / sc - coef * z[r] : gp;
-      gm += trc * w[r];
+      const float gp = g * uq[0][r];
+      float gm = active ? gp / sc - coef * t[0][r] : gp;
+      gm += trc * uq[1][r];
       AC[r * SR + lane] = gm;
       S[L.g3s + lane * L.gp + r] = gm;
     }
@@ -737,6 +737,14 @@ __host__ __device__ inline int s_forward_lds_floats(int din, int H, int dout) {
   return L.vec + s_up4(dout) * SR + 16;
 }
 
+#ifdef SMLP_STAMP
+#define SMLP_T0() long long t0_ = __builtin_readcyclecounter(); long long stamp_[5] = {0, 0, 0, 0, 0};
+#define SMLP_T(k) { const long long tn_ = __builtin_readcyclecounter(); stamp_[k] += tn_ - t0_; t0_ = tn_; }
+#else
+#define SMLP_T0()
+#define SMLP_T(k)
+#endif
+
 template <int H, int ACT, int HEAD, int KP>
 __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, SPolicyHead ph,
                                                         SReduce rd) {
@@ -744,16 +752,31 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
   const SLds L = s_lds(n.din, H, n.dout, HEAD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = n.dout;
+  SMLP_T0()
   s_load_weights<H>(L, S, n);
   float logdet_p = 0.f;
   if (HEAD == HEAD_BB_POLICY) {
-    for (int e = tid; e < K * K; e += SBT) {
-      S[L.lo + e] = ph.L_old[e];
-      S[L.lp + e] = ph.L_proj[e];
+    const int LP = s_kpad(K);
+    for (int e = tid; e < LP * LP; e += SBT) {
+      const int i = e / LP, j = e - i * LP;
+      const bool in = i < K && j < K;
+      S[L.lo + e] = in ? ph.L_old[i * K + j] : 0.f;
+      S[L.lp + e] = in ? ph.L_proj[i * K + j] : 0.f;
     }
-    for (int e = tid; e < K; e += SBT) {
-      S[L.rdo + e] = 1.f / ph.L_old[e * K + e];
-      S[L.rdp + e] = 1.f / ph.L_proj[e * K + e];
+    for (int e = tid; e < L.doutp; e += SBT) {
+      S[L.rdo + e] = e < K ? 1.f / ph.L_old[e * K + e] : 0.f;
+      S[L.rdp + e] = e < K ? 1.f / ph.L_proj[e * K + e] : 0.f;
+    }
+    if (KP > 0) {
+      for (int e = tid; e < LP * LP; e += SBT) {
+        const int i = e / LP, j = e - i * LP;
+        const bool in = i < K && j < K;
+        const float a = in ? ph.Li_old[i * K + j] : 0.f, b = in ? ph.Li_proj[i * K + j] : 0.f;
+        S[L.lio + e] = a;
+        S[L.liot + j * LP + i] = a;
+        S[L.lip + e] = b;
+        S[L.lipt + j * LP + i] = b;
+      }
     }
     logdet_p = wave_sum(lane < K ? logf(ph.L_proj[lane * K + lane]) : 0.f);
   }
@@ -775,7 +798,9 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
     }
     __syncthreads();
     float h1[H / SNW], h2[H / SNW];
+    SMLP_T(0)
     s_forward<H, ACT>(L, S, K, lane, wave, h1, h2, vecs, n.act);
+    SMLP_T(1)
     const float* g;
     if (HEAD == HEAD_VALUE) {
       if (wave == 0) acc_d[0] += s_value_head(L, S, vh, r0, n.N, lane, vecs, vecs + SR);
@@ -791,21 +816,25 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
       g = vecs + 2 * L.doutp * SR;                     // AC slot
     }
     __syncthreads();
+    SMLP_T(2)
     s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g, n.act);
-    s_param_grads<H>(L, S, n.din, K, slab, !first);
-    if (HEAD == HEAD_BB_POLICY) {
-      // d logp / d L_proj summed over the rows: sum g u y^T (lower triangle used)
-      float* gpl = slab + rd.P;
-      const int nb = (L.doutp / 4) * (L.doutp / 4);
-      for (int t = tid; t < nb; t += SBT)
-        s_outer_block(S + L.gus, L.gp, S + L.ys, L.gp, K, K, t, gpl, !first);
-    }
+    SMLP_T(3)
+    s_param_grads<H>(L, S, n.din, K, slab, !first,
+                     HEAD == HEAD_BB_POLICY ? slab + rd.P : nullptr);
     first = false;
+    SMLP_T(4)
   }
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) rd.dpart[blockIdx.x * 8 + i] = acc_d[i];
   }
+#ifdef SMLP_STAMP
+  // diagnostic build (scripts/smlp_stamps.py): cycles of workgroup 0, wave 0 --
+  // {setup + loads, forward, head, backward, gradients} behind the slabs
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 5; ++i)       // the 8 spare floats at the end of the workspace
+      rd.slabs[(int64_t)gridDim.x * rd.PS + 16 * (int64_t)gridDim.x + 16 + i] = (float)stamp_[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -873,6 +902,34 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void smlp_reduce_kernel(SFinish f)
   }
 }
 
+// Li = L^-1 for a lower-triangular [K,K] factor (one workgroup, double
+// precision in LDS): the row kernel applies the inverses as dense products
+__global__ __launch_bounds__(SM_BT) void tri_inverse_kernel(const float* __restrict__ Lm,
+                                                            float* __restrict__ Li, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int KP = sm_pitch(K);
+  double* A = reinterpret_cast<double*>(smem_raw);
+  double* X = A + K * KP;
+  sm_load(A, Lm, K, KP, true);
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    X[i * KP + j] = i == j ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  sm_trsm_l(X, A, K, KP);
+  for (int e = threadIdx.x; e < K * K; e += SM_BT) {
+    const int i = e / K, j = e - i * K;
+    Li[e] = j <= i ? (float)X[i * KP + j] : 0.f;
+  }
+}
+inline int s_tri_inverse(const float* Lm, float* Li, int K, hipStream_t st) {
+  const size_t lds = 2 * (size_t)K * sm_pitch(K) * sizeof(double);
+  tce_lds_limit(reinterpret_cast<const void*>(tri_inverse_kernel), lds);
+  hipLaunchKernelGGL(tri_inverse_kernel, dim3(1), dim3(SM_BT), lds, st, Lm, Li, K);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Matrix side of a black-box policy epoch for DIAGONAL factors (std_only):
 // Cholesky head, KL covariance projection (oracle/kl_oracle.py cov_projection
@@ -884,8 +941,8 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void smlp_reduce_kernel(SFinish f)
 __global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
     const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
     double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
-    float* __restrict__ L_proj, float* __restrict__ gL_tr, float* __restrict__ out16,
-    double* __restrict__ dctx) {
+    float* __restrict__ L_proj, float* __restrict__ Li_proj, float* __restrict__ gL_tr,
+    float* __restrict__ out16, double* __restrict__ dctx) {
   const int k = threadIdx.x;
   const bool live = k < K;
   double sig = 1, so = 1;
@@ -940,6 +997,7 @@ __global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
     const int i = e / K, j = e - i * K;
     L_new[e] = i == j ? dg[0][i] : 0.f;
     L_proj[e] = i == j ? dg[1][i] : 0.f;
+    Li_proj[e] = i == j ? 1.f / dg[1][i] : 0.f;
     gL_tr[e] = i == j ? dg[2][i] : 0.f;
   }
   if (live) {
@@ -1278,13 +1336,19 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   hipStream_t st = (hipStream_t)stream;
   const int P = s_nparams(din, H, K);
   const int KK = s_up4(K * K);
-  // mats: L_new | L_proj | g_pL | gL_tr | gL_p  [K,K] each, then out16 [16]
+  // mats: L_new | L_proj | g_pL | gL_tr | gL_p | Li_old | Li_proj  [K,K] each, then out16 [16]
   float* L_new = mats;
   float* L_proj = L_new + KK;
   float* g_pL = L_proj + KK;
   float* gL_tr = g_pL + KK;
   float* gL_p = gL_tr + KK;
-  float* out16 = gL_p + KK;
+  float* Li_old = gL_p + KK;
+  float* Li_proj = Li_old + KK;
+  float* out16 = Li_proj + KK;
+  {
+    const int rc0 = s_tri_inverse(L_old, Li_old, K, st);     // once per update
+    if (rc0) return rc0;
+  }
   TCE_CHECK_ARG(act >= 0 && act <= 3, "bb_policy_epochs: unknown activation");
   SNet n{x, x_stride, N, din, K, param, act};
   SReduce rd{};
@@ -1297,7 +1361,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
     int rc;
     if (diag) {
       hipLaunchKernelGGL(bb_diag_fwd_kernel, dim3(1), dim3(64), 0, st, param + P, min_std, L_old, K,
-                         eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, gL_tr, out16, proj_ctx);
+                         eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, Li_proj, gL_tr, out16,
+                         proj_ctx);
       TCE_LAUNCH_CHECK();
     } else {
       rc = tce_chol_build_fwd_f32(param + P, L_new, 1, K, nvec, min_std, stream);
@@ -1308,8 +1373,13 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
       rc = tce_kl_shared_mat_f32(L_new, L_old, L_proj, N, K, tr_coeff, tr_include_cov, zero3, 1,
                                  out16, gL_tr, stream);
       if (rc) return rc;
+      if (K <= 32) {                                 // the register head works with the inverse
+        rc = s_tri_inverse(L_proj, Li_proj, K, st);
+        if (rc) return rc;
+      }
     }
-    const SPolicyHead ph{actions, logp_old, adv, mean_old, L_old, L_proj, eps_mean, tr_coeff,
+    const SPolicyHead ph{actions, logp_old, adv, mean_old, L_old, L_proj, Li_old, Li_proj,
+                         eps_mean, tr_coeff,
                          ent_coef, lastep ? mean_new_out : nullptr,
                          lastep ? proj_mean_out : nullptr};
     rc = s_dispatch_policy(H, n, ph, rd, st);
@@ -1337,6 +1407,6 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   return 0;
 }
 
-int64_t tce_bb_policy_mats_len(int K) { return 5 * (int64_t)s_up4(K * K) + 16; }
+int64_t tce_bb_policy_mats_len(int K) { return 7 * (int64_t)s_up4(K * K) + 16; }
 
 }  // extern "C"
