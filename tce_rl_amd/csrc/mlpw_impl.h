@@ -136,19 +136,27 @@ struct WArgs {
   int P;
 };
 
+// fp32 chain-kernel shape (scripts/mlpw_variant.py builds others to compare)
+#ifndef MLPW_F32_WAVES
+#define MLPW_F32_WAVES 8          // waves per workgroup
+#define MLPW_F32_PU 32            // output units per W2 panel
+#define MLPW_F32_WGS 1            // workgroups per compute unit
+#endif
+
 template <typename real>
 struct WCfg {
   // chain kernel: two waves per SIMD in fp32; fp64 keeps its B operands in 128
   // registers per lane and spills at the 256 of a two-wave kernel (tried: 279
   // spilled registers), so it runs one wave per SIMD
-  static constexpr int WAVES = sizeof(real) == 4 ? 8 : 4;
+  static constexpr int WAVES = sizeof(real) == 4 ? MLPW_F32_WAVES : 4;
+  static constexpr int WGS = sizeof(real) == 4 ? MLPW_F32_WGS : 1;   // chain workgroups per CU
   // copies of the db1 / db2 / dw3 accumulators in LDS: one per wave (plain
   // read-modify-write, fixed summation order); fewer copies than waves would
   // go through LDS atomics
   static constexpr int NACC = WAVES;
   static constexpr int NT = WAVES * 64;
   static constexpr int TILE = WAVES * 16;                   // batch rows per tile
-  static constexpr int PU = sizeof(real) == 4 ? 32 : 16;    // output units per panel
+  static constexpr int PU = sizeof(real) == 4 ? MLPW_F32_PU : 16;    // output units per panel
   static constexpr int NTILE = PU / 16;
   static constexpr int WPAD = sizeof(real) == 4 ? 8 : 2;    // panel pitch = H + WPAD
   static constexpr int KC = sizeof(real) == 4 ? 16 : 8;     // gradient kernel: rows per stage
@@ -434,10 +442,14 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     }
 
     WSTAMP(0)
-    // ---- layer 2 through the W2 panels: H2^T = act(W2 H1^T + b2).  The H2
-    // tiles are not kept: their share of v = w3 . H2 is taken at once and
-    // (backward) the tile is parked in the dY2 rows of the workspace.
+    // ---- layer 2 through the W2 panels: H2^T = act(W2 H1^T + b2).  Their
+    // share of v = w3 . H2 is taken at once; (backward) the tiles stay in
+    // registers -- they become dY2, the B operand of the backward panels -- next
+    // to H1, which the backward panels need for act'(H1).  (Round 2 parked H2
+    // in the dY2 rows of the workspace and read H1 back: 3 x R x H elements of
+    // HBM traffic per epoch for 64 registers.)
     real v = 0;
+    vacc dy2[BWD ? NJ : 1];
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       const bool last = !BWD && s == NP - 1;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           acc[jj][i] = wact<real, ACT>(acc[jj][i]);
           v += w3v[i] * acc[jj][i];
         }
-        if (BWD) *reinterpret_cast<v4*>(pd + 16 * J) = acc[jj];
+        if (BWD) dy2[J] = acc[jj];
       }
       WSTAMP(6)
       __syncthreads();
@@ -494,16 +506,11 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         dv = d * inv_n;
         if (g == 0) { loss_sum += l; gb3 += dv; }
       }
-      // dY2 = dv w3 act'(H2): the parked H2 tiles come back (this lane reads
-      // what it wrote), dY2 replaces them in the workspace and stays in
-      // registers as the B operand of the backward panels; dw3 = sums over the
-      // 16 batch lanes of a row (db2 and db1 are column sums of the dY2 / dY1
-      // rows: the gradient kernel takes them from its A fragments for free)
-      vacc dy2[NJ];
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) {
-        dy2[J] = *reinterpret_cast<const v4*>(pd + 16 * J);
-      }
+      // dY2 = dv w3 act'(H2) in place of the H2 tiles: written to the workspace
+      // for the gradient kernel and kept as the B operand of the backward
+      // panels; dw3 = sums over the 16 batch lanes of a row (db2 and db1 are
+      // column sums of the dY2 / dY1 rows: the gradient kernel takes them from
+      // its A fragments for free)
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
         const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
@@ -529,17 +536,11 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       }
       WSTAMP(2)
       // ---- dH1^T = W2^T dY2^T through the W2^T panels; dY1 = dH1 act'(H1)
-      // (the H1 tile of the panel is read back from the workspace)
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
         const bool last = s == NP - 1;
         const bool pre = !last || more;
         if (pre) fetch(last ? 0 : NP + s + 1);
-        vacc hb[NTILE];
-#pragma unroll
-        for (int jj = 0; jj < NTILE; ++jj) {
-          hb[jj] = *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj));
-        }
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[jj][i] *= wact_d<real, ACT>(hb[jj][i]);
+          for (int i = 0; i < 4; ++i) acc[jj][i] *= wact_d<real, ACT>(h1[J][i]);
           *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
         }
         __syncthreads();
@@ -874,6 +875,8 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
   const int64_t ntiles = (a.R + C::TILE - 1) / C::TILE;
   int grid = mlpw_cu_count();
   if (max_wg > 0 && max_wg < grid) grid = max_wg;
+  int cgrid = grid * C::WGS;                                // chain kernel: WGS workgroups per CU
+  if (ntiles < cgrid) cgrid = (int)ntiles;
   if (ntiles < grid) grid = (int)ntiles;
   // workspace: w2p | w2tp | h1s | dy2s | dy1s
   real* w2p = workspace;
@@ -896,7 +899,7 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
       tce_lds_limit(reinterpret_cast<const void*>(&mlpw_grad_kernel<real, H, KPG>), (size_t)(glds0));
       set = true;
     }
-    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, true>), dim3(grid), dim3(C::NT), lds,
+    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, true>), dim3(cgrid), dim3(C::NT), lds,
                        st, a);
     TCE_LAUNCH_CHECK();
     const dim3 ggrid(grid, GradCfg<real, H>::NSPLIT);
@@ -913,7 +916,7 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
       tce_lds_limit(reinterpret_cast<const void*>(&mlpw_chain_kernel<real, H, KPG, ACT, false>), (size_t)(lds));
       set = true;
     }
-    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, false>), dim3(grid), dim3(C::NT), lds,
+    hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, false>), dim3(cgrid), dim3(C::NT), lds,
                        st, a);
     TCE_LAUNCH_CHECK();
   }
@@ -924,6 +927,18 @@ template <typename real, int H, int KPG>
 int mlpw_launch(WArgs<real> a, real* workspace, real* grad, real* stats, int max_wg,
                 const real* w2, WAdam<real> ad, hipStream_t st) {
   switch (a.act) {
+#ifdef MLPW_ONLY_LEAKY
+    case W_LEAKY:
+      return mlpw_launch_act<real, H, KPG, W_LEAKY>(a, workspace, grad, stats, max_wg, w2, ad, st);
+  }
+  tce_set_error("mlpw_critic: activation not built");
+  return 1;
+}
+template <typename real, int H, int KPG>
+int mlpw_launch_unused(WArgs<real> a, real* workspace, real* grad, real* stats, int max_wg,
+                       const real* w2, WAdam<real> ad, hipStream_t st) {
+  switch (a.act) {
+#endif
 #ifndef MLPW_ONLY_RELU
     case W_TANH:
       return mlpw_launch_act<real, H, KPG, W_TANH>(a, workspace, grad, stats, max_wg, w2, ad, st);
