@@ -8,19 +8,24 @@ def tce_config(env="metaworld", num_env=4096, num_basis=8, dtype="float32",
                evaluation_interval=0, num_env_test=None):
     fam = {
         # (env_id, dof, tau, delay, alpha, bbf, w_scale, g_scale, rel_goal, dt,
-        #  act, policy hidden, critic hidden, mean_bound, cov_bound, min_std)
+        #  act, policy hidden, critic hidden, mean_bound, cov_bound, min_std,
+        #  lr_policy, lr_critic, weight decay, entropy_schedule, target_entropy)
+        # -- the values of mprl/config/<task>/tcp/entire/shared.yaml, checked
+        # against the resolved documents in tests/golden/resolved/
+        # (tests/test_config_cpu.py)
         "metaworld": ("metaworld_ProDMP_TCE/reach-v2", 4, 5.0, 0.0, 10, 5, 0.1,
                       0.1, True, 0.0125, "relu", (128, 2), (128, 2), 0.005,
-                      0.0005, 1e-5),
+                      0.0005, 1e-5, 3e-4, 3e-4, 0.0, "linear", 0),
         "box_push": ("fancy_ProDMP_TCE/BoxPushingDense-v0", 7, 2.0, 0.0, 10, 3,
                      0.3, 0.3, False, 0.02, "leaky_relu", (128, 2), (256, 2),
-                     0.05, 0.0005, 1e-4),
+                     0.05, 0.0005, 1e-4, 1e-4, 1e-3, 5e-5, "linear", 0.0),
         "table_tennis": ("fancy_ProDMP_TCE/TableTennisRndInit-v0", 7, 0.75, 0.3,
                          25, 3, 0.7, 0.1, True, 0.008, "tanh", (256, 1),
-                         (256, 2), 0.005, 0.00025, 1e-5),
+                         (256, 2), 0.005, 0.00025, 1e-5, 3e-4, 3e-4, 1e-5,
+                         False, -1),
     }[env]
     (env_id, dof, tau, delay, alpha, bbf, ws, gs, rel, dt, act, ph, ch, mb, cb,
-     min_std) = fam
+     min_std, lr_p, lr_c, wd, ent_sched, ent_target) = fam
     mp = {"type": "prodmp", "args": dict(
         num_dof=dof, tau=tau, delay=delay, alpha_phase=3, num_basis=num_basis,
         basis_bandwidth_factor=bbf, num_basis_outside=0, alpha=alpha,
@@ -29,7 +34,7 @@ def tce_config(env="metaworld", num_env=4096, num_basis=8, dtype="float32",
     critic_act = "leaky_relu" if env == "table_tennis" else act
     params = {
         "agent": {"type": "TemporalCorrelatedAgent", "args": dict(
-            lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0, wd_critic=0.0,
+            lr_policy=lr_p, lr_critic=lr_c, wd_policy=wd, wd_critic=wd,
             schedule_lr_policy=True, schedule_lr_critic=True, clip_critic=0.0,
             clip_grad_norm=0.0, entropy_penalty_coef=0.0, discount_factor=1,
             gae_scaling=0.95, epochs_policy=epochs, epochs_critic=epochs,
@@ -52,8 +57,8 @@ def tce_config(env="metaworld", num_env=4096, num_basis=8, dtype="float32",
             device=device)},
         "projection": {"type": "KLProjectionLayer", "args": dict(
             proj_type="kl", mean_bound=mb, cov_bound=cb,
-            trust_region_coeff=1.0, scale_prec=True, entropy_schedule="linear",
-            target_entropy=0, temperature=0.7, entropy_eq=False,
+            trust_region_coeff=1.0, scale_prec=True, entropy_schedule=ent_sched,
+            target_entropy=ent_target, temperature=0.7, entropy_eq=False,
             entropy_first=False, do_regression=False, dtype=dtype,
             device=device)},
         "sampler": {"type": "TemporalCorrelatedSampler", "args": dict(

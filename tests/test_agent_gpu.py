@@ -674,6 +674,135 @@ def test_full_size_step_is_repeatable_and_inside_the_trust_region():
     assert ra["num_global_steps"] == 2 * 4096 * 500
 
 
+@pytest.mark.parametrize("env,N,nb,dtype", [
+    ("box_push", 8192, 8, "float64"),            # BASELINE configs[2] as the reference runs it
+    ("table_tennis", 4096, 8, "float32"),        # configs[4], one GPU's shard, K 63
+    ("table_tennis", 4096, 3, "float32")])       # ... with the reference's 3 basis functions
+def test_full_size_steps_of_the_other_configs(env, N, nb, dtype):
+    """BASELINE configs[2] and [4] at their stated env counts (per GPU), the
+    size-independent properties test_full_size_step_... checks for configs[1]:
+    two runs from the same seeds end bit-identical, the projected policy stays
+    inside the KL bounds, nothing is non-finite, the step count is N x T x
+    iterations.  (50 + 50 epochs like the benchmark would take a minute per
+    case in float64: 6 + 6 epochs exercise the same launches.)"""
+    runs = []
+    T = {"box_push": 100, "table_tennis": 350}[env]
+    for _ in range(2):
+        torch.manual_seed(11)
+        agent, cfg = build(N, 6, True, env=env, num_basis=nb, dtype=dtype,
+                           adaptive_critic_split=False)
+        torch.manual_seed(12)
+        res = [agent.step() for _ in range(2)][-1]
+        runs.append((res, to_cpu_params(agent.policy.mean_net),
+                     to_cpu_params(agent.critic.net),
+                     agent.policy.variance_net.variable.detach().cpu().clone()))
+        del agent
+        torch.cuda.empty_cache()
+    (ra, pa, ca, va), (rb, pb, cb, vb) = runs
+    for x, y in zip(pa + ca + [va], pb + cb + [vb]):
+        assert torch.equal(x, y)
+    p = cfg["params"]["projection"]["args"]
+    assert ra["projection_proj_old_cov_diff_max"] <= p["cov_bound"] * 1.02
+    assert ra["projection_proj_old_mean_diff_max"] <= p["mean_bound"] * 1.02
+    for k, v in ra.items():
+        if isinstance(v, float):
+            assert np.isfinite(v), k
+    assert ra["num_global_steps"] == 2 * N * T
+
+
+def test_full_size_bbrl_shard_is_repeatable():
+    """BASELINE configs[3], one GPU's 4096-env shard, the reference's 100 + 100
+    epochs (mprl/config/metaworld/bbrl/entire/shared.yaml:38-39): two runs end
+    bit-identical (fixed slab order in csrc/smlp.hip), nothing is non-finite,
+    the variance set from the projection stays positive."""
+    from tce_rl_amd.config import bbrl_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        cfg = bbrl_config(num_env=4096, epochs=100)
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        agent = exp.agent
+        torch.manual_seed(12)
+        res = [agent.step() for _ in range(2)][-1]
+        runs.append((res, to_cpu_params(agent.policy.mean_net),
+                     to_cpu_params(agent.critic.net),
+                     agent.policy.variance_net.variable.detach().cpu().clone()))
+        del agent, exp
+    (ra, pa, ca, va), (rb, pb, cb, vb) = runs
+    for x, y in zip(pa + ca + [va], pb + cb + [vb]):
+        assert torch.equal(x, y)
+    for k, v in ra.items():
+        if isinstance(v, float):
+            assert np.isfinite(v), k
+    assert ra["num_global_steps"] == 2 * 4096 * 500
+    assert np.isfinite(ra["projection_kl"]) and ra["projection_entropy"] != 0
+
+
+_RESOLVED = sorted(f[:-5] for f in __import__("os").listdir(
+    __import__("os").path.join(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__)), "golden", "resolved")))
+
+
+@pytest.mark.parametrize("doc", _RESOLVED)
+def test_step_from_the_references_resolved_documents(doc):
+    """f3: the reference's own experiment documents (every
+    mprl/config/<task>/<tcp|bbrl>/entire/local.yaml resolved against its
+    shared.yaml; VALUES committed under tests/golden/resolved/ by
+    make_resolved_cfg.py) drive MPExperiment + agent.step() on the GPU, one
+    per task family and agent type.  Changed for the run: the env count (the
+    reference's 4 .. 38 MuJoCo processes -> 32 synthetic envs), the epochs
+    (2 + 2), the task metric names (the synthetic suite reports `success`) and
+    -- black-box documents, whose MP block leaves the phase / basis constants
+    to fancy_gym's defaults -- those constants."""
+    import json
+    import os
+    from tce_rl_amd.mp_exp import MPExperiment, dim_policy_out
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = json.load(open(os.path.join(here, "golden", "resolved", doc + ".json")))
+    p = d["params"]
+    for blk in p.values():
+        blk["args"]["device"] = "cuda"
+    sa = p["sampler"]["args"]
+    sa.update(num_env_train=32, num_env_test=8, task_specified_metrics=["success"])
+    p["agent"]["args"].update(epochs_policy=2, epochs_critic=2,
+                              evaluation_interval=0)
+    fam = "TableTennis" if "TableTennis" in sa["env_id"] else \
+        "BoxPushing" if "BoxPushing" in sa["env_id"] else \
+        "HopperJump" if "HopperJump" in sa["env_id"] else "metaworld"
+    defaults = {"metaworld": dict(alpha=10, dt=0.0125),
+                "BoxPushing": dict(alpha=10, dt=0.02),
+                "TableTennis": dict(alpha=25, dt=0.008),
+                "HopperJump": dict(alpha=25, dt=0.008)}[fam]
+    for k, v in dict(defaults, alpha_phase=3, basis_bandwidth_factor=3,
+                     dtype=p["agent"]["args"]["dtype"],
+                     device="cuda").items():
+        p["mp"]["args"].setdefault(k, v)
+    if "mp" in sa:
+        sa["mp"] = p["mp"]
+    if "mp" in p["policy"]["args"]:
+        p["policy"]["args"]["mp"] = p["mp"]
+    cfg = {"name": d["name"], "seed": 0, "iterations": d["iterations"],
+           "params": p}
+    torch.manual_seed(0)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    agent = exp.agent
+    assert agent.policy.dim_out == dim_policy_out(p)
+    assert type(agent).__name__ == p["agent"]["type"]
+    for _ in range(2):
+        res = agent.step()
+    for k in ("critic_loss_mean", "surrogate_loss_mean", "policy_loss_mean",
+              "trust_region_loss_mean", "entropy_mean"):
+        assert np.isfinite(res[k]), k
+    for q in agent.policy.parameters + agent.critic.parameters:
+        assert torch.isfinite(q).all()
+    want = torch.float64 if "64" in str(p["agent"]["args"]["dtype"]) \
+        else torch.float32
+    assert agent.policy.parameters[0].dtype == want
+
+
 def test_objective_on_one_stream_equals_two_streams(monkeypatch):
     """tce_policy_objective_streams(1) -- what a sharded run uses, where the
     second stream would share a hardware queue with the critic's -- runs the

@@ -64,3 +64,80 @@ def test_reference_config_files_resolve():
                     assert hasattr(mod, p[blk]["type"]), (root, p[blk]["type"])
                 n += 1
     assert n >= 4
+
+
+# ---------------------------------------------------------------------------
+# tce_rl_amd.config (hyper-parameters typed by hand for the BASELINE points)
+# against the reference's own resolved documents (tests/golden/resolved/*.json,
+# written by tests/golden/make_resolved_cfg.py from mprl/config/*/*/entire/)
+# ---------------------------------------------------------------------------
+RES = os.path.join(HERE, "golden", "resolved")
+# keys that are deployment choices, not hyper-parameters
+_SKIP = {"device", "dtype", "seed", "total_iterations", "total_train_steps",
+         "num_env_train", "num_env_test", "env_id", "evaluation_interval",
+         "episodes_per_train_env", "episodes_per_test_env", "mp",
+         # the synthetic env suite reports its own task metrics
+         "task_specified_metrics",
+         # accepted by get_mp, only False is supported (mp/prodmp.py)
+         "learn_tau", "learn_delay"}
+
+
+def _num(v):
+    try:
+        return float(v)                 # "3e-4" is a string for YAML 1.1
+    except (TypeError, ValueError):
+        return v
+
+
+def _diff(ours, ref, path=""):
+    out = []
+    for k, rv in ref.items():
+        if k in _SKIP:
+            continue
+        if k not in ours:
+            out.append("%s%s missing (reference: %r)" % (path, k, rv))
+        elif isinstance(rv, dict):
+            out += _diff(ours[k], rv, path + k + ".")
+        elif _num(ours[k]) != _num(rv):
+            out.append("%s%s = %r, reference %r" % (path, k, ours[k], rv))
+    return out
+
+
+@pytest.mark.parametrize("fixture,env,nb", [
+    ("metaworld_tcp", "metaworld", 8),
+    ("box_push_random_init_tcp", "box_push", 8),
+    ("table_tennis_4d_tcp", "table_tennis", 3)])
+def test_tce_config_matches_the_reference_documents(fixture, env, nb):
+    import json
+    from tce_rl_amd.config import tce_config
+    ref = json.load(open(os.path.join(RES, fixture + ".json")))["params"]
+    ours = tce_config(env, num_basis=nb)["params"]
+    problems = []
+    for blk in ("agent", "mp", "policy", "critic", "projection", "sampler"):
+        assert ours[blk]["type"] == ref[blk]["type"]
+        problems += _diff(ours[blk]["args"], ref[blk]["args"], blk + ".")
+    assert not problems, "\n".join(problems)
+
+
+def test_bbrl_config_matches_the_reference_document():
+    import json
+    from tce_rl_amd.config import bbrl_config
+    ref = json.load(open(os.path.join(RES, "metaworld_bbrl.json")))["params"]
+    ours = bbrl_config()["params"]
+    problems = []
+    for blk in ("agent", "mp", "policy", "critic", "projection", "sampler"):
+        assert ours[blk]["type"] == ref[blk]["type"]
+        problems += _diff(ours[blk]["args"], ref[blk]["args"], blk + ".")
+    assert not problems, "\n".join(problems)
+
+
+def test_resolved_fixtures_are_current():
+    """The committed fixtures equal what the generator writes from the
+    reference tree today (runs where /root/reference exists)."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not here")
+    import json
+    for f in sorted(os.listdir(RES)):
+        doc = json.load(open(os.path.join(RES, f)))
+        cfg = mp_exp.load_config(os.path.join("/root/reference", doc["source"]))
+        assert json.loads(json.dumps(cfg["params"])) == doc["params"], f

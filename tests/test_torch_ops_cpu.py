@@ -10,7 +10,11 @@ def test_ops_are_registered_with_schemas():
     ns = torch.ops.tce_rl_amd
     for name in ("gae", "segment_advantage", "mdp_reward", "rms_update",
                  "mvn_log_prob", "maha", "kl_mean_projection",
-                 "kl_cov_projection", "critic_values"):
+                 "kl_cov_projection", "critic_values",
+                 # SURVEY 8b's list, completed in round 3
+                 "prodmp_traj", "prodmp_pair_logprob", "mvn_rsample",
+                 "mvn_entropy", "critic_epoch", "adam_flat", "flat_grad_norm",
+                 "allreduce_flat"):
         op = getattr(ns, name)
         assert "tce_rl_amd::" + name in str(op.default._schema)
     s = str(ns.rms_update.default._schema)            # mutation is declared
@@ -36,6 +40,17 @@ def test_fake_implementations_infer_shapes():
         assert ns.kl_mean_projection(x, x, L, 0.01).shape == (8, 5)
         proj, ctx = ns.kl_cov_projection(torch.empty(1, 5, 5), L, 1e-3)
         assert proj.shape == (1, 5, 5) and ctx.dtype == torch.float64
+        assert ns.mvn_rsample(x, L, x).shape == (8, 5)
+        assert ns.mvn_entropy(torch.empty(3, 5, 5)).shape == (3,)
+        w1, b1, w2 = torch.empty(128, 39), torch.empty(128), \
+            torch.empty(128, 128)
+        stats, grad = ns.critic_epoch(torch.empty(100, 39), torch.empty(100),
+                                      torch.empty(100), 0.0, w1, b1, w2, b1,
+                                      torch.empty(1, 128), torch.empty(1),
+                                      "relu")
+        assert stats.shape == (2,) and grad.shape == (128 * 39 + 128 + 128 * 128
+                                                      + 128 + 128 + 1,)
+        assert ns.flat_grad_norm(torch.empty(10), 1.0).shape == (3,)
 
 
 def test_no_cpu_implementation():

@@ -140,3 +140,152 @@ def test_opcheck():
     opcheck(ns.kl_mean_projection.default, (m, x, L, 0.05), test_utils=tests)
     mean, var = torch.zeros(K, device="cuda"), torch.ones(K, device="cuda")
     opcheck(ns.rms_update.default, (x, mean, var, 1e-4), test_utils=tests)
+
+
+def _mp_case(N=40, seed=4):
+    from tce_rl_amd import ops
+    from tce_rl_amd.mp import ProDMP
+    from tce_rl_amd.util import select_pred_pairs
+    g = torch.Generator().manual_seed(seed)
+    mp = ProDMP(num_dof=4, num_basis=5, tau=5.0, alpha_phase=3, alpha=10,
+                dt=0.0125, basis_bandwidth_factor=5, weights_scale=0.1,
+                goal_scale=0.1, relative_goal=True, dtype=torch.float32,
+                device="cuda")
+    K, T = 24, 500
+    t0 = torch.zeros(N, device="cuda")
+    times = ops.times(t0, mp.dt, T)
+    w = (0.1 * torch.randn(N, K, generator=g)).cuda()
+    y0 = torch.rand(N, 4, generator=g).cuda()
+    v0 = torch.zeros(N, 4, device="cuda")
+    L = _chol(K, g)
+    torch.manual_seed(0)
+    pairs = select_pred_pairs(num_all=T, num_select=25,
+                              fixed_interval=True).to(torch.long).cuda()
+    return mp, times, w, t0, y0, v0, L, pairs
+
+
+def test_prodmp_ops_equal_the_op_layer():
+    """prodmp_traj / prodmp_pair_logprob (+ backward) through the dispatcher ==
+    the direct op layer (itself held to the oracle in test_prodmp_gpu.py)."""
+    import tce_rl_amd.torch_ops as T
+    from tce_rl_amd import ops
+    ns = torch.ops.tce_rl_amd
+    mp, times, w, t0, y0, v0, L, pairs = _mp_case()
+    h = T.mp_handle(mp)
+    traj = ns.prodmp_traj(h, times, w, t0, y0, v0)
+    assert torch.equal(traj, ops.prodmp_traj(mp, times, w, t0, y0, v0))
+    N = w.shape[0]
+    gsum = torch.randn(N, pairs.shape[0], device="cuda")
+    m1, L1 = w.clone().requires_grad_(True), L.clone().requires_grad_(True)
+    lp1 = ns.prodmp_pair_logprob(h, traj, m1, L1, times, t0, y0, v0, pairs)
+    (lp1 * gsum).sum().backward()
+    m2, L2 = w.clone().requires_grad_(True), L.clone().requires_grad_(True)
+    lp2 = ops.pair_log_prob(mp, traj, m2, ops.expand_shared(L2, N), times, t0,
+                            y0, v0, pairs)
+    (lp2 * gsum).sum().backward()
+    torch.testing.assert_close(lp1, lp2, rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(m1.grad, m2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(torch.tril(L1.grad), torch.tril(L2.grad),
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_sampling_entropy_and_optimizer_ops():
+    import tce_rl_amd.torch_ops  # noqa: F401
+    from tce_rl_amd import ops
+    ns = torch.ops.tce_rl_amd
+    g = torch.Generator().manual_seed(5)
+    N, K = 50, 20
+    mean = torch.randn(N, K, generator=g).cuda()
+    eps = torch.randn(N, K, generator=g).cuda()
+    L = _chol(K, g)
+    smp = ns.mvn_rsample(mean, L, eps)
+    torch.testing.assert_close(smp, mean + eps @ L.T, rtol=1e-5, atol=1e-5)
+    La = L.clone().requires_grad_(True)
+    ent = ns.mvn_entropy(La)
+    ref = torch.distributions.MultivariateNormal(
+        torch.zeros(K, device="cuda", dtype=torch.float64),
+        scale_tril=L.double()).entropy()
+    torch.testing.assert_close(ent.double(), ref, rtol=1e-6, atol=1e-6)
+    ent.backward()
+    torch.testing.assert_close(La.grad, torch.diag(1.0 / L.diagonal()),
+                               rtol=1e-6, atol=1e-6)
+    # adam_flat == torch.optim.Adam with clip_grad_norm_
+    n = 1000
+    p0 = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    p = p0.cuda().clone()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    st = torch.zeros(4, device="cuda")
+    q = p0.double().clone().requires_grad_(True)
+    opt = torch.optim.Adam([q], lr=1e-2, weight_decay=1e-3)
+    for _ in range(3):
+        ns.adam_flat(p, gr.cuda(), m, v, st, 1e-2, 0.9, 0.999, 1e-8, 1e-3, 5.0,
+                     1.0)
+        q.grad = gr.double().clone()
+        torch.nn.utils.clip_grad_norm_([q], 5.0)
+        opt.step()
+    torch.testing.assert_close(p.cpu().double(), q.detach(), rtol=0, atol=2e-6)
+    assert float(st[0]) == 3.0
+    norms = ns.flat_grad_norm(gr.cuda(), 5.0).cpu()
+    assert norms[0].item() == pytest.approx(gr.norm().item(), rel=1e-6)
+    assert norms[1].item() == pytest.approx(min(5.0, gr.norm().item()), rel=1e-5)
+    flat = gr.cuda().clone()
+    ns.allreduce_flat(flat, True)                 # no process group: identity
+    assert torch.equal(flat, gr.cuda())
+
+
+def test_critic_epoch_op():
+    """critic_epoch == torch autograd of the same network and loss (fp64)."""
+    import tce_rl_amd.torch_ops  # noqa: F401
+    from tce_rl_amd.nn import MLP
+    torch.manual_seed(0)
+    mlp = MLP("ValueFunction", 39, 1, [128, 128], "orthogonal", 1.0, "relu",
+              None, torch.float32, torch.device("cuda"))
+    R = 5000
+    x = torch.randn(R, 48, device="cuda")[:, :39]
+    ret = 2 * torch.randn(R, device="cuda")
+    old = ret + 0.3 * torch.randn(R, device="cuda")
+    ls = mlp.layers
+    ws = [ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, ls[2].weight,
+          ls[2].bias]
+    stats, grad = torch.ops.tce_rl_amd.critic_epoch(x, ret, old, 0.2, *ws,
+                                                    "relu")
+    ref = [w.detach().double().clone().requires_grad_(True) for w in ws]
+    h = torch.relu(x.double() @ ref[0].t() + ref[1])
+    h = torch.relu(h @ ref[2].t() + ref[3])
+    v = (h @ ref[4].t() + ref[5]).squeeze(-1)
+    l = (ret.double() - v) ** 2
+    vc = old.double() + (v - old.double()).clamp(-0.2, 0.2)
+    loss = torch.max(l, (vc - ret.double()) ** 2).mean()
+    loss.backward()
+    flat = torch.cat([w.grad.reshape(-1) for w in ref])
+    assert stats[0].item() == pytest.approx(loss.item(), rel=1e-5)
+    torch.testing.assert_close(grad.double(), flat, rtol=1e-3, atol=2e-6)
+    assert stats[1].item() == pytest.approx((flat ** 2).sum().item(), rel=1e-4)
+
+
+def test_opcheck_of_the_round3_ops():
+    import tce_rl_amd.torch_ops as T
+    from torch.library import opcheck
+    ns = torch.ops.tce_rl_amd
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    mp, times, w, t0, y0, v0, L, pairs = _mp_case(N=8)
+    h = T.mp_handle(mp)
+    opcheck(ns.prodmp_traj.default, (h, times, w, t0, y0, v0), test_utils=tests)
+    traj = ns.prodmp_traj(h, times, w, t0, y0, v0)
+    opcheck(ns.prodmp_pair_logprob.default,
+            (h, traj, w.clone().requires_grad_(True),
+             L.clone().requires_grad_(True), times, t0, y0, v0, pairs),
+            test_utils=tests)
+    eps = torch.randn_like(w)
+    opcheck(ns.mvn_rsample.default, (w, L, eps), test_utils=tests)
+    opcheck(ns.mvn_entropy.default, (L.clone().requires_grad_(True),),
+            test_utils=tests)
+    n = 64
+    p, gr = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    m, v, st = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), \
+        torch.zeros(4, device="cuda")
+    opcheck(ns.adam_flat.default, (p, gr, m, v, st, 1e-3, 0.9, 0.999, 1e-8,
+                                   0.0, 0.0, 1.0), test_utils=tests)
+    opcheck(ns.flat_grad_norm.default, (gr, 1.0), test_utils=tests)
+    opcheck(ns.allreduce_flat.default, (gr.clone(), False), test_utils=tests)
