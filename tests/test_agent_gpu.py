@@ -771,10 +771,10 @@ def test_step_from_the_references_resolved_documents(doc):
     fam = "TableTennis" if "TableTennis" in sa["env_id"] else \
         "BoxPushing" if "BoxPushing" in sa["env_id"] else \
         "HopperJump" if "HopperJump" in sa["env_id"] else "metaworld"
-    defaults = {"metaworld": dict(alpha=10, dt=0.0125),
-                "BoxPushing": dict(alpha=10, dt=0.02),
-                "TableTennis": dict(alpha=25, dt=0.008),
-                "HopperJump": dict(alpha=25, dt=0.008)}[fam]
+    defaults = {"metaworld": dict(alpha=10, dt=0.0125, tau=5.0),
+                "BoxPushing": dict(alpha=10, dt=0.02, tau=2.0),
+                "TableTennis": dict(alpha=25, dt=0.008, tau=0.75),
+                "HopperJump": dict(alpha=25, dt=0.008, tau=2.0)}[fam]
     for k, v in dict(defaults, alpha_phase=3, basis_bandwidth_factor=3,
                      dtype=p["agent"]["args"]["dtype"],
                      device="cuda").items():
