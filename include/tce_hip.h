@@ -653,6 +653,13 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
  * to 4); proj_ctx: double [tce_kl_cov_proj_ctx_len(K)], zeroed by the caller
  * once per update; mean_new_out / proj_mean_out (nullable) [N,K]: the last
  * epoch's means. */
+/* Skinny linear layer on rows, y [N][dout] = x [N][din] A (+ bias): transposed
+ * != 0: A = W^T for a torch Linear weight W [dout][din] (MLP.forward's output
+ * layer, mprl/util/util_nn.py:225-246); transposed == 0: A = W for W
+ * [din][dout] (its input gradient dX = dY W under autograd).  D_in <= 256,
+ * D_out <= 128; x rows may be strided, y is contiguous; bias nullable. */
+int tce_lin_rows_f32(const float* x, int64_t x_stride, int64_t N, int din, int dout,
+                     const float* W, int transposed, const float* bias, float* y, void* stream);
 int tce_smlp_supported(int din, int H, int dout, int head);
 int64_t tce_smlp_num_params(int din, int H, int dout);
 int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout);

@@ -1163,6 +1163,92 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Skinny linear layer on rows: y [N][dout] = x [N][din] A (+ b), A = W^T for a
+// torch Linear weight W [dout][din] (forward of an output layer) or A = W for
+// W [din][dout] (the input gradient dX = dY W of the same layer) -- the two
+// products around the policy mean net's output layer [N,128] <-> [N,K] that
+// were the last library GEMMs of a TCE policy epoch.  Lane = row, the four
+// waves split the outputs (OPW each, in registers), A sits in LDS as
+// [din][4 OPW] and is read as broadcast 16-byte pieces, the x tile as
+// row-major [64][pitch 4 x odd].
+template <int OPW>
+__global__ __launch_bounds__(SBT) void lin_rows_kernel(const float* __restrict__ x,
+                                                       int64_t x_stride, int64_t N, int din,
+                                                       int dout, const float* __restrict__ W,
+                                                       int transposed,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  constexpr int DP = 4 * OPW;                              // padded outputs
+  const int dinp = s_up4(din), xp = s_pitch(din);
+  float* As = S;                                           // [dinp][DP]
+  float* Bs = As + dinp * DP;                              // [DP]
+  float* Xs = Bs + DP;                                     // [64][xp]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < dinp * DP; e += SBT) {
+    const int i = e / DP, o = e - i * DP;
+    float v = 0.f;
+    if (i < din && o < dout) v = transposed ? W[(int64_t)o * din + i] : W[(int64_t)i * dout + o];
+    As[e] = v;
+  }
+  for (int e = tid; e < DP; e += SBT) Bs[e] = (bias && e < dout) ? bias[e] : 0.f;
+  for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < N; r0 += (int64_t)gridDim.x * SR) {
+    __syncthreads();
+    for (int e = tid; e < SR * dinp; e += SBT) {
+      const int r = e / dinp, c = e - r * dinp;
+      const int64_t row = r0 + r;
+      Xs[r * xp + c] = (c < din && row < N) ? x[row * x_stride + c] : 0.f;
+    }
+    __syncthreads();
+    float acc[OPW];
+#pragma unroll
+    for (int u = 0; u < OPW; ++u) acc[u] = Bs[wave * OPW + u];
+    for (int i0 = 0; i0 < dinp; i0 += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(Xs + lane * xp + i0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float* ar = As + (i0 + t) * DP + wave * OPW;
+#pragma unroll
+        for (int u = 0; u < OPW; u += 4) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ar + u);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[u + q] += av[q] * xv[t];
+        }
+      }
+    }
+    // through LDS for coalesced row stores: y tile [64][dout]
+    __syncthreads();
+    float* Ys = Xs;                                        // reuse (xp >= ... see host check)
+    const int yp = s_pitch(DP);
+#pragma unroll
+    for (int u = 0; u < OPW; u += 4)
+      *reinterpret_cast<f32x4*>(Ys + lane * yp + wave * OPW + u) =
+          f32x4{acc[u], acc[u + 1], acc[u + 2], acc[u + 3]};
+    __syncthreads();
+    for (int e = tid; e < SR * dout; e += SBT) {
+      const int r = e / dout, o = e - r * dout;
+      if (r0 + r < N) y[(r0 + r) * dout + o] = Ys[r * yp + o];
+    }
+  }
+}
+
+inline int s_grid(int64_t N) { return (int)tmin<int64_t>(ceil_div(N, SR), S_MAX_GRID); }
+
+template <int OPW>
+int lin_rows_launch(const float* x, int64_t x_stride, int64_t N, int din, int dout, const float* W,
+                    int transposed, const float* bias, float* y, hipStream_t st) {
+  constexpr int DP = 4 * OPW;
+  const int tile = SR * (s_pitch(din) > s_pitch(DP) ? s_pitch(din) : s_pitch(DP));
+  const size_t lds = sizeof(float) * ((size_t)s_up4(din) * DP + DP + tile);
+  TCE_CHECK_ARG(lds <= S_LDS_MAX, "lin_rows: shape does not fit the LDS");
+  tce_lds_limit(reinterpret_cast<const void*>(lin_rows_kernel<OPW>), lds);
+  hipLaunchKernelGGL(lin_rows_kernel<OPW>, dim3(s_grid(N)), dim3(SBT), lds, st, x, x_stride, N,
+                     din, dout, W, transposed, bias, y);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 inline bool s_shape_ok(int din, int H, int dout) {
   return din >= 1 && din <= 64 && (H == 32 || H == 64) && dout >= 1 && dout <= 64;
 }
@@ -1170,7 +1256,6 @@ inline size_t s_lds_bytes(int din, int H, int dout, int head) {
   if (head == HEAD_NONE) return sizeof(float) * (size_t)s_forward_lds_floats(din, H, dout);
   return sizeof(float) * (size_t)s_lds(din, H, dout, head).total;
 }
-inline int s_grid(int64_t N) { return (int)tmin<int64_t>(ceil_div(N, SR), S_MAX_GRID); }
 
 template <int H, int ACT, int HEAD, int KP>
 int s_launch_epoch(const SNet& n, const SValueHead& vh, const SPolicyHead& ph, const SReduce& rd,
@@ -1405,6 +1490,18 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
     TCE_LAUNCH_CHECK();
   }
   return 0;
+}
+
+int tce_lin_rows_f32(const float* x, int64_t x_stride, int64_t N, int din, int dout,
+                     const float* W, int transposed, const float* bias, float* y, void* stream) {
+  TCE_CHECK_ARG(x && W && y && N > 0 && din >= 1 && din <= 256 && dout >= 1 && dout <= 128 &&
+                    x_stride >= din,
+                "lin_rows: bad arguments (D_in <= 256, D_out <= 128)");
+  hipStream_t st = (hipStream_t)stream;
+  if (dout <= 16) return lin_rows_launch<4>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
+  if (dout <= 32) return lin_rows_launch<8>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
+  if (dout <= 64) return lin_rows_launch<16>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
+  return lin_rows_launch<32>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
 }
 
 int64_t tce_bb_policy_mats_len(int K) { return 7 * (int64_t)s_up4(K * K) + 16; }

@@ -301,12 +301,19 @@ class DirectEpoch:
             call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
                  *[ptr(t) for t in self.w], self.act, None, ptr(h2), None,
                  None, None, st)
-            mean = torch.addmm(self.b3, h2, self.w3.t())
+            # output layer [N,128] -> [N,K] and, below, its input gradient: the
+            # row kernel of csrc/smlp.hip (tce_lin_rows_f32) -- no library GEMM
+            # is left in the epoch
+            mean = new(N, K)
+            call("tce_lin_rows_f32", ptr(h2), 128, N, 128, K, ptr(self.w3), 1,
+                 ptr(self.b3), ptr(mean), st)
             g_mean, g_L, sur, out = evaluate(mean, L[0], c, started=True,
                                              defer=True)
             # ---- backward into the flat gradient.  The hidden layers' launch
             # fills [0, P) (its w3 / b3 slots with zeros), so it goes first.
-            gh = torch.mm(g_mean, self.w3)
+            gh = new(N, 128)
+            call("tce_lin_rows_f32", ptr(g_mean), K, N, K, 128, ptr(self.w3),
+                 0, None, ptr(gh), st)
             call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
                  *[ptr(t) for t in self.w], self.act, ptr(gh), None,
                  ptr(self.partials), ptr(self.opt.flat_grad), ptr(self.stats),

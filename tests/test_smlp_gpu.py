@@ -229,3 +229,24 @@ def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
                                atol=1e-6)
     torch.testing.assert_close(pL.cpu().double(), last[3], rtol=1e-4,
                                atol=1e-6)
+
+
+@pytest.mark.parametrize("N,din,dout,transposed", [
+    (4096, 128, 24, True), (4096, 24, 128, False), (70, 128, 63, True),
+    (1000, 63, 128, False), (129, 256, 36, True), (5, 7, 3, True),
+    (300, 20, 100, False)])
+def test_lin_rows(N, din, dout, transposed):
+    """tce_lin_rows_f32 (the output layer of the policy mean net and its input
+    gradient) against torch in float64."""
+    from tce_rl_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(N + din)
+    x = torch.randn(N, din + 4, generator=g).cuda()[:, :din]
+    W = torch.randn(*((dout, din) if transposed else (din, dout)),
+                    generator=g).cuda()
+    b = torch.randn(dout, generator=g).cuda() if transposed else None
+    y = torch.empty(N, dout, device="cuda")
+    call("tce_lin_rows_f32", ptr(x), x.stride(0), N, din, dout, ptr(W),
+         int(transposed), ptr(b), ptr(y), stream())
+    A = W.double().t() if transposed else W.double()
+    ref = x.double() @ A + (b.double() if b is not None else 0)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-4)
