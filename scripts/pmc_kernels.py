@@ -39,6 +39,14 @@ runw = critic_ops.make_runner(wide)
 for _ in range(3):
     big.fill_(1.0)
     runw.epoch(xw, rw, rw, 0.0)
+# round 3: the same critic in float64
+wide64 = MLP("ValueFunction", 22, 1, [256, 256], "orthogonal", 1.0, "leaky_relu", None, torch.float64, torch.device("cuda"))
+runw64 = critic_ops.make_runner(wide64)
+xw64, rw64 = xw.double(), rw.double()
+for _ in range(3):
+    big.fill_(1.0)
+    runw64.epoch(xw64, rw64, rw64, 0.0)
+del xw64, rw64
 acts = torch.randn(N, T, 8, device="cuda", generator=g); obs0 = torch.randn(N, 48, device="cuda", generator=g); shift = torch.zeros(48, device="cuda")
 for _ in range(3):
     big.fill_(1.0)
