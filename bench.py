@@ -126,6 +126,20 @@ def profiled_us(kernel_substr):
     return None, None
 
 
+def wide_traffic(tag, rows):
+    """(HBM bytes per epoch of the wide critic -- chain + gradient kernel --,
+    source) from the committed PMC passes, which ran at 819 200 rows (C3);
+    other row counts are scaled (the traffic is per-row activations)."""
+    key = "<float" if tag in ("f32", "float32") else "<double"
+    a, src = pmc_lookup("mlpw_chain_kernel" + key)
+    b, _ = pmc_lookup("mlpw_grad_kernel" + key)
+    if a is None or b is None:
+        return None, None
+    if rows != 819200:
+        return int((a + b) * rows / 819200), src + " (819 200 rows, scaled to %d)" % rows
+    return a + b, src
+
+
 def hbm_entry(name, alg, us, us_cold=None, note=None, pmc_kernel=None):
     traffic, src = pmc_lookup(pmc_kernel) if pmc_kernel else (None, None)
     d = {"kernel": name, "bound": "hbm", "achieved": round(alg / us / 1e3, 1),
@@ -308,11 +322,8 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
             "bound": "mfma", "achieved": round(fl / us_w / 1e6, 2),
             "peak": peak, "unit": "TFLOP/s",
             "frac": round(fl / us_w / 1e6 / peak, 4),
-            "traffic": (None if tag != "f32" or pmc_traffic("mlpw_chain_kernel")
-                        is None else pmc_traffic("mlpw_chain_kernel") +
-                        pmc_traffic("mlpw_grad_kernel")),
-            "traffic_source": pmc_source("mlpw_chain_kernel")
-            if tag == "f32" else None,
+            "traffic": wide_traffic(tag, n3 * t3)[0],
+            "traffic_source": wide_traffic(tag, n3 * t3)[1],
             "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
             "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
                         "D_in 22 -> 256 -> 256 -> 1, leaky_relu",
@@ -428,7 +439,10 @@ def run_config(name, spec, steps, warmup):
             "peak": peak, "unit": "TFLOP/s",
             "frac": round(flops / us / 1e6 / peak, 4),
             "us_per_launch": round(us, 1), "algorithmic_flops": flops,
-            "traffic": None,
+            "traffic": wide_traffic(spec["dtype"], rows)[0]
+            if hs[0] == 256 else None,
+            "traffic_source": wide_traffic(spec["dtype"], rows)[1]
+            if hs[0] == 256 else None,
             "measured": "HIP events around the %d critic epochs of every "
                         "timed step, policy epochs on a second stream" % E}
     else:
