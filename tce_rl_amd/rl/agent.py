@@ -160,7 +160,8 @@ class AbstractAgent(ABC):
         pool_key: graphs that are replayed CONCURRENTLY (the black-box agent's
         critic and policy epochs) must not share a memory pool."""
         if getattr(self, "_graph_stream", None) is None:
-            self._graph_stream = torch.cuda.Stream(device=self.device)
+            from .. import streams
+            self._graph_stream = streams.get("graph", self.device)
             self._graph_pools = {}
         if pool_key not in self._graph_pools:
             self._graph_pools[pool_key] = torch.cuda.graph_pool_handle()
@@ -502,7 +503,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         units [32 - n, 32) of every XCD, the policy the rest)."""
         n = self.critic_cus_per_xcd
         if not n:
-            self._policy_stream, self._critic_stream = torch.cuda.Stream(), None
+            from .. import streams
+            self._policy_stream, self._critic_stream = \
+                streams.get("policy", self.device), None
             return
         import ctypes
         from .. import _lib
@@ -963,7 +966,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             # epoch, replayed from HIP graphs: side by side on two streams
             main = torch.cuda.current_stream()
             if getattr(self, "_bb_stream", None) is None:
-                self._bb_stream = torch.cuda.Stream(device=self.device)
+                from .. import streams
+                self._bb_stream = streams.get("policy", self.device)
             side = self._bb_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
