@@ -488,6 +488,39 @@ int tce_policy_record_f32(const float* sur2, const float* out16, const float* no
 int tce_policy_record_f64(const double* sur2, const double* out16, const double* norms2,
                           double ent_coef, double* row19, void* stream);
 
+/* One whole TCE policy epoch WITHOUT autograd in one call (the loop body of
+ * update_policy, mprl/rl/agent/temporal_correlated_agent.py:523-612, for a
+ * non-contextual covariance and a D_in <= 40 -> 128 -> 128 -> K float32 mean
+ * net): Cholesky head + covariance projection (second stream), mean net
+ * forward (tce_mlp_hidden_f32 + tce_lin_rows_f32), tce_policy_objective_f32
+ * (deferred join), the parameter gradients written straight into the flat
+ * gradient `grad` (tce_lin_rows_f32, tce_mlp_hidden_f32 backward,
+ * tce_out_layer_grad, tce_policy_objective_end, tce_chol_build_bwd), then --
+ * do_adam -- tce_adam_flat on all parameters and tce_policy_record into
+ * rec_row19.  param / grad / m / v: FLAT in the order W1 [128][din] | b1 | W2 |
+ * b2 | W3 [K][128] | b3 | variance vector [nvec].  x [N, din] rows with stride
+ * x_stride.  The objective's arguments (mean_old ... obj_ws) are those of
+ * tce_policy_objective_f32 (obj_ws = its `ws`); ws: float
+ * [tce_policy_epoch_ws_len(N, K)]; partials: float [min(tce_mlp_critic_grid(),
+ * ceil(N / 64))][tce_mlp_critic_num_params(din) + 2]; ol_ws: float
+ * [tce_out_layer_grad_ws_len(N, K, 128)].  After the call ws holds, behind
+ * 2 N 128 floats, mean_new [N,K] and its gradient.  do_adam == 0: the caller
+ * (env shards) all-reduces `grad`, steps and records itself. */
+int64_t tce_policy_epoch_ws_len(int64_t N, int K);
+int tce_policy_epoch_f32(
+    const float* x, int64_t x_stride, int64_t N, int din, int act, int nvec, float min_std,
+    float* param, float* grad, const float* mean_old, const float* L_old, const float* traj,
+    const float* logp_old, const float* adv, const int64_t* pairs, const float* tab, int M, int nbg,
+    float tau, float delay, float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
+    int times_flags_fwd, int times_flags_bwd, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, float* basis_ws, int* flag_ws, float* pair_work,
+    float eps_mean, double eps_cov, const float* beta, int entropy_eq, double* proj_ctx,
+    float tr_coeff, int tr_include_cov, float ent_coef, double* sur_ws, double* kl_ws,
+    float* obj_ws, float* ws, float* partials, float* ol_ws, int T, int P, int dof, int K,
+    float* m, float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
+    float weight_decay, float clip_grad, float grad_scale, int do_adam, float* rec_row19,
+    void* stream);
+
 /* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
  * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->
  * mprl/util/util_nn.py:225-246) -- on the kernels of the fused critic epoch.

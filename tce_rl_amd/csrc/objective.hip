@@ -788,6 +788,86 @@ int tce_out_layer_grad_f64(const double* grad_out, const double* hidden, double*
 DEFINE_KL_SHARED_MAT(f32, float)
 DEFINE_KL_SHARED_MAT(f64, double)
 
+// ---------------------------------------------------------------------------
+// One whole TCE policy epoch without autograd in ONE call (what
+// rl/objective.py:DirectEpoch.run issued as 12 separate calls: the epoch was
+// host-bound at 25 - 35 us per call): Cholesky head + covariance projection on
+// the second stream, mean net forward (two 128-wide hidden layers on the fused
+// MFMA kernel, output layer on the row kernel), the objective and its gradient
+// (deferred join), output layer input gradient, hidden layers' backward into
+// the flat gradient, output layer weight gradient, join, Cholesky head
+// backward, flat Adam (do_adam; a sharded caller all-reduces first), record.
+// Parameters FLAT in the order W1 [128][din] | b1 | W2 [128][128] | b2 | W3
+// [K][128] | b3 | variance vector [nvec] (the FlatAdam buffer of the policy).
+// ws: float [tce_policy_epoch_ws_len(N, K)].
+int64_t tce_policy_epoch_ws_len(int64_t N, int K) {
+  return 2 * obj_up4(N * 128) + 2 * obj_up4(N * (int64_t)K) + 2 * obj_up4((int64_t)K * K) + 32;
+}
+
+int tce_policy_epoch_f32(
+    const float* x, int64_t x_stride, int64_t N, int din, int act, int nvec, float min_std,
+    float* param, float* grad, const float* mean_old, const float* L_old, const float* traj,
+    const float* logp_old, const float* adv, const int64_t* pairs, const float* tab, int M, int nbg,
+    float tau, float delay, float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
+    int times_flags_fwd, int times_flags_bwd, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, float* basis_ws, int* flag_ws, float* pair_work,
+    float eps_mean, double eps_cov, const float* beta, int entropy_eq, double* proj_ctx,
+    float tr_coeff, int tr_include_cov, float ent_coef, double* sur_ws, double* kl_ws,
+    float* obj_ws, float* ws, float* partials, float* ol_ws, int T, int P, int dof, int K,
+    float* m, float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
+    float weight_decay, float clip_grad, float grad_scale, int do_adam, float* rec_row19,
+    void* stream) {
+  TCE_CHECK_ARG(x && param && grad && ws && partials && ol_ws && obj_ws && rec_row19 && N > 0 &&
+                    din >= 1 && din <= 40 && K == dof * nbg && K <= 64,
+                "policy_epoch: bad arguments");
+  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "policy_epoch: optimizer state missing");
+  const int H = 128;
+  float* w1 = param;
+  float* b1 = w1 + (int64_t)H * din;
+  float* w2 = b1 + H;
+  float* b2 = w2 + H * H;
+  float* w3 = b2 + H;
+  float* b3 = w3 + (int64_t)K * H;
+  float* var = b3 + K;
+  const int64_t PH = (int64_t)H * din + H + H * H + H;     // hidden-layer parameters
+  float* g_w3 = grad + PH;
+  float* g_b3 = g_w3 + (int64_t)K * H;
+  float* g_var = g_b3 + K;
+  float* h2 = ws;
+  float* gh = h2 + obj_up4(N * 128);
+  float* mean = gh + obj_up4(N * 128);
+  float* g_mean = mean + obj_up4(N * (int64_t)K);
+  float* L = g_mean + obj_up4(N * (int64_t)K);
+  float* g_L = L + obj_up4((int64_t)K * K);
+  float* sur2 = g_L + obj_up4((int64_t)K * K);
+  float* out16 = sur2 + 4;
+  float* stats = out16 + 16;
+  // ---- forward
+  OBJ_TRY(tce_policy_objective_begin_f32(var, nvec, min_std, L_old, eps_cov, beta, entropy_eq,
+                                         proj_ctx, L, obj_ws, N, K, P, stream));
+  OBJ_TRY(tce_mlp_hidden_f32(x, 0, x_stride, (int)N, N, din, w1, b1, w2, b2, act, nullptr, h2,
+                             nullptr, nullptr, nullptr, stream));
+  OBJ_TRY(tce_lin_rows_f32(h2, 128, N, 128, K, w3, 1, b3, mean, stream));
+  OBJ_TRY(tce_policy_objective_f32(
+      mean, L, mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau, delay, scaled_dt,
+      inv_scale_g, rel_goal, times, times_flags_fwd, times_flags_bwd, init_time, init_pos,
+      init_vel, reg, basis_ws, flag_ws, pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx,
+      tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16, N, T, P,
+      dof, K, 1, 1, stream));
+  // ---- backward into the flat gradient (the hidden layers' launch fills [0, PH + 129): first)
+  OBJ_TRY(tce_lin_rows_f32(g_mean, K, N, K, 128, w3, 0, nullptr, gh, stream));
+  OBJ_TRY(tce_mlp_hidden_f32(x, 0, x_stride, (int)N, N, din, w1, b1, w2, b2, act, gh, nullptr,
+                             partials, grad, stats, stream));
+  OBJ_TRY(tce_out_layer_grad_f32(g_mean, h2, g_w3, g_b3, ol_ws, N, K, 128, stream));
+  OBJ_TRY(tce_policy_objective_end_f32(g_L, obj_ws, N, K, P, stream));
+  OBJ_TRY(tce_chol_build_bwd_f32(var, g_L, g_var, 1, K, nvec, stream));
+  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
+  const int64_t n = PH + (int64_t)K * H + K + nvec;
+  OBJ_TRY(tce_adam_flat_f32(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps,
+                            weight_decay, clip_grad, grad_scale, stream));
+  return tce_policy_record_f32(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+}
+
 int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
                           float ent_coef, float* row19, void* stream) {
   TCE_CHECK_ARG(sur2 && out16 && norms2 && row19, "policy_record: null buffer");

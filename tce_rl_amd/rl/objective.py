@@ -284,50 +284,50 @@ class DirectEpoch:
         self.ol_ws = torch.empty(lib.tce_out_layer_grad_ws_len(self.N, self.K,
                                                                128),
                                  dtype=torch.float32, device=dev)
+        # workspace of tce_policy_epoch_f32: h2 | gh | mean | g_mean | L | g_L |
+        # sur2 [4] | out16 [16] | stats
+        self.ws = torch.zeros(lib.tce_policy_epoch_ws_len(self.N, self.K),
+                              dtype=torch.float32, device=dev)
+        up4 = lambda n: (n + 3) // 4 * 4
+        o = 2 * up4(self.N * 128) + 2 * up4(self.N * self.K) + \
+            2 * up4(self.K * self.K)
+        self.sur, self.out16 = self.ws[o:o + 2], self.ws[o + 4:o + 20]
 
     def run(self, rec_row):
         """One epoch; rec_row [19] receives {surrogate, entropy loss, trust
-        region loss, total, entropy, |g|, |g| clipped, 12 KL means}."""
-        c, st = self.c, stream()
-        x, N, K, din = self.x, self.N, self.K, self.din
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32,
-                                         device=x.device)
-        self.opt.bind_grads()
-        with torch.no_grad():
-            # ---- forward
-            L = new(1, K, K)
-            begin(self.var, self.min_std, L, c, N)    # second stream
-            h2 = new(N, 128)
-            call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
-                 *[ptr(t) for t in self.w], self.act, None, ptr(h2), None,
-                 None, None, st)
-            # output layer [N,128] -> [N,K] and, below, its input gradient: the
-            # row kernel of csrc/smlp.hip (tce_lin_rows_f32) -- no library GEMM
-            # is left in the epoch
-            mean = new(N, K)
-            call("tce_lin_rows_f32", ptr(h2), 128, N, 128, K, ptr(self.w3), 1,
-                 ptr(self.b3), ptr(mean), st)
-            g_mean, g_L, sur, out = evaluate(mean, L[0], c, started=True,
-                                             defer=True)
-            # ---- backward into the flat gradient.  The hidden layers' launch
-            # fills [0, P) (its w3 / b3 slots with zeros), so it goes first.
-            gh = new(N, 128)
-            call("tce_lin_rows_f32", ptr(g_mean), K, N, K, 128, ptr(self.w3),
-                 0, None, ptr(gh), st)
-            call("tce_mlp_hidden_f32", ptr(x), 0, x.stride(0), N, N, din,
-                 *[ptr(t) for t in self.w], self.act, ptr(gh), None,
-                 ptr(self.partials), ptr(self.opt.flat_grad), ptr(self.stats),
-                 st)
-            call("tce_out_layer_grad_f32", ptr(g_mean), ptr(h2),
-                 ptr(self.g_w3), ptr(self.g_b3), ptr(self.ol_ws), N, K, 128,
-                 st)
-            end(g_L, c, N)          # g_L complete (second stream joined)
-            call("tce_chol_build_bwd_f32", ptr(self.var), ptr(g_L),
-                 ptr(self.g_var), 1, K, self.nvec, st)
-            ag = self.agent
-            ag._optimizer_step(self.opt, ag.policy_net_params,
-                               ag.clip_grad_norm, want_norms=False)
-            # ---- record
-            assert rec_row.is_contiguous() and rec_row.numel() == 19
-            call("tce_policy_record_f32", ptr(sur), ptr(out),
-                 ptr(self.opt.dev_state) + 4, c.ent_coef, ptr(rec_row), st)
+        region loss, total, entropy, |g|, |g| clipped, 12 KL means}.  ONE C
+        call (tce_policy_epoch_f32: ~26 launches); a sharded run stops it in
+        front of the optimizer step, all-reduces the flat gradient, then steps
+        and records."""
+        c, ag, opt = self.c, self.agent, self.opt
+        x, N, K = self.x, self.N, self.K
+        mp = c.mp
+        T, P = c.times.shape[1], c.pairs.shape[0]
+        _workspaces(c, N, K, P, x)
+        B, flag = ops._mp_ws(mp, T, x.device)
+        flags = c.general | (ops._times_flags(mp, c.times, c.t0) & 2)
+        opt.bind_grads()
+        assert rec_row.is_contiguous() and rec_row.numel() == 19
+        g = opt.param_groups[0]
+        do_adam = not ag.dist.active
+        if do_adam:
+            opt.host_step += 1
+        call("tce_policy_epoch_f32", ptr(x), x.stride(0), N, self.din,
+             self.act, self.nvec, self.min_std, ptr(opt.flat_param),
+             ptr(opt.flat_grad), ptr(c.mean_old), ptr(c.L_old), ptr(c.traj),
+             ptr(c.lp_old), ptr(c.adv), ptr(c.pairs), *mp.c_args(),
+             ptr(c.times), flags, c.general | 2 | 4, ptr(c.t0), ptr(c.y0),
+             ptr(c.v0), mp.cov_reg, ptr(B), ptr(flag), ptr(c.pl_work),
+             float(c.eps_mean), float(c.eps_cov), ptr(c.beta), c.entropy_eq,
+             ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov, c.ent_coef,
+             ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(self.ws),
+             ptr(self.partials), ptr(self.ol_ws), T, P, mp.num_dof, K,
+             ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+             float(g["weight_decay"]), float(ag.clip_grad_norm), 1.0,
+             int(do_adam), ptr(rec_row), stream())
+        if not do_adam:
+            ag._optimizer_step(opt, ag.policy_net_params, ag.clip_grad_norm,
+                               want_norms=False)
+            call("tce_policy_record_f32", ptr(self.sur), ptr(self.out16),
+                 ptr(opt.dev_state) + 4, c.ent_coef, ptr(rec_row), stream())
