@@ -312,6 +312,7 @@ class DirectEpoch:
         do_adam = not ag.dist.active
         if do_adam:
             opt.host_step += 1
+            opt._opt_called = True            # for LinearLR's order check
         call("tce_policy_epoch_f32", ptr(x), x.stride(0), N, self.din,
              self.act, self.nvec, self.min_std, ptr(opt.flat_param),
              ptr(opt.flat_grad), ptr(c.mean_old), ptr(c.L_old), ptr(c.traj),

@@ -113,6 +113,7 @@ def critic_update(agent, states, returns, old_values):
     if not agent.dist.active:
         launch(E, True, rec, 1.0)
         opt.host_step += E
+        opt._opt_called = True                # for LinearLR's order check
         # the kernels leave |g|^2: the two norms of grad_norm_clip from it
         before = rec[:, 1].sqrt()
         after = before
@@ -193,6 +194,7 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     if not agent.dist.active:
         launch(E, True, rec)
         opt.host_step += E
+        opt._opt_called = True
     else:
         for e in range(E):
             launch(1, False, rec[e])
