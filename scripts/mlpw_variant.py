@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 CS = os.path.join(ROOT, "tce_rl_amd", "csrc")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 W, PU, KPG, WGS = (int(a) for a in args[:4])
-tag = "w%d_pu%d_k%d_g%d" % (W, PU, KPG, WGS)
+extra = [a for a in os.environ.get("MLPW_EXTRA", "").split() if a]   # e.g. "-DMLPW_STASH_AFTER"
+tag = "w%d_pu%d_k%d_g%d" % (W, PU, KPG, WGS) + "".join("_" + e.lstrip("-D").lower() for e in extra)
 so = os.path.join(ROOT, "scripts", "variants", "libmlpw_%s.so" % tag)
 os.makedirs(os.path.dirname(so), exist_ok=True)
 if not os.path.exists(so) or "--rebuild" in sys.argv:
@@ -23,7 +24,7 @@ if not os.path.exists(so) or "--rebuild" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC",
                            "-std=c++17", "-DMLPW_F32_WAVES=%d" % W, "-DMLPW_F32_PU=%d" % PU,
                            "-DMLPW_F32_WGS=%d" % WGS, "-DMLPW_F32_KPG=%d" % KPG,
-                           "-DMLPW_ONLY_LEAKY", "-c", os.path.join(CS, "mlpw_f32.hip"), "-o", o])
+                           "-DMLPW_ONLY_LEAKY"] + extra + ["-c", os.path.join(CS, "mlpw_f32.hip"), "-o", o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC",
                            "-o", so, o] + others)
 if "--build-only" in sys.argv:

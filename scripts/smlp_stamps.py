@@ -48,6 +48,6 @@ for net, dout, tag in ((agent.critic.net, 1, "critic"),
     P = lib.tce_smlp_num_params(net.dim_in, H, dout)
     PS = (P + dout * dout + 3) // 4 * 4
     grid = min((N + 63) // 64, 1024)
-    o = grid * PS + 16 * grid + 16
+    o = grid * PS + 16 * grid + 24
     st = ws[o:o + 5].cpu().tolist()
     print(tag, {k: int(v) for k, v in zip(names, st)}, "total", int(sum(st)))

@@ -6,7 +6,7 @@ from tce_rl_amd.config import tce_config
 from tce_rl_amd.mp_exp import MPExperiment
 env, N, dtype = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 for wg in map(int, sys.argv[4:]):
-    cfg = tce_config(env, num_env=N, epochs=50, dtype=dtype)
+    cfg = tce_config(env, num_env=N, epochs=50, dtype=dtype, num_basis=int(os.environ.get("NB", "8")))
     cfg["params"]["agent"]["args"]["critic_workgroups"] = wg
     exp = MPExperiment(); exp.initialize(cfg, 0, None)
     ts = []

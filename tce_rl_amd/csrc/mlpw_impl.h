@@ -204,6 +204,12 @@ struct ChainLds {
 #define WSTAMP(k)
 #endif
 
+// k-block after which panel_mma runs its mid() callback (even: the one-tile
+// path steps by two)
+#ifndef MLPW_MID_AT
+#define MLPW_MID_AT(NJ) ((NJ) / 2)
+#endif
+
 // nothing moves across: keeps the compiler from hoisting every LDS read of an
 // unrolled phase to its top (which spills) and the next step's reads ahead of
 // this step's MFMAs
@@ -211,10 +217,15 @@ __device__ inline void wfence() { __builtin_amdgcn_sched_barrier(0); }
 
 // acc[jj] += panel rows (16 jj + m) . B operand tiles (H / 16 of them).  The
 // A fragments of k-block Jk + 1 are read while block Jk is multiplied.
-template <typename real, int H>
+// `mid()` is called once in the middle of the MFMA sequence: work that does
+// not depend on this panel's result (the LDS writes of the NEXT panel, fetched
+// into registers at the top of the step) issues in the shadow of the matrix
+// pipe instead of after the last MFMA.
+struct NoMid { __device__ void operator()() const {} };
+template <typename real, int H, typename Mid = NoMid>
 __device__ inline void panel_mma(const real* pan, int m, int g,
                                  const typename WV<real>::acc* bop,
-                                 typename WV<real>::acc* acc) {
+                                 typename WV<real>::acc* acc, Mid mid = Mid()) {
   typedef typename WV<real>::v4 v4;
   typedef typename WV<real>::acc vacc;
   constexpr int WP = H + WCfg<real>::WPAD;
@@ -253,6 +264,7 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
         alt = wmfma(A[b][1][i], bop[Jk + 1][i], alt);
       }
       wfence();
+      if (Jk == MLPW_MID_AT(NJ)) { mid(); wfence(); }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[0][i] += alt[i];
@@ -280,6 +292,7 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = wmfma(A[b][jj][i], bop[Jk][i], acc[jj]);
       wfence();
+      if (Jk == MLPW_MID_AT(NJ)) { mid(); wfence(); }
     }
   }
   wfence();
@@ -459,12 +472,18 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj)
         acc[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + 4 * g);
+      // the other buffer is free since the last barrier: the next panel goes
+      // there in the middle of this panel's MFMAs (its fetch was issued at the
+      // top of the step; the LDS writes issue beside the matrix pipe)
+#ifdef MLPW_STASH_AFTER
       panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc);
       WSTAMP(4)
-      // the other buffer is free since the last barrier: the next panel goes
-      // there now (fills the result latency of the last MFMAs, and its wait
-      // for the fetch comes before this step's stores enter the same counter)
       if (pre) stash((s & 1) ^ 1);
+#else
+      panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc,
+                         [&]() { if (pre) stash((s & 1) ^ 1); });
+      WSTAMP(4)
+#endif
       WSTAMP(5)
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj) {
@@ -544,8 +563,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
+#ifdef MLPW_STASH_AFTER
         panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc);
         if (pre) stash(((NP + s) & 1) ^ 1);
+#else
+        panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc,
+                           [&]() { if (pre) stash(((NP + s) & 1) ^ 1); });
+#endif
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;

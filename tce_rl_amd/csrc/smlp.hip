@@ -833,7 +833,7 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
   // {setup + loads, forward, head, backward, gradients} behind the slabs
   if (blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 5; ++i)       // the 8 spare floats at the end of the workspace
-      rd.slabs[(int64_t)gridDim.x * rd.PS + 16 * (int64_t)gridDim.x + 16 + i] = (float)stamp_[i];
+      rd.slabs[(int64_t)gridDim.x * rd.PS + 16 * (int64_t)gridDim.x + 24 + i] = (float)stamp_[i];
 #endif
 }
 
@@ -1334,7 +1334,7 @@ int64_t tce_smlp_num_params(int din, int H, int dout) { return s_nparams(din, H,
 int64_t tce_smlp_ws_len(int64_t N, int din, int H, int dout) {
   const int64_t PS = s_up4(s_nparams(din, H, dout) + dout * dout);
   const int64_t g = s_grid(N);
-  return g * PS + 2 * (g * 8) + 2 * 8 + 8;
+  return g * PS + 2 * (g * 8) + 2 * 8 + 8 + 8;   // ... + dsum + zero3 + 8 spare (stamps)
 }
 
 int tce_smlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, int H, int dout,
