@@ -185,14 +185,40 @@ __global__ __launch_bounds__(256) void mlpw_prep_kernel(const real* __restrict__
 // ---------------------------------------------------------------------------
 // chain kernel
 // ---------------------------------------------------------------------------
+// dW1 / db1 inside the chain kernel (round 3): the dY1 tile of a backward panel
+// goes through a small LDS transpose instead of the [R][H] workspace, the
+// gradient kernel reads dY2 and H1 only.  For the shapes whose LDS has room for
+// the two transpose buffers (D_in <= 24, H = 256: both shipped wide critics).
+#ifdef MLPW_NO_FUSE
+template <typename real, int H, int KPG> struct WFuse { static constexpr bool on = false; };
+#else
+template <typename real, int H, int KPG> struct WFuse {
+  typedef WCfg<real> C;
+  static constexpr int NOT1 = C::NTILE * 2;                  // dW1 output tiles per panel (32 features)
+  // fp32 only: with two waves per SIMD (one of either turn group) the extra
+  // MFMAs spread evenly; the one-wave-per-SIMD fp64 kernel would wait at every
+  // panel barrier for the two waves whose turn it is
+  static constexpr bool on = sizeof(real) == 4 && H == 256 && KPG == 6 && C::WGS == 1 &&
+                             C::WAVES % NOT1 == 0 && (H / C::PU) % (C::WAVES / NOT1) == 0;
+};
+#endif
+
 template <typename real, int H, int KPG>
 struct ChainLds {
   static constexpr int W1P = 4 * KPG + 4;
   static constexpr int WP = H + WCfg<real>::WPAD;
   static constexpr int PANEL = WCfg<real>::PU * WP;
+  // dY1 transpose: [2][TILE rows][PU positions], pitch PU + 4 (fp32: 36 = 4 x
+  // odd, the 16-byte row writes of 16 consecutive rows are conflict free) /
+  // PU + 2 (fp64)
+  static constexpr int TP1 = WCfg<real>::PU + (sizeof(real) == 4 ? 4 : 2);
+  static constexpr int T1 = WFuse<real, H, KPG>::on ? 2 * WCfg<real>::TILE * TP1 : 0;
+  // the tile's X rows [TILE][4 KPG features], pitch odd
+  static constexpr int XP = 4 * KPG + 1;
+  static constexpr int XS = WFuse<real, H, KPG>::on ? WCfg<real>::TILE * XP : 0;
   static constexpr size_t bytes(bool bwd) {
     return sizeof(real) * ((size_t)H * W1P + 3 * H + 2 * PANEL +
-                           (bwd ? (size_t)WCfg<real>::NACC * H : 0)) + 64;
+                           (bwd ? (size_t)WCfg<real>::NACC * H + T1 + XS : 0)) + 64;
   }
 };
 
@@ -313,9 +339,25 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   real* Bs = W1s + H * W1P;                                  // b1 | b2 | w3, position order
   real* pan = Bs + 3 * H;                                    // [2][PU][WP]
   real* gacc = pan + 2 * LD::PANEL;                          // [NACC][H] dw3 (positions)
+  real* t1buf = gacc + C::NACC * H;                          // [2][TILE][TP1] dY1 of a panel (FUSE)
+  real* xs = t1buf + LD::T1;                                 // [TILE][XP] X rows of the tile (FUSE)
+  constexpr int XP = LD::XP;
+  constexpr bool FUSE = BWD && WFuse<real, H, KPG>::on;
+  constexpr int TP1 = LD::TP1;
+  // FUSE: this wave's share of dW1 (+ db1 through a column of ones): panel sp's
+  // NTILE x 2 output tiles [16 unit positions x 16 features] go to the waves
+  // ((sp * NTILE * 2) + 2 at + xt) mod WAVES, each contracting all TILE rows
+  constexpr int NOT1 = NTILE * 2;                            // dW1 output tiles per panel
+  constexpr int NG1 = C::WAVES / NOT1 > 0 ? C::WAVES / NOT1 : 1;   // panel groups taking turns
+  constexpr int NPW = FUSE ? NP / NG1 : 1;                   // panels (accumulators) per wave
+  vacc gw1[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) gw1[q] = (vacc){0, 0, 0, 0};
   __shared__ real sred[2 * C::WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int my_grp = wave_u / NOT1, my_at = (wave_u % NOT1) >> 1, my_xt = wave_u & 1;
   const int m = lane & 15, g = lane >> 4;                    // m: A row / batch column
   const int din = a.din;
   const int64_t ntiles = (a.R + C::TILE - 1) / C::TILE;
@@ -414,7 +456,38 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       rt = a.ret[rok ? r : a.R - 1];
       if (a.clip > real(0)) ov = a.old_v[rok ? r : a.R - 1];
     }
-    if (more) load_x(tile + gridDim.x, xn);
+    // (FUSE: the next tile's rows are requested in the last backward step --
+    // eight registers less through the tile)
+    if (more && !FUSE) load_x(tile + gridDim.x, xn);
+    // one turn: dW1 tile (panel sp, my_at, my_xt) += dY1[rows][positions]^T X[rows][features]
+    // over the TILE rows (A from the transpose buffer sp & 1, B = X from L2; the
+    // feature D_in is a column of ones: db1)
+    auto dw1_turn = [&](int sp, vacc& accum) {
+      const real* tb = t1buf + (sp & 1) * C::TILE * TP1 + 16 * my_at + m;
+      const int f = 16 * my_xt + m;
+      const int fc = f < din ? f : din - 1;
+      // (opaque per turn: the X rows are the same in every turn of a tile, and
+      // the compiler would otherwise keep all of them in registers)
+      int jo = g;
+      asm volatile("" : "+v"(jo));
+      const real* xf = xs + fc;
+      constexpr int CH = 4;                                  // k-steps per batch of loads
+#pragma unroll
+      for (int k0 = 0; k0 < C::TILE / 4; k0 += CH) {
+        real av[CH], bv[CH];
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) {
+          const int j = 4 * (k0 + kk) + jo;                  // row of the tile
+          av[kk] = tb[j * TP1];
+          const real xv = xf[j * XP];
+          bv[kk] = f < din ? xv : (f == din ? real(1) : real(0));
+        }
+        wfence();
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) accum = wmfma(av[kk], bv[kk], accum);
+        wfence();
+      }
+    };
 
     // ---- layer 1: H1^T = act(W1 X^T + b1), two row blocks at a time
     vacc h1[NJ];
@@ -498,6 +571,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       }
       WSTAMP(6)
       __syncthreads();
+      // past the tile's first barrier no wave is still in the previous tile's
+      // last dW1 turn: the row offsets of this tile replace the old ones
+      if (FUSE && s == 0) {
+        real* xw = xs + (wave * 16 + m) * XP + KPG * g;
+#pragma unroll
+        for (int k = 0; k < KPG; ++k) xw[k] = xb[k];
+      }
     }
 
     WSTAMP(1)
@@ -560,6 +640,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         const bool last = s == NP - 1;
         const bool pre = !last || more;
         if (pre) fetch(last ? 0 : NP + s + 1);
+        if (FUSE && last && more) load_x(tile + gridDim.x, xn);
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
@@ -567,18 +648,28 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc);
         if (pre) stash(((NP + s) & 1) ^ 1);
 #else
-        panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc,
-                           [&]() { if (pre) stash(((NP + s) & 1) ^ 1); });
+        panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc, [&]() {
+          if (pre) stash(((NP + s) & 1) ^ 1);
+          // the dY1 tile of panel s - 1 became visible at the last barrier: the
+          // waves whose turn it is take its dW1 tiles now, beside this panel's MFMAs
+          if (FUSE && s > 0 && ((s - 1) % NG1) == my_grp) dw1_turn(s - 1, gw1[(s - 1) / NG1]);
+        });
 #endif
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[jj][i] *= wact_d<real, ACT>(h1[J][i]);
-          *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
+          if (FUSE)
+            *reinterpret_cast<v4*>(t1buf + (s & 1) * C::TILE * TP1 + (wave * 16 + m) * TP1 +
+                                   16 * jj + 4 * g) = acc[jj];
+          else
+            *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
         }
         __syncthreads();
       }
+      // the last panel's dW1 tiles (its dY1 tile is visible since the barrier above)
+      if (FUSE && ((NP - 1) % NG1) == my_grp) dw1_turn(NP - 1, gw1[(NP - 1) / NG1]);
       WSTAMP(3)
     }
   }
@@ -587,6 +678,24 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     for (int k = 0; k < 8; ++k) a.dy1s[k] = (real)stt_[k];
 #endif
 
+  if (FUSE) {
+    // ---- slab sections W1, b1 (unit order): this wave's tiles
+    real* outp = a.partials + (int64_t)blockIdx.x * (a.P + 2);
+    real* oW1 = outp;
+    real* ob1 = outp + (int64_t)H * din;
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+      const int sp = q * NG1 + my_grp;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pos = C::PU * sp + 16 * my_at + drow<real>(g, i);
+        const int u = unit_of_pos<real>(pos);
+        const int f = 16 * my_xt + m;
+        if (f < din) oW1[(int64_t)u * din + f] = gw1[q][i];
+        else if (f == din) ob1[u] = gw1[q][i];
+      }
+    }
+  }
   if (BWD) {
     // ---- slab: w3 (unit order), b3, loss
     loss_sum = wave_sum(loss_sum);
@@ -632,7 +741,8 @@ struct GradLds {
   static constexpr int PX = XW == 32 ? 48 : 80;  // pitches = 16 mod 32 (conflict-free column reads)
   static constexpr int PA = GradCfg<real, H>::UR + 16;
   static constexpr int PB = H + 16;
-  static constexpr int ROW = 2 * PA + PB + PX;
+  static constexpr bool FUSE = WFuse<real, H, KPG>::on;     // dW1 / db1 come from the chain kernel
+  static constexpr int ROW = FUSE ? PA + PB : 2 * PA + PB + PX;
   static constexpr int BUF = WCfg<real>::KC * ROW;
   static constexpr size_t bytes() { return sizeof(real) * 2 * (size_t)BUF + 64; }
 };
@@ -648,6 +758,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   constexpr int NVA = (KC * G::UR / 4 + NT - 1) / NT;        // staged 4-chunks per thread
   constexpr int NVB = (KC * H / 4 + NT - 1) / NT;
   constexpr int NVX = (KC * LD::XW + NT - 1) / NT;
+  constexpr bool FUSE = LD::FUSE;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* lds = reinterpret_cast<real*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -684,7 +795,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       const int64_t off = (ok ? r : r_lo) * H + ubase + 4 * c4;
       const v4 z = {0, 0, 0, 0};
       sa2[q] = ok ? *reinterpret_cast<const v4*>(a.dy2s + off) : z;
-      sa1[q] = ok ? *reinterpret_cast<const v4*>(a.dy1s + off) : z;
+      if (!FUSE) sa1[q] = ok ? *reinterpret_cast<const v4*>(a.dy1s + off) : z;
     }
 #pragma unroll
     for (int q = 0; q < NVB; ++q) {
@@ -696,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       sb[q] = ok ? *reinterpret_cast<const v4*>(a.h1s + (ok ? r : r_lo) * H + 4 * c4) : z;
     }
 #pragma unroll
-    for (int q = 0; q < NVX; ++q) {
+    for (int q = 0; q < (FUSE ? 0 : NVX); ++q) {
       const int idx = q * NT + tid;
       const int row = idx / LD::XW, f = idx - row * LD::XW;
       const int64_t r = r0 + row;
@@ -712,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   auto stash = [&](int buf) {
     real* A2 = lds + buf * LD::BUF;
     real* A1 = A2 + KC * LD::PA;
-    real* B2 = A1 + KC * LD::PA;
+    real* B2 = FUSE ? A1 : A1 + KC * LD::PA;
     real* BX = B2 + KC * LD::PB;
 #pragma unroll
     for (int q = 0; q < NVA; ++q) {
@@ -720,7 +831,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       if (idx < KC * G::UR / 4) {
         const int row = idx / (G::UR / 4), c4 = idx - row * (G::UR / 4);
         *reinterpret_cast<v4*>(A2 + row * LD::PA + 4 * c4) = sa2[q];
-        *reinterpret_cast<v4*>(A1 + row * LD::PA + 4 * c4) = sa1[q];
+        if (!FUSE) *reinterpret_cast<v4*>(A1 + row * LD::PA + 4 * c4) = sa1[q];
       }
     }
 #pragma unroll
@@ -732,7 +843,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < NVX; ++q) {
+    for (int q = 0; q < (FUSE ? 0 : NVX); ++q) {
       const int idx = q * NT + tid;
       if (idx < KC * LD::XW) {
         const int row = idx / LD::XW, f = idx - row * LD::XW;
@@ -752,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
     if (more) fetch(r0 + KC);
     const real* A2 = lds + cur * LD::BUF;
     const real* A1 = A2 + KC * LD::PA;
-    const real* B2 = A1 + KC * LD::PA;
+    const real* B2 = FUSE ? A1 : A1 + KC * LD::PA;
     const real* BX = B2 + KC * LD::PB;
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
@@ -761,9 +872,11 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
 #pragma unroll
       for (int at = 0; at < NAT; ++at) {
         a2[at] = A2[row * LD::PA + wave * G::UW + 16 * at + m];
-        a1[at] = A1[row * LD::PA + wave * G::UW + 16 * at + m];
         sb2[at] += a2[at];                                    // db2, db1: column sums
-        sb1[at] += a1[at];
+        if (!FUSE) {
+          a1[at] = A1[row * LD::PA + wave * G::UW + 16 * at + m];
+          sb1[at] += a1[at];
+        }
       }
 #pragma unroll
       for (int bt = 0; bt < NJ; ++bt) {
@@ -772,7 +885,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
         for (int at = 0; at < NAT; ++at) acc2[at][bt] = wmfma(a2[at], b, acc2[at][bt]);
       }
 #pragma unroll
-      for (int xt = 0; xt < NXT; ++xt) {
+      for (int xt = 0; xt < (FUSE ? 0 : NXT); ++xt) {
         const real b = BX[row * LD::PX + 16 * xt + m];
 #pragma unroll
         for (int at = 0; at < NAT; ++at) acc1[at][xt] = wmfma(a1[at], b, acc1[at][xt]);
@@ -799,7 +912,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
     if (g == 0) {
       const int u = unit_of_pos<real>(ubase + wave * G::UW + 16 * at + m);
       ob2[u] = v2;
-      ob1[u] = v1;
+      if (!FUSE) ob1[u] = v1;
     }
   }
 #pragma unroll
@@ -812,7 +925,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       for (int bt = 0; bt < NJ; ++bt)
         oW2[(int64_t)ua * H + unit_of_pos<real>(16 * bt + m)] = acc2[at][bt][i];
 #pragma unroll
-      for (int xt = 0; xt < NXT; ++xt) {
+      for (int xt = 0; xt < (FUSE ? 0 : NXT); ++xt) {
         const int f = 16 * xt + m;
         if (f < din) oW1[(int64_t)ua * din + f] = acc1[at][xt][i];
       }
