@@ -203,6 +203,16 @@ template <typename real, int H, int KPG> struct WFuse {
 };
 #endif
 
+// panels by LDS-DMA (fp32) or through registers (fp64: measured slower by DMA --
+// one wave per SIMD sits in the barrier's vmcnt(0) instead of in its MFMAs)
+#ifndef MLPW_GLDS_F32
+#define MLPW_GLDS_F32 1
+#define MLPW_GLDS_F64 0
+#endif
+template <typename real> struct WGlds {
+  static constexpr bool on = sizeof(real) == 4 ? MLPW_GLDS_F32 : MLPW_GLDS_F64;
+};
+
 template <typename real, int H, int KPG>
 struct ChainLds {
   static constexpr int W1P = 4 * KPG + 4;
@@ -410,8 +420,35 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #pragma unroll
     for (int q = 0; q < NCH; ++q) *reinterpret_cast<chunk*>(dst + q * (NT / CPR) * WP) = stg[q];
   };
-  fetch(0);
-  stash(0);
+  // GLDS: panels go from L2 straight into the LDS (global_load_lds_dwordx4: one wave
+  // instruction = 1 KiB of one panel row, wave-uniform LDS address + 16 bytes
+  // per lane): no staging registers, no ds_write pass.  The barrier that ends a
+  // step waits for them (hipcc drains vmcnt before a barrier while an LDS-DMA
+  // is in flight).
+  constexpr int IPR = H * (int)sizeof(real) / 1024;          // instructions per panel row
+  constexpr int NDMA = C::PU * IPR / C::WAVES;               // per wave and panel
+  static_assert(IPR >= 1 && C::PU * IPR % C::WAVES == 0, "panel DMA");
+  constexpr bool GLDS = WGlds<real>::on;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto dma = [&](int s, int buf) {
+    const real* base = panel_src(s);
+    asm volatile("" : "+s"(base));
+    typedef const __attribute__((address_space(1))) void* gvp;
+    typedef __attribute__((address_space(3))) void* lvp;
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) {
+      const int e = wave_s * NDMA + q, row = e / IPR, part = e % IPR;
+      __builtin_amdgcn_global_load_lds(
+          (gvp)(base + row * H + part * (1024 / (int)sizeof(real)) + lane * EPC),
+          (lvp)(pan + buf * LD::PANEL + row * WP + part * (1024 / (int)sizeof(real))), 16, 0, 0);
+    }
+  };
+  if (GLDS) {
+    dma(0, 0);
+  } else {
+    fetch(0);
+    stash(0);
+  }
   __syncthreads();
   // the panel steps of a tile alternate between the two buffers; their number
   // per tile is even, so step s always reads buffer s & 1 (compile-time
@@ -540,7 +577,11 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     for (int s = 0; s < NP; ++s) {
       const bool last = !BWD && s == NP - 1;
       const bool pre = !last || more;                       // another panel follows
-      if (pre) fetch(last ? 0 : s + 1);
+      // (GLDS: the other buffer is free since the last barrier)
+      if (pre) {
+        if (GLDS) dma(last ? 0 : s + 1, (s & 1) ^ 1);
+        else fetch(last ? 0 : s + 1);
+      }
       vacc acc[NTILE];
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj)
@@ -548,15 +589,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       // the other buffer is free since the last barrier: the next panel goes
       // there in the middle of this panel's MFMAs (its fetch was issued at the
       // top of the step; the LDS writes issue beside the matrix pipe)
-#ifdef MLPW_STASH_AFTER
-      panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc);
-      WSTAMP(4)
-      if (pre) stash((s & 1) ^ 1);
-#else
       panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc,
-                         [&]() { if (pre) stash((s & 1) ^ 1); });
+                         [&]() { if (!GLDS && pre) stash((s & 1) ^ 1); });
       WSTAMP(4)
-#endif
       WSTAMP(5)
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj) {
@@ -639,22 +674,20 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       for (int s = 0; s < NP; ++s) {
         const bool last = s == NP - 1;
         const bool pre = !last || more;
-        if (pre) fetch(last ? 0 : NP + s + 1);
+        if (pre) {
+          if (GLDS) dma(last ? 0 : NP + s + 1, ((NP + s) & 1) ^ 1);
+          else fetch(last ? 0 : NP + s + 1);
+        }
         if (FUSE && last && more) load_x(tile + gridDim.x, xn);
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
-#ifdef MLPW_STASH_AFTER
-        panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc);
-        if (pre) stash(((NP + s) & 1) ^ 1);
-#else
         panel_mma<real, H>(pan + ((NP + s) & 1) * LD::PANEL, m, g, dy2, acc, [&]() {
-          if (pre) stash(((NP + s) & 1) ^ 1);
+          if (!GLDS && pre) stash(((NP + s) & 1) ^ 1);
           // the dY1 tile of panel s - 1 became visible at the last barrier: the
           // waves whose turn it is take its dW1 tiles now, beside this panel's MFMAs
           if (FUSE && s > 0 && ((s - 1) % NG1) == my_grp) dw1_turn(s - 1, gw1[(s - 1) / NG1]);
         });
-#endif
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
