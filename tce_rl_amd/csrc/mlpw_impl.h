@@ -257,11 +257,33 @@ __device__ inline void wfence() { __builtin_amdgcn_sched_barrier(0); }
 // not depend on this panel's result (the LDS writes of the NEXT panel, fetched
 // into registers at the top of the step) issues in the shadow of the matrix
 // pipe instead of after the last MFMA.
+// `hook(h)`, h = 0 .. WHooks<real>::N - 1, is called once per k-block pair
+// (fp64) / k-block (fp32) between two groups of MFMAs: a slice of work left
+// over from the PREVIOUS panel (its activation epilogue, the dW1 products of
+// an earlier one) issues while the matrix pipe works on this panel, instead of
+// after the panel's last MFMA with the pipe idle.
 struct NoMid { __device__ void operator()() const {} };
-template <typename real, int H, typename Mid = NoMid>
+struct NoHook { __device__ void operator()(int) const {} };
+template <typename real, int H> struct WHooks {
+  static constexpr int N = WCfg<real>::NTILE == 1 ? H / 32 : H / 16;   // hook calls per panel
+  static constexpr int NE = 4 * WCfg<real>::NTILE;                     // result elements per lane and panel
+  // elements [lo(h), lo(h + 1)) of the previous panel are finished in hook h >= 1
+  // (hook 0 requests what they need from the LDS)
+  static constexpr int lo(int h) { return h < 1 ? 0 : ((h - 1) * NE + N - 2) / (N - 1); }
+};
+// (timing experiment only -- wrong results: no barrier between panel steps)
+#ifdef MLPW_NOSYNC
+#define WSTEP_SYNC() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define WSTEP_SYNC() __syncthreads()
+#endif
+#ifndef MLPW_DEFER
+#define MLPW_DEFER 1              // 0: every panel's epilogue right behind its MFMAs (round 2)
+#endif
+template <typename real, int H, typename Mid = NoMid, typename Hook = NoHook>
 __device__ inline void panel_mma(const real* pan, int m, int g,
                                  const typename WV<real>::acc* bop,
-                                 typename WV<real>::acc* acc, Mid mid = Mid()) {
+                                 typename WV<real>::acc* acc, Mid mid = Mid(), Hook hook = Hook()) {
   typedef typename WV<real>::v4 v4;
   typedef typename WV<real>::acc vacc;
   constexpr int WP = H + WCfg<real>::WPAD;
@@ -293,6 +315,7 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
         A[b ^ 1][0] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 2));
         A[b ^ 1][1] = *reinterpret_cast<const v4*>(p + 16 * (Jk + 3));
       }
+      hook(Jk >> 1);
       wfence();
 #pragma unroll
       for (int i = 1; i < 4; ++i) {
@@ -322,6 +345,7 @@ __device__ inline void panel_mma(const real* pan, int m, int g,
         for (int jj = 0; jj < NTILE; ++jj)
           A[b ^ 1][jj] = *reinterpret_cast<const v4*>(p + 16 * jj * WP + 16 * (Jk + 1));
       }
+      hook(Jk);
       wfence();
 #pragma unroll
       for (int i = 1; i < 4; ++i)
@@ -527,12 +551,18 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     };
 
     // ---- layer 1: H1^T = act(W1 X^T + b1), two row blocks at a time
+    // (go: the lane group, opaque per tile -- the forward-only kernel has no LDS
+    // stores in its loop, and the compiler would otherwise keep every bias, w3
+    // and W1 value it reads in registers across the tiles: 121 spilled
+    // registers in the fp64 build)
+    int go = g;
+    asm volatile("" : "+v"(go));
     vacc h1[NJ];
 #pragma unroll
     for (int J = 0; J < NJ; J += 2) {
-      vacc c0 = *reinterpret_cast<const v4*>(Bs + 16 * J + 4 * g);
-      vacc c1 = *reinterpret_cast<const v4*>(Bs + 16 * J + 16 + 4 * g);
-      const real* p0 = W1s + (16 * J + m) * W1P + KPG * g;
+      vacc c0 = *reinterpret_cast<const v4*>(Bs + 16 * J + 4 * go);
+      vacc c1 = *reinterpret_cast<const v4*>(Bs + 16 * J + 16 + 4 * go);
+      const real* p0 = W1s + (16 * J + m) * W1P + KPG * go;
       const real* p1 = p0 + 16 * W1P;
 #pragma unroll
       for (int s = 0; s < KPG; s += 2) {
@@ -573,41 +603,66 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     // HBM traffic per epoch for 64 registers.)
     real v = 0;
     vacc dy2[BWD ? NJ : 1];
+    // The epilogue of panel s - 1 (bias, activation, its share of v) runs inside
+    // the MFMAs of panel s, one element per hook; only the last panel's is
+    // exposed.  (The bias is added there too: the accumulators start at zero
+    // instead of waiting for an LDS read at the top of every panel.)
+    vacc facc[2][NTILE];
+    auto fwd_elem = [&](int sp, int n, const vacc* b2r, const vacc* w3r) {
+      const int jj = n >> 2, i = n & 3;
+      const real hv = wact<real, ACT>(facc[sp & 1][jj][i] + b2r[jj][i]);
+      v += w3r[jj][i] * hv;
+      if (BWD) dy2[sp * NTILE + jj][i] = hv;
+    };
+    vacc b2r[NTILE], w3r[NTILE];
+    const int bo = 4 * go;
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       const bool last = !BWD && s == NP - 1;
-      const bool pre = !last || more;                       // another panel follows
+      // another panel follows (GLDS: no branch around the DMA -- after the last
+      // tile panel 0 is fetched once more into the free buffer and never read)
+      const bool pre = GLDS || !last || more;
       // (GLDS: the other buffer is free since the last barrier)
       if (pre) {
         if (GLDS) dma(last ? 0 : s + 1, (s & 1) ^ 1);
         else fetch(last ? 0 : s + 1);
       }
-      vacc acc[NTILE];
 #pragma unroll
-      for (int jj = 0; jj < NTILE; ++jj)
-        acc[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + 4 * g);
+      for (int jj = 0; jj < NTILE; ++jj) facc[s & 1][jj] = (vacc){0, 0, 0, 0};
       // the other buffer is free since the last barrier: the next panel goes
       // there in the middle of this panel's MFMAs (its fetch was issued at the
       // top of the step; the LDS writes issue beside the matrix pipe)
-      panel_mma<real, H>(pan + (s & 1) * LD::PANEL, m, g, h1, acc,
-                         [&]() { if (!GLDS && pre) stash((s & 1) ^ 1); });
+      panel_mma<real, H>(
+          pan + (s & 1) * LD::PANEL, m, g, h1, facc[s & 1],
+          [&]() { if (!GLDS && pre) stash((s & 1) ^ 1); },
+          [&](int h) {
+            if (s == 0 || !MLPW_DEFER) return;
+            typedef WHooks<real, H> HK;
+            if (h == 0) {
+#pragma unroll
+              for (int jj = 0; jj < NTILE; ++jj) {
+                b2r[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * ((s - 1) * NTILE + jj) + bo);
+                w3r[jj] = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * ((s - 1) * NTILE + jj) + bo);
+              }
+            } else {
+#pragma unroll
+              for (int n = HK::lo(h); n < HK::lo(h + 1); ++n) fwd_elem(s - 1, n, b2r, w3r);
+            }
+          });
       WSTAMP(4)
-      WSTAMP(5)
+      if (s == NP - 1 || !MLPW_DEFER) {
 #pragma unroll
-      for (int jj = 0; jj < NTILE; ++jj) {
-        const int J = s * NTILE + jj;
-        const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[jj][i] = wact<real, ACT>(acc[jj][i]);
-          v += w3v[i] * acc[jj][i];
+        for (int jj = 0; jj < NTILE; ++jj) {
+          b2r[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + bo);
+          w3r[jj] = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * (s * NTILE + jj) + bo);
         }
-        if (BWD) dy2[J] = acc[jj];
+#pragma unroll
+        for (int n = 0; n < 4 * NTILE; ++n) fwd_elem(s, n, b2r, w3r);
       }
       WSTAMP(6)
-      __syncthreads();
+      WSTEP_SYNC();
       // past the tile's first barrier no wave is still in the previous tile's
-      // last dW1 turn: the row offsets of this tile replace the old ones
+      // last dW1 turn: the X rows of this tile replace the old ones
       if (FUSE && s == 0) {
         real* xw = xs + (wave * 16 + m) * XP + KPG * g;
 #pragma unroll
@@ -673,7 +728,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
         const bool last = s == NP - 1;
-        const bool pre = !last || more;
+        const bool pre = GLDS || !last || more;
         if (pre) {
           if (GLDS) dma(last ? 0 : NP + s + 1, ((NP + s) & 1) ^ 1);
           else fetch(last ? 0 : NP + s + 1);
@@ -699,7 +754,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           else
             *reinterpret_cast<v4*>(p1s + 16 * J) = acc[jj];
         }
-        __syncthreads();
+        WSTEP_SYNC();
       }
       // the last panel's dW1 tiles (its dY1 tile is visible since the barrier above)
       if (FUSE && ((NP - 1) % NG1) == my_grp) dw1_turn(NP - 1, gw1[(NP - 1) / NG1]);
