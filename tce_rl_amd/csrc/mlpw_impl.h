@@ -831,8 +831,20 @@ struct GradLds {
   static constexpr int PB = H + 16;
   static constexpr bool FUSE = WFuse<real, H, KPG>::on;     // dW1 / db1 come from the chain kernel
   static constexpr int ROW = FUSE ? PA + PB : 2 * PA + PB + PX;
-  static constexpr int BUF = WCfg<real>::KC * ROW;
-  static constexpr size_t bytes() { return sizeof(real) * 2 * (size_t)BUF + 64; }
+  // rows per stage (fused: the LDS the dY1 / X images took holds twice the rows)
+#ifndef MLPW_KC_FUSED
+#define MLPW_KC_FUSED 1           // (2: measured 1 % slower)
+#endif
+#ifndef MLPW_GRAD_GLDS
+#define MLPW_GRAD_GLDS 1
+#endif
+  // (tried: three stage buffers with the rows requested two stages ahead,
+  // counted vmcnt + bare s_barrier -- 0.4 % slower: HBM latency is not what the
+  // gradient kernel waits for)
+  static constexpr int NBUF = 2;
+  static constexpr int KC = WCfg<real>::KC * (FUSE ? MLPW_KC_FUSED : 1);
+  static constexpr int BUF = KC * ROW;
+  static constexpr size_t bytes() { return sizeof(real) * NBUF * (size_t)BUF + 64; }
 };
 
 template <typename real, int H, int KPG>
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   typedef typename WV<real>::acc vacc;
   typedef GradCfg<real, H> G;
   typedef GradLds<real, H, KPG> LD;
-  constexpr int KC = WCfg<real>::KC, NJ = H / 16, NAT = G::NAT, NXT = LD::XW / 16;
+  constexpr int KC = LD::KC, NJ = H / 16, NAT = G::NAT, NXT = LD::XW / 16;
   constexpr int NT = 512;
   constexpr int NVA = (KC * G::UR / 4 + NT - 1) / NT;        // staged 4-chunks per thread
   constexpr int NVB = (KC * H / 4 + NT - 1) / NT;
@@ -873,9 +885,33 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   for (int at = 0; at < NAT; ++at) { sb2[at] = 0; sb1[at] = 0; }
   v4 sa2[NVA], sa1[NVA], sb[NVB];
   real sx[NVX];
+  // GL: the dY2 / dY1 / H1 rows of a stage go from HBM straight into the LDS
+  // (one global_load_lds_dwordx4 per 1 KiB row; X, if staged at all, still
+  // through registers).  Rows past R of the last stage come from the workspace
+  // like the others: the chain kernel wrote them (whole tiles), dY2 / dY1 as
+  // exact zeros.
+  constexpr bool GL = WGlds<real>::on && G::UR == H && H * sizeof(real) == 1024 &&
+                      KC % 8 == 0 && MLPW_GRAD_GLDS;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto dma = [&](int64_t r0, int buf) {
+    typedef const __attribute__((address_space(1))) void* gvp;
+    typedef __attribute__((address_space(3))) void* lvp;
+    real* A2 = lds + buf * LD::BUF;
+    real* A1 = A2 + KC * LD::PA;
+    real* B2 = FUSE ? A1 : A1 + KC * LD::PA;
+#pragma unroll
+    for (int q = 0; q < KC / 8; ++q) {
+      const int row = wave_s * (KC / 8) + q;
+      const int64_t off = (r0 + row) * H + lane * 4;
+      __builtin_amdgcn_global_load_lds((gvp)(a.dy2s + off), (lvp)(A2 + row * LD::PA), 16, 0, 0);
+      if (!FUSE)
+        __builtin_amdgcn_global_load_lds((gvp)(a.dy1s + off), (lvp)(A1 + row * LD::PA), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvp)(a.h1s + off), (lvp)(B2 + row * LD::PB), 16, 0, 0);
+    }
+  };
   auto fetch = [&](int64_t r0) {
 #pragma unroll
-    for (int q = 0; q < NVA; ++q) {
+    for (int q = 0; q < (GL ? 0 : NVA); ++q) {
       const int idx = q * NT + tid;
       const int row = idx / (G::UR / 4), c4 = idx - row * (G::UR / 4);
       const int64_t r = r0 + row;
@@ -886,7 +922,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       if (!FUSE) sa1[q] = ok ? *reinterpret_cast<const v4*>(a.dy1s + off) : z;
     }
 #pragma unroll
-    for (int q = 0; q < NVB; ++q) {
+    for (int q = 0; q < (GL ? 0 : NVB); ++q) {
       const int idx = q * NT + tid;
       const int row = idx / (H / 4), c4 = idx - row * (H / 4);
       const int64_t r = r0 + row;
@@ -914,7 +950,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
     real* B2 = FUSE ? A1 : A1 + KC * LD::PA;
     real* BX = B2 + KC * LD::PB;
 #pragma unroll
-    for (int q = 0; q < NVA; ++q) {
+    for (int q = 0; q < (GL ? 0 : NVA); ++q) {
       const int idx = q * NT + tid;
       if (idx < KC * G::UR / 4) {
         const int row = idx / (G::UR / 4), c4 = idx - row * (G::UR / 4);
@@ -923,7 +959,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < NVB; ++q) {
+    for (int q = 0; q < (GL ? 0 : NVB); ++q) {
       const int idx = q * NT + tid;
       if (idx < KC * H / 4) {
         const int row = idx / (H / 4), c4 = idx - row * (H / 4);
@@ -942,13 +978,17 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
 
   int cur = 0;
   if (r_lo < r_hi) {
+    if (GL) dma(r_lo, 0);
     fetch(r_lo);
     stash(0);
   }
   __syncthreads();
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += KC) {
     const bool more = r0 + KC < r_hi;
-    if (more) fetch(r0 + KC);
+    if (more) {
+      if (GL) dma(r0 + KC, cur ^ 1);         // free since the last barrier
+      fetch(r0 + KC);
+    }
     const real* A2 = lds + cur * LD::BUF;
     const real* A1 = A2 + KC * LD::PA;
     const real* B2 = FUSE ? A1 : A1 + KC * LD::PA;
