@@ -314,7 +314,9 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
                          dtype=dtype)[:, :-1, :22]
         rt = torch.randn(n3, t3, device="cuda", generator=g, dtype=dtype)
         runw = critic_ops.make_runner(wide)
-        us_w = kernel_time_us(lambda: runw.epoch(st, rt, rt, 0.0), launches=3)
+        # (12 launches: three 3 ms launches right after the busy-wait kernel run
+        # before the clocks are back up -- 10 % slower than steady state)
+        us_w = kernel_time_us(lambda: runw.epoch(st, rt, rt, 0.0), launches=12)
         fl = 6.0 * (22 * 256 + 256 * 256 + 256) * n3 * t3
         extra["critic_256x2_" + tag] = {
             "kernel": "mlpw_chain_kernel + mlpw_grad_kernel + "

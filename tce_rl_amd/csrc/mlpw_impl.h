@@ -607,6 +607,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     // the MFMAs of panel s, one element per hook; only the last panel's is
     // exposed.  (The bias is added there too: the accumulators start at zero
     // instead of waiting for an LDS read at the top of every panel.)
+    // (fp32 only: + 0.5 %; the fp64 kernel measured the same either way and needs
+    // the registers)
+    constexpr bool DEFER = MLPW_DEFER && sizeof(real) == 4;
     vacc facc[2][NTILE];
     auto fwd_elem = [&](int sp, int n, const vacc* b2r, const vacc* w3r) {
       const int jj = n >> 2, i = n & 3;
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           pan + (s & 1) * LD::PANEL, m, g, h1, facc[s & 1],
           [&]() { if (!GLDS && pre) stash((s & 1) ^ 1); },
           [&](int h) {
-            if (s == 0 || !MLPW_DEFER) return;
+            if (s == 0 || !DEFER) return;
             typedef WHooks<real, H> HK;
             if (h == 0) {
 #pragma unroll
@@ -650,7 +653,12 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
             }
           });
       WSTAMP(4)
-      if (s == NP - 1 || !MLPW_DEFER) {
+      // (v pinned here: where a step ends in a branch -- the register-staged
+      // build -- the compiler otherwise sinks every panel's epilogue to the end
+      // of the tile, with all the raw accumulators alive until then: 214
+      // spilled registers in the fp64 forward kernel)
+      asm volatile("" : "+v"(v));
+      if (s == NP - 1 || !DEFER) {
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) {
           b2r[jj] = *reinterpret_cast<const v4*>(Bs + H + 16 * (s * NTILE + jj) + bo);
