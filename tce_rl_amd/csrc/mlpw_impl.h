@@ -719,6 +719,8 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           dy2[J][i] = dv * w3v[i] * wact_d<real, ACT>(hv);
         }
         *reinterpret_cast<v4*>(pd + 16 * J) = dy2[J];
+        // (tried: a four-value butterfly -- 5 cross-lane adds instead of 16 -- for
+        // these row sums: no measurable difference, fp32 or fp64)
 #pragma unroll
         for (int i = 0; i < 4; ++i) t3[i] = row16_sum(t3[i]);
         if (m == 0) {
@@ -846,6 +848,9 @@ struct GradLds {
 #ifndef MLPW_GRAD_GLDS
 #define MLPW_GRAD_GLDS 1
 #endif
+#ifndef MLPW_GRAD_GLDS_F64
+#define MLPW_GRAD_GLDS_F64 1
+#endif
   // (tried: three stage buffers with the rows requested two stages ahead,
   // counted vmcnt + bare s_barrier -- 0.4 % slower: HBM latency is not what the
   // gradient kernel waits for)
@@ -898,8 +903,9 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   // through registers).  Rows past R of the last stage come from the workspace
   // like the others: the chain kernel wrote them (whole tiles), dY2 / dY1 as
   // exact zeros.
-  constexpr bool GL = WGlds<real>::on && G::UR == H && H * sizeof(real) == 1024 &&
-                      KC % 8 == 0 && MLPW_GRAD_GLDS;
+  constexpr int EPI = 1024 / (int)sizeof(real);              // elements per DMA instruction
+  constexpr bool GL = G::UR % EPI == 0 && H % EPI == 0 && KC % 8 == 0 &&
+                      (sizeof(real) == 4 ? MLPW_GRAD_GLDS : MLPW_GRAD_GLDS_F64);
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   auto dma = [&](int64_t r0, int buf) {
     typedef const __attribute__((address_space(1))) void* gvp;
@@ -910,11 +916,19 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
 #pragma unroll
     for (int q = 0; q < KC / 8; ++q) {
       const int row = wave_s * (KC / 8) + q;
-      const int64_t off = (r0 + row) * H + lane * 4;
-      __builtin_amdgcn_global_load_lds((gvp)(a.dy2s + off), (lvp)(A2 + row * LD::PA), 16, 0, 0);
-      if (!FUSE)
-        __builtin_amdgcn_global_load_lds((gvp)(a.dy1s + off), (lvp)(A1 + row * LD::PA), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvp)(a.h1s + off), (lvp)(B2 + row * LD::PB), 16, 0, 0);
+      const int64_t off = (r0 + row) * H + lane * (EPI / 64);
+#pragma unroll
+      for (int e = 0; e < G::UR / EPI; ++e) {
+        __builtin_amdgcn_global_load_lds((gvp)(a.dy2s + off + ubase + e * EPI),
+                                         (lvp)(A2 + row * LD::PA + e * EPI), 16, 0, 0);
+        if (!FUSE)
+          __builtin_amdgcn_global_load_lds((gvp)(a.dy1s + off + ubase + e * EPI),
+                                           (lvp)(A1 + row * LD::PA + e * EPI), 16, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < H / EPI; ++e)
+        __builtin_amdgcn_global_load_lds((gvp)(a.h1s + off + e * EPI),
+                                         (lvp)(B2 + row * LD::PB + e * EPI), 16, 0, 0);
     }
   };
   auto fetch = [&](int64_t r0) {
