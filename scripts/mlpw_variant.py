@@ -29,7 +29,8 @@ if not os.path.exists(so) or "--rebuild" in sys.argv:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC",
                                "-std=c++17", "-DMLPW_F32_WAVES=%d" % W, "-DMLPW_F32_PU=%d" % PU,
                                "-DMLPW_F32_WGS=%d" % WGS, "-DMLPW_F32_KPG=%d" % KPG,
-                               "-DMLPW_ONLY_LEAKY"] + extra + ["-c", os.path.join(CS, src + ".hip"), "-o", o])
+                               ] + ([] if os.environ.get("MLPW_ALL_ACTS") else ["-DMLPW_ONLY_LEAKY"]) +
+                              extra + ["-c", os.path.join(CS, src + ".hip"), "-o", o])
         objs.append(o)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC",
                            "-o", so] + objs + others)

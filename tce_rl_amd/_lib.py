@@ -9,7 +9,8 @@ import re
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtce_hip.so")
+# (TCE_HIP_LIB: another build of the same library -- scripts/mlpw_variant.py -- for A / B runs)
+LIB_PATH = os.environ.get("TCE_HIP_LIB") or os.path.join(_PKG, "libtce_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "tce_hip.h")
 
 _lib = None

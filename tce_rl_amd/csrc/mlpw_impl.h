@@ -137,6 +137,14 @@ struct WArgs {
 };
 
 // fp32 chain-kernel shape (scripts/mlpw_variant.py builds others to compare)
+// fp64: 8 waves = two per SIMD at 256 registers each, which holds ONE [hidden x 16
+// rows] image, not two (PARK in the chain kernel: H2 waits in the workspace, H1 is
+// re-read per backward panel).  6.41 -> 6.16 ms per C3 epoch against 4 waves with
+// both images resident: the second wave hides the panel start-up / barrier / epilogue
+// stalls that nothing covered at one wave per SIMD (VERDICT r2's suggestion).
+#ifndef MLPW_F64_WAVES
+#define MLPW_F64_WAVES 8
+#endif
 #ifndef MLPW_F32_WAVES
 #define MLPW_F32_WAVES 8          // waves per workgroup
 #define MLPW_F32_PU 32            // output units per W2 panel
@@ -145,10 +153,8 @@ struct WArgs {
 
 template <typename real>
 struct WCfg {
-  // chain kernel: two waves per SIMD in fp32; fp64 keeps its B operands in 128
-  // registers per lane and spills at the 256 of a two-wave kernel (tried: 279
-  // spilled registers), so it runs one wave per SIMD
-  static constexpr int WAVES = sizeof(real) == 4 ? MLPW_F32_WAVES : 4;
+  // chain kernel: two waves per SIMD (fp64: see MLPW_F64_WAVES)
+  static constexpr int WAVES = sizeof(real) == 4 ? MLPW_F32_WAVES : MLPW_F64_WAVES;
   static constexpr int WGS = sizeof(real) == 4 ? MLPW_F32_WGS : 1;   // chain workgroups per CU
   // copies of the db1 / db2 / dw3 accumulators in LDS: one per wave (plain
   // read-modify-write, fixed summation order); fewer copies than waves would
@@ -602,7 +608,14 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     // in the dY2 rows of the workspace and read H1 back: 3 x R x H elements of
     // HBM traffic per epoch for 64 registers.)
     real v = 0;
-    vacc dy2[BWD ? NJ : 1];
+    // PARK (fp64 with two waves per SIMD: 256 registers per lane): ONE register
+    // image of [hidden x 16 rows] -- H1 through the forward panels, then dY2.
+    // The H2 tiles wait in the dY2 rows of the workspace (each lane reads back
+    // what it wrote), H1 for act'(H1) is re-read per backward panel.
+    constexpr bool PARK = BWD && sizeof(real) == 8 && C::WAVES == 8;
+    vacc dy2_own[BWD && !PARK ? NJ : 1];
+    vacc* dy2 = PARK ? h1 : dy2_own;
+    vacc park_t[NTILE];
     // The epilogue of panel s - 1 (bias, activation, its share of v) runs inside
     // the MFMAs of panel s, one element per hook; only the last panel's is
     // exposed.  (The bias is added there too: the accumulators start at zero
@@ -615,7 +628,8 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       const int jj = n >> 2, i = n & 3;
       const real hv = wact<real, ACT>(facc[sp & 1][jj][i] + b2r[jj][i]);
       v += w3r[jj][i] * hv;
-      if (BWD) dy2[sp * NTILE + jj][i] = hv;
+      if (PARK) park_t[jj][i] = hv;
+      else if (BWD) dy2[sp * NTILE + jj][i] = hv;
     };
     vacc b2r[NTILE], w3r[NTILE];
     const int bo = 4 * go;
@@ -666,6 +680,11 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         }
 #pragma unroll
         for (int n = 0; n < 4 * NTILE; ++n) fwd_elem(s, n, b2r, w3r);
+        if (PARK) {
+#pragma unroll
+          for (int jj = 0; jj < NTILE; ++jj)
+            *reinterpret_cast<v4*>(a.dy2s + r * H + 4 * g + 16 * (s * NTILE + jj)) = park_t[jj];
+        }
       }
       WSTAMP(6)
       WSTEP_SYNC();
@@ -708,6 +727,12 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       // panels; dw3 = sums over the 16 batch lanes of a row (db2 and db1 are
       // column sums of the dY2 / dY1 rows: the gradient kernel takes them from
       // its A fragments for free)
+      if (PARK) {
+        // H2 back from the workspace into the image H1 occupied (its last use as
+        // the B operand was the last forward panel)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) dy2[J] = *reinterpret_cast<const v4*>(pd + 16 * J);
+      }
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
         const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
@@ -744,6 +769,12 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           else fetch(last ? 0 : NP + s + 1);
         }
         if (FUSE && last && more) load_x(tile + gridDim.x, xn);
+        vacc h1p[NTILE];                                       // PARK: this panel's H1 tile, from the workspace
+        if (PARK) {
+#pragma unroll
+          for (int jj = 0; jj < NTILE; ++jj)
+            h1p[jj] = *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj));
+        }
         vacc acc[NTILE];
 #pragma unroll
         for (int jj = 0; jj < NTILE; ++jj) acc[jj] = (vacc){0, 0, 0, 0};
@@ -757,7 +788,8 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[jj][i] *= wact_d<real, ACT>(h1[J][i]);
+          for (int i = 0; i < 4; ++i)
+            acc[jj][i] *= wact_d<real, ACT>(PARK ? h1p[jj][i] : h1[J][i]);
           if (FUSE)
             *reinterpret_cast<v4*>(t1buf + (s & 1) * C::TILE * TP1 + (wave * 16 + m) * TP1 +
                                    16 * jj + 4 * g) = acc[jj];
