@@ -455,10 +455,10 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   // per lane): no staging registers, no ds_write pass.  The barrier that ends a
   // step waits for them (hipcc drains vmcnt before a barrier while an LDS-DMA
   // is in flight).
-  constexpr int IPR = H * (int)sizeof(real) / 1024;          // instructions per panel row
+  constexpr int IPR = H * (int)sizeof(real) >= 1024 ? H * (int)sizeof(real) / 1024 : 1;   // instructions per panel row
   constexpr int NDMA = C::PU * IPR / C::WAVES;               // per wave and panel
-  static_assert(IPR >= 1 && C::PU * IPR % C::WAVES == 0, "panel DMA");
-  constexpr bool GLDS = WGlds<real>::on;
+  static_assert(C::PU * IPR % C::WAVES == 0, "panel DMA");
+  constexpr bool GLDS = WGlds<real>::on && H * sizeof(real) >= 1024;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   auto dma = [&](int s, int buf) {
     const real* base = panel_src(s);
