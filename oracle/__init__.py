@@ -40,4 +40,8 @@ Pinning status
   pinned against an INDEPENDENT solution of the constrained problem it solves:
   ``tests/test_kl_optimum_cpu.py`` (scipy SLSQP on the Cholesky parameters), plus
   KKT / finite-difference self-tests.
+* ``frob_oracle`` (Frobenius projection, named by the factory, selected by no
+  experiment file): **parity unpinned** for the same reason; the paper's two
+  closed forms sample by sample; ``tests/test_frob_gpu.py`` checks that both
+  distances land on their bounds where they were exceeded.
 """

@@ -180,6 +180,69 @@ class KLProjectionLayer(BaseProjectionLayer):
         return proj_mean, proj_L
 
 
+def gaussian_frobenius(policy, p, q, scale_prec):
+    """(mean_part, cov_part) [N] of the Frobenius trust-region metric of Otto
+    et al. (ICLR 2021, sec. 4.1): mean_part = (mu_q - mu)^T Sigma_q^-1 (mu_q -
+    mu) (scale_prec; else the squared Euclidean distance), cov_part =
+    tr((Sigma_q - Sigma)^T (Sigma_q - Sigma))."""
+    mean, L = p
+    mean_o, L_o = q
+    N = mean.shape[0]
+    if scale_prec:
+        mean_part = ops.maha(mean, mean_o, L_o)
+    else:
+        mean_part = ((mean_o - mean) ** 2).sum(-1)
+    shared = getattr(L, "_tce_base", None) is not None or L.dim() == 2
+    Lb = ops.first_matrix(L)[None] if shared else ops.full_L(L, N)
+    Lob = ops.first_matrix(L_o)[None] if (
+        getattr(L_o, "_tce_base", None) is not None or L_o.dim() == 2) \
+        else ops.full_L(L_o, N)
+    diff = Lob @ Lob.transpose(-1, -2) - Lb @ Lb.transpose(-1, -2)
+    cov_part = (diff * diff).sum((-1, -2))
+    return mean_part, cov_part.expand(N) if cov_part.shape[0] == 1 else cov_part
+
+
+class FrobeniusProjectionLayer(BaseProjectionLayer):
+    """Frobenius projection (Otto et al. 2021, sec. 4.1 / app. B.1), named by
+    the reference's factory (mprl/rl/projection/__init__.py:4-5,18-24) and used
+    by none of its experiment files.  Both steps are closed forms --
+        mu~    = (mu + omega mu_old) / (1 + omega),   omega = sqrt(d_mean / eps_mu) - 1
+        Sigma~ = (Sigma + eta Sigma_old) / (1 + eta), eta   = sqrt(d_cov / eps_Sigma) - 1
+    where a bound is exceeded, the identity elsewhere -- and run as a handful of
+    batched torch operations on the device with autograd through them (one
+    matrix when the covariance is not contextual); not a hot path of any
+    BASELINE config, so no kernel was written for it.  The third-party class is
+    not under /root/reference: what is built is the paper's statement."""
+
+    def trust_region_value(self, policy, p, q):
+        return gaussian_frobenius(policy, p, q, self.scale_prec)
+
+    def _trust_region_projection(self, policy, p, q, eps, eps_cov, beta):
+        mean, L = p
+        mean_o, L_o = q
+        N = mean.shape[0]
+        mean_o, L_o = mean_o.detach(), ops.detach_L(L_o)
+        mean_part, cov_part = gaussian_frobenius(policy, (mean, L), (mean_o, L_o),
+                                                 self.scale_prec)
+        omega = torch.sqrt(mean_part.clamp_min(1e-30) / eps) - 1.0
+        omega = torch.where(mean_part > eps, omega, torch.zeros_like(omega))
+        proj_mean = (mean + omega[:, None] * mean_o) / (1.0 + omega[:, None])
+        shared = not policy.contextual_std
+        Lb = ops.first_matrix(L)[None] if shared else ops.full_L(L, N)
+        Lob = ops.first_matrix(L_o)[None] if shared else ops.full_L(L_o, N)
+        cp = cov_part[:1] if shared else cov_part
+        cov, cov_o = Lb @ Lb.transpose(-1, -2), Lob @ Lob.transpose(-1, -2)
+        eta = torch.sqrt(cp.clamp_min(1e-30) / eps_cov) - 1.0
+        eta = torch.where(cp > eps_cov, eta, torch.zeros_like(eta))
+        new_cov = (cov + eta[:, None, None] * cov_o) / (1.0 + eta[:, None, None])
+        proj = torch.where((cp > eps_cov)[:, None, None],
+                           torch.linalg.cholesky(new_cov), Lb)
+        proj_p = (proj_mean, ops.expand_shared(proj[0], N) if shared else proj)
+        if beta is not None:
+            proj_p = self._entropy_projection(policy, proj_p, beta)
+        return proj_p
+
+
 def projection_factory(typ, **kwargs):
     """mprl/rl/projection/__init__.py:18-40."""
     dtype, device = parse_dtype_device(kwargs["dtype"], kwargs["device"])
@@ -188,9 +251,11 @@ def projection_factory(typ, **kwargs):
     kwargs["dtype"] = dtype
     del kwargs["device"]
     classes = {"BaseProjectionLayer": BaseProjectionLayer,
-               "KLProjectionLayer": KLProjectionLayer}
+               "KLProjectionLayer": KLProjectionLayer,
+               "FrobeniusProjectionLayer": FrobeniusProjectionLayer}
     if typ not in classes:
         raise NotImplementedError(
-            "%s: only the KL (and identity) projection of the TCE/BBRL "
-            "configs is built" % typ)
+            "%s: the KL projection of every TCE / BBRL config, the Frobenius "
+            "and the identity layer are built; the Wasserstein and PAPI layers "
+            "of the third-party package are not" % typ)
     return classes[typ](**kwargs)
