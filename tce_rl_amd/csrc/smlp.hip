@@ -938,11 +938,19 @@ inline int s_tri_inverse(const float* Lm, float* Li, int K, hipStream_t st) {
 // (eta lambda_k + 1)), the covariance halves of the three KL terms, the
 // entropy of the projected policy and the trust region gradient w.r.t. the new
 // factor.  One wave.  dctx (double): [lambda K | mu K | eta, active, -, -].
-__global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
+// (A device function: its own 64-thread kernel before the first epoch; behind
+// an epoch's Adam step the finish kernel runs it for the NEXT epoch -- one launch
+// less in a chain of dependent launches.  Called by whole workgroups; wave 0
+// does the work, `dg` is the caller's [3][64] LDS array.)
+__device__ inline void bb_diag_fwd_body(
     const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
     double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
     float* __restrict__ L_proj, float* __restrict__ Li_proj, float* __restrict__ gL_tr,
-    float* __restrict__ out16, double* __restrict__ dctx) {
+    float* __restrict__ out16, double* __restrict__ dctx, float (*dg)[64]) {
+  if (threadIdx.x >= 64) {
+    __syncthreads();                                     // (the barrier below)
+    return;
+  }
   const int k = threadIdx.x;
   const bool live = k < K;
   double sig = 1, so = 1;
@@ -988,7 +996,6 @@ __global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
   }
   const double pl = active ? so * sqrt(mu) : sig;
   // the matrices (diagonal; everything else zero)
-  __shared__ float dg[3][64];
   dg[0][k] = (float)sig;
   dg[1][k] = (float)pl;
   dg[2][k] = include_cov ? (float)((double)tr_coeff * (sig / (pl * pl) - 1.0 / sig)) : 0.f;
@@ -1028,6 +1035,16 @@ __global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
   }
 }
 
+__global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
+    const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
+    double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
+    float* __restrict__ L_proj, float* __restrict__ Li_proj, float* __restrict__ gL_tr,
+    float* __restrict__ out16, double* __restrict__ dctx) {
+  __shared__ float dg[3][64];
+  bb_diag_fwd_body(var, min_std, L_old, K, eps_cov, tr_coeff, include_cov, L_new, L_proj, Li_proj,
+                   gL_tr, out16, dctx, dg);
+}
+
 // finish of a black-box policy epoch (one workgroup): the mean parts of the KL
 // terms and the trust region loss from the Mahalanobis sums, the corrections
 // on the diagonal of d / d L_proj, -- diagonal factors -- the covariance
@@ -1045,10 +1062,15 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
     int include_cov, float ent_coef, float* __restrict__ param, float* __restrict__ grad,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ state, float lr, float b1,
     float b2, float eps, float wd, float clip_grad, float gscale, int do_adam,
-    float* __restrict__ out16, float* __restrict__ rec) {
+    float* __restrict__ out16, float* __restrict__ rec,
+    // next_fwd (diagonal factors, behind the Adam step): bb_diag_fwd_body of the NEXT epoch
+    int next_fwd, float min_std, double eps_cov, float* __restrict__ L_new_w,
+    float* __restrict__ L_proj_w, float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w,
+    double* __restrict__ dctx_w) {
   __shared__ float red[SNW];
   __shared__ float coef_s, step_s;
   __shared__ double gsh[64];
+  __shared__ float dg[3][64];
   const int tid = threadIdx.x;
   const double invN = 1.0 / (double)N;
   const float sum_g = (float)(-dsum[0] * invN);          // sum over rows of d surrogate / d logp
@@ -1159,6 +1181,14 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
     m[p] = mi;
     v[p] = vi;
     param[p] = w - step_size * mi / (sqrtf(vi) / bc2s + eps);
+  }
+  if (next_fwd) {
+    // the next epoch's head / projection from the parameters just written (same
+    // workgroup: visible behind the barrier)
+    __threadfence_block();
+    __syncthreads();
+    bb_diag_fwd_body(param + P, min_std, L_old, K, eps_cov, tr_coeff, include_cov, L_new_w,
+                     L_proj_w, Li_proj_w, gL_tr_w, out16, dctx_w, dg);
   }
 }
 
@@ -1444,11 +1474,16 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   for (int e = 0; e < epochs; ++e) {
     const bool lastep = e == epochs - 1;
     int rc;
+    // (diagonal factors: from the second epoch on the previous finish kernel has
+    // already run this epoch's head / projection behind its Adam step)
+    const bool chained = diag && do_adam;
     if (diag) {
-      hipLaunchKernelGGL(bb_diag_fwd_kernel, dim3(1), dim3(64), 0, st, param + P, min_std, L_old, K,
-                         eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, Li_proj, gL_tr, out16,
-                         proj_ctx);
-      TCE_LAUNCH_CHECK();
+      if (e == 0 || !chained) {
+        hipLaunchKernelGGL(bb_diag_fwd_kernel, dim3(1), dim3(64), 0, st, param + P, min_std, L_old,
+                           K, eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, Li_proj, gL_tr,
+                           out16, proj_ctx);
+        TCE_LAUNCH_CHECK();
+      }
     } else {
       rc = tce_chol_build_fwd_f32(param + P, L_new, 1, K, nvec, min_std, stream);
       if (rc) return rc;
@@ -1478,7 +1513,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
       hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 0, 0, g_pL, gL_tr,
                          gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff,
                          tr_include_cov, ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2,
-                         eps, weight_decay, clip_grad, grad_scale, do_adam, out16, rec + 7 * e);
+                         eps, weight_decay, clip_grad, grad_scale, do_adam, out16, rec + 7 * e, 0,
+                         0.f, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr);
       TCE_LAUNCH_CHECK();
       rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
       if (rc) return rc;
@@ -1486,7 +1522,9 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
     hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 1, diag, g_pL, gL_tr,
                        gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff, tr_include_cov,
                        ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,
-                       clip_grad, grad_scale, do_adam, out16, rec + 7 * e);
+                       clip_grad, grad_scale, do_adam, out16, rec + 7 * e,
+                       chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr,
+                       proj_ctx);
     TCE_LAUNCH_CHECK();
   }
   return 0;
