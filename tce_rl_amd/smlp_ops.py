@@ -2,7 +2,7 @@
 row kernels of csrc/smlp.hip (D_in <= 64 -> H -> H -> D_out, H in {32, 64},
 float32): rollout forward, the critic update and the policy update of
 ``BlackBoxAgent`` (mprl/rl/agent/black_box_agent.py:105-389) without autograd
-and without library GEMMs -- two launches per critic epoch, four (diagonal
+and without library GEMMs -- two launches per critic epoch, three (diagonal
 covariance, the reference's BBRL configuration) or seven per policy epoch.
 """
 import torch
