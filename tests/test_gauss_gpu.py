@@ -245,12 +245,17 @@ def test_kl_cov_projection_kernel_is_the_constrained_optimum(ops, K):
     GPU) against a direct SLSQP solution of
         min KL_cov(S~ || S)  s.t.  KL_cov(S~ || S_old) <= eps
     (tests/test_kl_optimum_cpu.py; nothing of oracle/kl_oracle.py involved)."""
+    import os
     import numpy as np
-    from test_kl_optimum_cpu import direct_cov_projection, kl_cov, spd
-    g = np.random.default_rng(K)
-    S_old, S = spd(K, g), spd(K, g, scale=1.7)
-    eps = 5e-3
-    C_ref, f_ref, slack = direct_cov_projection(S, S_old, eps)
+    from test_kl_optimum_cpu import kl_cov
+    # the SLSQP solutions come from tests/golden/kl_slsqp.npz (generator:
+    # tests/golden/make_kl_slsqp.py; one K = 24 solve takes minutes on a GPU
+    # box's host share -- tests/test_kl_optimum_cpu.py re-solves the small
+    # cases against the file)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "kl_slsqp.npz"))
+    S, S_old, eps = gold["S_%d" % K], gold["S_old_%d" % K], float(gold["eps"])
+    C_ref = gold["C_%d" % K]
+    f_ref, slack = (float(x) for x in gold["f_slack_%d" % K])
     assert abs(slack) < 2e-8           # SLSQP's own feasibility (300 unknowns at K 24)
     chol = lambda A: torch.linalg.cholesky(torch.as_tensor(A))[None].cuda()
     pl = ops.kl_cov_projection(chol(S), chol(S_old), eps)[0].cpu()

@@ -133,3 +133,18 @@ def test_mean_projection_is_the_constrained_optimum(K):
     assert abs(half_maha(pm, m_old) - eps) < 1e-12
     assert abs(half_maha(pm, m) - r.fun) <= 1e-8 * max(1.0, r.fun)
     np.testing.assert_allclose(pm, r.x, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [4, 12])
+def test_slsqp_fixture_is_reproducible(K):
+    """tests/golden/kl_slsqp.npz (read by the GPU test of the projection
+    kernel) holds what direct_cov_projection returns for the same inputs."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "kl_slsqp.npz"))
+    g = np.random.default_rng(K)
+    S_old, S = spd(K, g), spd(K, g, scale=1.7)
+    np.testing.assert_array_equal(S, gold["S_%d" % K])
+    np.testing.assert_array_equal(S_old, gold["S_old_%d" % K])
+    C, f, slack = direct_cov_projection(S, S_old, float(gold["eps"]))
+    np.testing.assert_allclose(C, gold["C_%d" % K], rtol=1e-6, atol=1e-8)
+    assert abs(f - float(gold["f_slack_%d" % K][0])) <= 1e-8 * max(1.0, abs(f))
