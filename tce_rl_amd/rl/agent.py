@@ -310,11 +310,87 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
         self.critic_cus_per_xcd = kwargs.get("critic_cus_per_xcd", None)
         self.adaptive_critic_split = kwargs.get("adaptive_critic_split", True)
+        # step() returns its metrics as util.LazyMetrics (filled on first
+        # access) and does not wait for the critic epochs it has enqueued: the
+        # host prepares the next rollout meanwhile (overlapped updates, one
+        # process; otherwise the metrics are read before step() returns)
+        # (TCE_LAZY_METRICS=0: the default of this option, for A / B runs)
+        import os
+        self.lazy_metrics = kwargs.get(
+            "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
+        self._lazy_done = []            # end-of-step events of the last steps
+        self._split_probe = None        # events the next critic split is taken from
         self._critic_split = 0          # 0: all epochs beside the policy
         self._critic_stream = None
         self._policy_stream = None
 
+    def _lazy_step_possible(self):
+        from .. import critic_ops
+        return (self.lazy_metrics and self._can_overlap()
+                and not self.dist.active and self.device.type == "cuda"
+                and critic_ops.supported(self.critic.net))
+
+    def _step_lazy(self):
+        """step() without a host wait at its end (see lazy_metrics): phase
+        times come from HIP events, the records are read when the metrics are."""
+        self.num_iterations += 1
+        # at most one iteration ahead of the device
+        while len(self._lazy_done) >= 2:
+            self._lazy_done.pop(0).synchronize()
+        main = torch.cuda.current_stream()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(main)
+        dataset, num_env_interaction = self.sampler.run(
+            training=True, policy=self.policy, critic=self.critic)
+        self.num_global_steps += num_env_interaction * self.dist.world
+        ev[1].record(main)
+        dataset = self.process_dataset(dataset)
+        ev[2].record(main)
+        stat_items = {k: v for k, v in dataset.items()
+                      if k not in ("segment_params_L", "step_states_full",
+                                   "step_states", "step_actions")}
+        tail = self._update_overlapped(
+            dataset, lambda: util.device_stats_async(stat_items, "exploration"),
+            lazy=True)
+        if self.schedule_lr_critic:
+            self.critic_lr_scheduler.step()
+        if self.schedule_lr_policy:
+            self.policy_lr_scheduler.step()
+        ev[3].record(main)
+        self._lazy_done.append(ev[3])
+        steps = self.num_global_steps
+        lr_p = self.policy_lr_scheduler.get_last_lr()[0] \
+            if self.schedule_lr_policy else self.lr_policy
+        lr_c = self.critic_lr_scheduler.get_last_lr()[0] \
+            if self.schedule_lr_critic else self.lr_critic
+
+        def resolve():
+            ev[3].synchronize()
+            critic_loss_dict, policy_loss_dict, t_c, t_p, dataset_stats = tail()
+            return {**dataset_stats, **critic_loss_dict, **policy_loss_dict,
+                    "sampling_time": ev[0].elapsed_time(ev[1]) * 1e-3,
+                    "process_dataset_time": ev[1].elapsed_time(ev[2]) * 1e-3,
+                    "update_time": ev[2].elapsed_time(ev[3]) * 1e-3,
+                    "update_critic_time": t_c, "update_policy_time": t_p,
+                    "num_global_steps": steps, "lr_policy": lr_p,
+                    "lr_critic": lr_c}
+        result = util.LazyMetrics(resolve)
+        if self.evaluation_interval and (
+                self.evaluation_interval == 1 or
+                self.num_iterations % self.evaluation_interval == 1):
+            util.run_time_test(lock=True, key="evaluation")
+            evd = self.evaluate()[0]
+            result.update(util.device_stats(
+                {k: v for k, v in evd.items()
+                 if k not in ("segment_params_L", "step_states_full",
+                              "step_states", "step_actions")}, "evaluation"))
+            result["evaluation_time"] = util.run_time_test(
+                lock=False, key="evaluation")
+        return result
+
     def step(self):
+        if self._lazy_step_possible():
+            return self._step_lazy()
         self.num_iterations += 1
         util.run_time_test(lock=True, key="sampling")
         dataset, num_env_interaction = self.sampler.run(
@@ -385,7 +461,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
     def _can_overlap(self):
         return self.overlap_updates and self.num_minibatchs == 1
 
-    def _update_overlapped(self, dataset, side_work=None):
+    def _update_overlapped(self, dataset, side_work=None, lazy=False):
         """The critic and policy updates of one iteration touch disjoint
         networks and only read the dataset, so they are independent.  The
         critic epochs (one persistent MFMA kernel each, 1 workgroup per CU) are
@@ -427,6 +503,14 @@ class TemporalCorrelatedAgent(AbstractAgent):
                            dataset["step_returns"],
                            dataset["step_values"][:, :-1])
         E = ce.E
+        if self._split_probe is not None:
+            pev, pn1, pE = self._split_probe
+            if pev[4].query() and pev[5].query():
+                if self.adaptive_critic_split and cstream is None:
+                    first_ms = pev[0].elapsed_time(pev[4]) / max(pn1, 1)
+                    side_ms = pev[2].elapsed_time(pev[5])
+                    self._critic_split = int(min(pE, side_ms / first_ms + 2))
+                self._split_probe = None
         n1 = min(E, self._critic_split) if self._critic_split else E
         ev[0].record(main)
         cs = main if cstream is None else cstream
@@ -452,6 +536,17 @@ class TemporalCorrelatedAgent(AbstractAgent):
         main.wait_stream(side)
         if cstream is not None:
             main.wait_stream(cstream)
+        if lazy:
+            # nothing is read here: the caller's metrics resolve `tail` later;
+            # the next split comes from this step's events once they are done
+            # (looked at when the next update starts)
+            self._split_probe = (ev, n1, E)
+
+            def tail():
+                return ce.finish(), policy_loss_dict, \
+                    ev[0].elapsed_time(ev[1]) * 1e-3, \
+                    ev[2].elapsed_time(ev[3]) * 1e-3, finish_side()
+            return tail
         critic_loss_dict = ce.finish()
         side_result = finish_side()
         torch.cuda.synchronize()
@@ -885,6 +980,9 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # one launch per critic epoch, six per policy epoch, no autograd, no
         # library GEMM, no graph.  Off: the op-by-op / graph paths below.
         self.small_net_kernels = kwargs.get("small_net_kernels", True)
+        import os
+        self.lazy_metrics = kwargs.get(
+            "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
         self._epoch_graphs = {}
 
     def _epoch_graph(self, kind, E, opt, inputs, rec_cols):
@@ -945,7 +1043,65 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             eg.graph.replay()
         opt.host_step += n
 
+    def _step_lazy(self):
+        """step() that leaves its host reads to the returned metrics
+        (util.LazyMetrics; TemporalCorrelatedAgent.lazy_metrics): the row-kernel
+        updates of both networks side by side, nothing waited for."""
+        self.num_iterations += 1
+        done = self.__dict__.setdefault("_lazy_done", [])
+        while len(done) >= 2:
+            done.pop(0).synchronize()
+        main = torch.cuda.current_stream()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record(main)
+        dataset, n_steps = self.sampler.run(training=True, policy=self.policy,
+                                            critic=self.critic)
+        self.num_global_steps += n_steps * self.dist.world
+        ev[1].record(main)
+        dataset = self.process_dataset(dataset)
+        stats_fin = util.device_stats_async(
+            {k: v for k, v in dataset.items()
+             if k not in ("segment_params_L", "segment_state")}, "exploration")
+        if getattr(self, "_bb_stream", None) is None:
+            from .. import streams
+            self._bb_stream = streams.get("policy", self.device)
+        side = self._bb_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            finish_critic = self.update_critic(dataset, defer=True)
+        finish_policy = self.update_policy(dataset, defer=True)
+        main.wait_stream(side)
+        ev[2].record(main)
+        done.append(ev[2])
+        steps = self.num_global_steps
+
+        def resolve():
+            ev[2].synchronize()
+            return {**stats_fin(), **finish_critic(), **finish_policy(),
+                    "sampling_time": ev[0].elapsed_time(ev[1]) * 1e-3,
+                    "update_time": ev[1].elapsed_time(ev[2]) * 1e-3,
+                    "num_global_steps": steps, "lr_policy": self.lr_policy,
+                    "lr_critic": self.lr_critic}
+        result = util.LazyMetrics(resolve)
+        if self.evaluation_interval and (
+                self.evaluation_interval == 1 or
+                self.num_iterations % self.evaluation_interval == 1):
+            evd = self.evaluate()[0]
+            result.update(util.device_stats(
+                {k: v for k, v in evd.items()
+                 if k not in ("segment_params_L", "segment_state")},
+                "evaluation"))
+        return result
+
     def step(self):
+        from .. import smlp_ops
+        if self.lazy_metrics and self.overlap_updates and \
+                self.small_net_kernels and self.num_minibatchs == 1 and \
+                not self.dist.active and self.device.type == "cuda" and \
+                self.projection.initial_entropy is not None and \
+                smlp_ops.critic_supported(self) and \
+                getattr(self, "_bb_small_policy", False):
+            return self._step_lazy()
         self.num_iterations += 1
         util.run_time_test(lock=True, key="sampling")
         dataset, n_steps = self.sampler.run(training=True, policy=self.policy,
@@ -960,6 +1116,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         from .. import smlp_ops
         small = self.small_net_kernels and smlp_ops.critic_supported(self) \
             and smlp_ops.policy_supported(self, dataset["segment_params_L"])
+        # (the lazy step needs both networks on the row kernels: known from here on)
+        self._bb_small_policy = bool(small)
         if self.overlap_updates and (self.graph_epochs or small) and \
                 self.num_minibatchs == 1 and not self.dist.active:
             # the two updates are independent chains of ~100 small launches per
@@ -1072,7 +1230,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                 torch.stack(norms_c)]).cpu().numpy()
         return (lambda: stats(host)) if defer else stats(host)
 
-    def update_policy(self, dataset):
+    def update_policy(self, dataset, defer=False):
         states = dataset["segment_state"]
         actions = dataset["segment_action"]
         log_probs_old = dataset["segment_log_prob"]
@@ -1085,7 +1243,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         E = self.epochs_policy
         from .. import smlp_ops
         if self.small_net_kernels and smlp_ops.policy_supported(self, L_old):
-            return self._update_policy_small(dataset)
+            return self._update_policy_small(dataset, defer=defer)
+        assert not defer, "deferred reads: row-kernel path only"
         eg, st = self._epoch_graph(
             "policy", E, self.policy_optimizer,
             dict(states=states, actions=actions, log_probs_old=log_probs_old,
@@ -1172,7 +1331,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         return self._finish_policy_update(rec, last["t"], states, mean_old,
                                           L_old)
 
-    def _update_policy_small(self, dataset):
+    def _update_policy_small(self, dataset, defer=False):
         """update_policy on the row kernels of csrc/smlp.hip: per epoch the
         Cholesky head, the covariance projection, ONE kernel for everything
         per env (mean net forward, mean projection, log-prob, surrogate, trust
@@ -1198,29 +1357,20 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         N = states.shape[0]
         last = (mean_new, ops.expand_shared(L_new, N), proj_mean,
                 ops.expand_shared(proj_L, N))
-        return self._finish_policy_update(rec, last, states, mean_old, L_old)
+        return self._finish_policy_update(rec, last, states, mean_old, L_old,
+                                          defer=defer)
 
-    def _finish_policy_update(self, rec, last, states, mean_old, L_old):
-        host = rec.cpu().numpy()                          # ONE copy
-        for name, bad in zip(("surrogate_loss", "entropy_loss",
-                              "trust_region_loss"),
-                             np.isnan(host[:, :3]).any(axis=0)):
-            if bad:
-                raise Exception("NAN %s detected" % name)
+    def _finish_policy_update(self, rec, last, states, mean_old, L_old,
+                              defer=False):
+        """Everything that changes device state is enqueued here; the host
+        reads (per-epoch record, projection metrics) happen in the returned
+        closure when `defer` (BlackBoxAgent's lazy step), else at once."""
         mean_new, L_new, proj_mean, proj_L = last
-        names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
-                 "policy_loss", "entropy", "policy_grad_norm",
-                 "clipped_policy_grad_norm")
-        out = {}
-        for i, n in enumerate(names):
-            out.update(util.generate_stats(host[:, i], n))
         metrics = self.projection.compute_metrics(
             self.policy, (mean_new, L_new), (proj_mean, proj_L),
             self.num_iterations)
-        mh = torch.stack([v.to(self.dtype) for v in metrics.values()]) \
-            .cpu().numpy()
-        out.update({"projection_" + k: float(v)
-                    for k, v in zip(metrics.keys(), mh)})
+        mkeys = list(metrics.keys())
+        mdev = torch.stack([v.to(self.dtype) for v in metrics.values()])
         if self.set_variance and not self.policy.contextual_cov:
             with torch.no_grad():
                 m, L = self.policy.policy(states)
@@ -1228,7 +1378,25 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                         (mean_old, L_old),
                                         self.num_iterations)
                 self.policy.set_cov_variable(pL)
-        return out
+
+        def read():
+            host = rec.cpu().numpy()                      # ONE copy
+            for name, bad in zip(("surrogate_loss", "entropy_loss",
+                                  "trust_region_loss"),
+                                 np.isnan(host[:, :3]).any(axis=0)):
+                if bad:
+                    raise Exception("NAN %s detected" % name)
+            names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
+                     "policy_loss", "entropy", "policy_grad_norm",
+                     "clipped_policy_grad_norm")
+            out = {}
+            for i, n in enumerate(names):
+                out.update(util.generate_stats(host[:, i], n))
+            mh = mdev.cpu().numpy()
+            out.update({"projection_" + k: float(v)
+                        for k, v in zip(mkeys, mh)})
+            return out
+        return read if defer else read()
 
 
 def agent_factory(typ, **kwargs):

@@ -247,7 +247,24 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
         reference), float32 -> int64, then one small upload."""
         pairs = select_pred_pairs(num_all=self.num_times,
                                   **self.time_pairs_config)
-        self.pred_pairs = pairs.to(torch.long).to(self.device)
+        pairs = pairs.to(torch.long)
+        if self.device.type == "cuda":
+            # from pinned memory, without waiting for the stream: an upload from
+            # pageable memory blocks the host until everything enqueued before
+            # it has run (the previous iteration's critic epochs, see
+            # agent.lazy_metrics).  Three buffers in turn: the host is at most
+            # one iteration ahead of the device.
+            ring = self.__dict__.setdefault("_pairs_pinned", [])
+            if len(ring) < 3 or ring[0].shape != pairs.shape:
+                ring[:] = [torch.empty(pairs.shape, dtype=torch.long).pin_memory()
+                           for _ in range(3)]
+                self._pairs_turn = 0
+            buf = ring[self._pairs_turn % 3]
+            self._pairs_turn += 1
+            buf.copy_(pairs)
+            self.pred_pairs = buf.to(self.device, non_blocking=True)
+        else:
+            self.pred_pairs = pairs.to(self.device)
         # env shards of one job use the SAME segments (SURVEY 8e): rank 0's draw
         from ..dist import active, broadcast
         if active():

@@ -162,6 +162,44 @@ def device_stats_async(tensors, name):
     return finish
 
 
+class LazyMetrics(dict):
+    """The metrics of an iteration whose device work may still be running: a
+    dict that fills itself (one blocking read of the device-side records) on
+    first access.  `agent.step()` returns it so that the host can enqueue the
+    next rollout behind the critic epochs instead of waiting for them and then
+    leaving the GPU idle while it prepares ~50 small launches."""
+
+    def __init__(self, resolver):
+        super().__init__()
+        self._resolver = resolver
+
+    def resolve(self):
+        r, self._resolver = self._resolver, None
+        if r is not None:
+            dict.update(self, r())
+        return self
+
+    @property
+    def pending(self):
+        return self._resolver is not None
+
+
+def _lazy_method(name):
+    base = getattr(dict, name)
+
+    def f(self, *a, **k):
+        self.resolve()
+        return base(self, *a, **k)
+    f.__name__ = name
+    return f
+
+
+for _n in ("__getitem__", "__contains__", "__iter__", "__len__", "__repr__", "__eq__",
+           "__ne__", "get", "keys", "items", "values", "copy", "update", "pop",
+           "setdefault", "__setitem__", "__delitem__", "__or__", "__ror__"):
+    setattr(LazyMetrics, _n, _lazy_method(_n))
+
+
 def rewrite_dict(d, prefix):
     return {prefix + "_" + k: v for k, v in d.items()}
 
