@@ -855,3 +855,52 @@ def test_deferred_join_does_not_depend_on_side_stream_timing(monkeypatch):
                    [agent.policy.variance_net.variable.detach().cpu().clone()])
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+TIME_KEYS = ("sampling_time", "process_dataset_time", "update_time",
+             "update_critic_time", "update_policy_time", "projection_time",
+             "policy_epochs_device_time", "evaluation_time")
+
+
+@pytest.mark.parametrize("kind", ["tce", "bbrl"])
+def test_lazy_step_equals_eager_step(kind):
+    """step() hands its metrics back as util.LazyMetrics and does not wait for
+    the device (agent.lazy_metrics, the default): three iterations with the
+    metrics read only at the end leave bit-identical parameters and the same
+    metrics (timers aside) as three iterations that read them at once."""
+    from tce_rl_amd.util import LazyMetrics
+    out = []
+    for lazy in (False, True):
+        torch.manual_seed(31)
+        np.random.seed(31)
+        if kind == "tce":
+            agent, _ = build(64, 3, True, lazy_metrics=lazy)
+            nets = [agent.policy.mean_net, agent.critic.net]
+        else:
+            agent, _ = build_bbrl(64, 3)
+            agent.lazy_metrics = lazy
+            agent.evaluation_interval = 0     # (an evaluation reads the metrics)
+            nets = [agent.policy.mean_net, agent.critic.net]
+        torch.manual_seed(32)
+        results = [agent.step() for _ in range(3)]
+        if lazy:
+            # (the first BBRL iteration latches the initial entropy and is eager)
+            assert all(isinstance(r, LazyMetrics) for r in results[1:])
+            assert results[-1].pending
+        else:
+            assert not any(isinstance(r, LazyMetrics) and r.pending for r in results)
+        params = sum((to_cpu_params(n) for n in nets), []) + \
+            [agent.policy.variance_net.variable.detach().cpu().clone()]
+        out.append((params, [dict(r) for r in results]))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    for ra, rb in zip(out[0][1], out[1][1]):
+        assert set(ra) == set(rb)
+        for k in ra:
+            if k not in TIME_KEYS:
+                # (the gradient-norm records sum squares with float atomics:
+                # equal to the last bits, not bit for bit)
+                tol = 1e-3 if "grad_norm" in k else 0.0   # (std of 3 near-equal values)
+                same = ra[k] == rb[k] or (ra[k] != ra[k] and rb[k] != rb[k]) or \
+                    abs(ra[k] - rb[k]) <= tol * max(abs(ra[k]), abs(rb[k]))
+                assert same, (k, ra[k], rb[k])
