@@ -55,12 +55,18 @@ def task_of(env_id):
     return fam
 
 
+_TT_BASE = {}
+
+
 def initial_object(task, goal3, hand):
     """Object / ball position at reset as a function of goal and hand (no
     extra random draw, so a forced (goal, pos) reset fixes the whole state)."""
     if task == "table_tennis":
-        base = torch.tensor([1.5, 0.0, 0.3], dtype=hand.dtype,
-                            device=hand.device)
+        key = (hand.dtype, hand.device)
+        base = _TT_BASE.get(key)
+        if base is None:                 # (uploaded once: a host -> device copy
+            base = _TT_BASE[key] = torch.tensor(   # per reset would wait for the stream)
+                [1.5, 0.0, 0.3], dtype=hand.dtype, device=hand.device)
         return base + 0.2 * goal3
     return hand + 0.25 * (goal3 - hand)
 
@@ -108,14 +114,28 @@ class SyntheticTCEEnv:
         return self._obs0
 
     def reset(self):
+        """goal ~ U(-1, 1)^dof, hand position ~ 0.1 U(-1, 1)^dof, at rest, time
+        0 -- as few launches as it takes (a rollout resets twice and its ~50
+        small launches run at the device's back-to-back launch interval): one
+        draw for both, the observation written into one zeroed buffer (_obs
+        builds the same thing for a forced (goal, pos, vel) reset)."""
         N, D = self.num_env, self.num_dof
-        r = lambda *s: torch.rand(*s, generator=self.gen, dtype=self.dtype,
-                                  device=self.device)
-        self.goal = r(N, D) * 2 - 1
-        pos = 0.1 * (r(N, D) * 2 - 1)
-        vel = torch.zeros(N, D, dtype=self.dtype, device=self.device)
-        time = torch.zeros(N, dtype=self.dtype, device=self.device)
-        return self._obs(time, pos, vel)
+        u = torch.empty(N, 2 * D, dtype=self.dtype, device=self.device) \
+            .uniform_(-1.0, 1.0, generator=self.gen)
+        self.goal = u[:, :D]
+        obs = torch.zeros(N, self.dim_obs, dtype=self.dtype, device=self.device)
+        pos = obs[:, :D]
+        torch.mul(u[:, D:], 0.1, out=pos)
+        g3 = self.goal[:, :3]
+        obs[:, 2 * D:2 * D + 3] = initial_object(self.task, g3, pos[:, :3])
+        obs[:, 2 * D + 3:2 * D + 6] = g3
+        obs[:, self.dim_task_obs + 1:self.dim_task_obs + 1 + D] = pos
+        self._obs0 = obs
+        return self._visible(obs)
+
+    def _visible(self, obs):
+        """What reset() hands out of the full observation."""
+        return obs
 
     def step(self, actions, obs_shift=None, want_moments=False):
         """actions [N, T, 2 dof] (desired pos | vel) -> one whole episode.
@@ -164,6 +184,9 @@ class SyntheticBBEnv(SyntheticTCEEnv):
 
     def _obs(self, time, pos, vel):
         return super()._obs(time, pos, vel)[:, :self.dim_task_obs]
+
+    def _visible(self, obs):
+        return obs[:, :self.dim_task_obs]
 
     def step(self, params):
         from .. import ops

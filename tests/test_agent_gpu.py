@@ -119,7 +119,8 @@ def test_direct_epoch_equals_autograd_epoch():
                           for p in agent.policy.parameters]))
     (ra, pa), (rb, pb) = out
     for a, b in zip(pa, pb):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        # (two fp32 summation orders over 3 Adam steps: a few 1e-7 on weights of 1e-3 .. 1)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=5e-7)
     for k in ("surrogate_loss_mean", "trust_region_loss_mean", "entropy_mean",
               "policy_grad_norm_mean", "projection_new_old_cov_diff_mean",
               "projection_proj_old_mean_diff_mean"):
