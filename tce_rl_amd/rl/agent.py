@@ -319,7 +319,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.lazy_metrics = kwargs.get(
             "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
         self._lazy_done = []            # end-of-step events of the last steps
-        self._split_probe = None        # events the next critic split is taken from
+        self._split_probes = []         # events of the last steps the critic split is taken from
         self._critic_split = 0          # 0: all epochs beside the policy
         self._critic_stream = None
         self._policy_stream = None
@@ -503,14 +503,18 @@ class TemporalCorrelatedAgent(AbstractAgent):
                            dataset["step_returns"],
                            dataset["step_values"][:, :-1])
         E = ce.E
-        if self._split_probe is not None:
-            pev, pn1, pE = self._split_probe
-            if pev[4].query() and pev[5].query():
+        # (lazy steps) the newest earlier step whose events are complete gives the
+        # split; with all epochs beside the policy its critic event is the END of
+        # that step's epochs, which the host may be ahead of -- then an older one
+        for i in range(len(self._split_probes) - 1, -1, -1):
+            pev, pn1, pE = self._split_probes[i]
+            if pev[6].query() and pev[5].query():
                 if self.adaptive_critic_split and cstream is None:
-                    first_ms = pev[0].elapsed_time(pev[4]) / max(pn1, 1)
+                    first_ms = pev[0].elapsed_time(pev[6]) / max(min(pn1, 6), 1)
                     side_ms = pev[2].elapsed_time(pev[5])
                     self._critic_split = int(min(pE, side_ms / first_ms + 2))
-                self._split_probe = None
+                del self._split_probes[:i + 1]
+                break
         n1 = min(E, self._critic_split) if self._critic_split else E
         ev[0].record(main)
         cs = main if cstream is None else cstream
@@ -518,8 +522,14 @@ class TemporalCorrelatedAgent(AbstractAgent):
             else 8 * self.critic_cus_per_xcd
         if cstream is not None:
             cstream.wait_event(ev[0])
+        # (ev[6]: behind the first few epochs -- a per-epoch time that is complete
+        # long before the host comes back for the next split, lazy steps)
+        nprobe = min(n1, 6)
+        ev.append(torch.cuda.Event(enable_timing=True))
         with torch.cuda.stream(cs):
-            ce.run(n1, wg)
+            ce.run(nprobe, wg)
+            ev[6].record(cs)
+            ce.run(n1 - nprobe, wg)
             ev[4].record(cs)
         side.wait_event(ev[0])
         with torch.cuda.stream(side):
@@ -540,7 +550,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
             # nothing is read here: the caller's metrics resolve `tail` later;
             # the next split comes from this step's events once they are done
             # (looked at when the next update starts)
-            self._split_probe = (ev, n1, E)
+            self._split_probes = self._split_probes[-2:] + [(ev, n1, E)]
 
             def tail():
                 return ce.finish(), policy_loss_dict, \
