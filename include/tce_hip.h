@@ -279,6 +279,19 @@ int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, in
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 
+/* ---- exact median by radix select (csrc/select.hip) ---------------------------
+ * The "median" entry of the reference's metric dictionaries, generate_stats
+ * (mprl/util/util_numerical.py:130-164; per dataset tensor in
+ * temporal_correlated_agent.py:166-176, black_box_agent.py:83-103), without
+ * sorting the tensor: x [n] -> out[0] (double) = element of rank (n - 1) / 2 (the
+ * lower median, torch.median's convention; NaNs order above +inf).  ws: unsigned
+ * [tce_median_ws_len()], zeroed once by the caller (each call leaves it zeroed);
+ * one workspace per stream.  1 <= n < 2^32.
+ */
+int tce_median_ws_len(void);
+int tce_median_f32(const float* x, int64_t n, double* out, unsigned* ws, void* stream);
+int tce_median_f64(const double* x, int64_t n, double* out, unsigned* ws, void* stream);
+
 /* ---- GPU-resident synthetic env suite ------------------------
  * Stands in for the env processes behind SubprocVecEnv.step
  * (mprl/util/util_mp.py:119-185) and speaks the per-episode protocol the

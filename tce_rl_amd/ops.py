@@ -638,6 +638,24 @@ def rms_normalize(x, mean, var, eps=1e-8, inplace=False):
     return y
 
 
+_MEDIAN_WS = {}
+
+
+def median(x):
+    """Lower median of all elements of a float32 / float64 device tensor as a
+    0-dim float64 tensor (csrc/select.hip: radix select, no sort)."""
+    x = _c(x.detach()).reshape(-1)
+    s = stream()
+    key = (x.device, s)
+    ws = _MEDIAN_WS.get(key)
+    if ws is None:
+        ws = _MEDIAN_WS[key] = torch.zeros(
+            _lib.load().tce_median_ws_len(), dtype=torch.int32, device=x.device)
+    out = torch.empty((), dtype=torch.float64, device=x.device)
+    call("tce_median_" + sfx(x.dtype), ptr(x), x.numel(), ptr(out), ptr(ws), s)
+    return out
+
+
 def mdp_reward(step_rewards, event_flags):
     """make_mdp_reward: returns the re-shaped rewards (new tensor)."""
     check_dev(step_rewards, event_flags)

@@ -145,10 +145,11 @@ def device_stats_async(tensors, name):
             continue
         x = v.detach().double().reshape(-1)
         std = x.std() if x.numel() > 1 else x.new_zeros(())
-        # the median (a sort) on the tensor's own float type: the same element as
-        # after the exact conversion to double, at half the sorting work
-        med = v.detach().reshape(-1).median().double() \
-            if v.dtype in (torch.float32, torch.float64) else x.median()
+        if v.is_cuda and v.dtype in (torch.float32, torch.float64):
+            from .. import ops
+            med = ops.median(v)                   # radix select (csrc/select.hip)
+        else:
+            med = x.median()
         rows.append(torch.stack([x.mean(), x.max(), x.min(), med, std]))
         keys.append(k)
     if not rows:
