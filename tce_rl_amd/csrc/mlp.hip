@@ -639,6 +639,8 @@ void mlp_go(bool bwd, const MlpArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int tce_cu_budget_value(void);       // csrc/pair_logprob.hip
+
 extern "C" {
 
 int tce_mlp_critic_hidden(void) { return HID; }
@@ -721,7 +723,15 @@ int tce_mlp_hidden_f32(const float* x, int64_t env_stride, int64_t row_stride, i
             bwd ? nullptr : hidden_out, grad_hidden};
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = ceil_div(R, ROWS_PER_TILE);
-  const int grid = (int)tmin<int64_t>(tce_mlp_critic_grid(), ntiles);
+  int grid = (int)tmin<int64_t>(tce_mlp_critic_grid(), ntiles);
+  // beside the critic's persistent grid (tce_set_cu_budget) only that many CUs
+  // are free and a workgroup needs a whole one: as many workgroups as CUs, each
+  // staging the weights once for several tiles, instead of two or three rounds
+  // of one-tile workgroups
+#ifndef MLP_HIDDEN_IGNORE_BUDGET
+  const int budget = tce_cu_budget_value();
+  if (budget > 0 && grid > budget) grid = budget;
+#endif
   switch (act) {
     case 0: mlp_go<ACT_TANH>(bwd, a, grid, st); break;
     case 1: mlp_go<ACT_RELU>(bwd, a, grid, st); break;

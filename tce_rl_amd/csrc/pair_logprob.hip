@@ -753,6 +753,9 @@ int tce_set_cu_budget(int compute_units) {
   return 0;
 }
 
+// (library-internal: the budget for kernels of other translation units)
+int tce_cu_budget_value(void) { return g_cu_budget; }
+
 /* workspace (in elements of the dtype) of the pair log-prob calls; 0 for a
  * per-env L */
 int64_t tce_pair_logprob_work_len(int64_t N, int P, int dof, int nbg, int64_t L_stride,
