@@ -596,7 +596,7 @@ def main():
                     help="skip the `configs` block (the other BASELINE.json "
                          "configs, a few timed steps each)")
     ap.add_argument("--config-steps", type=int, default=3)
-    ap.add_argument("--config-warmup", type=int, default=2)
+    ap.add_argument("--config-warmup", type=int, default=4)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, what the driver's curve uses): 4096 "
                          "envs per GPU; strong: 4096 envs in total, "
