@@ -909,11 +909,31 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int din = a.din;
-  const int ubase = blockIdx.y * G::UR;
+  // (row range, unit half) of this workgroup.  NSPLIT = 2 (fp64, H = 256): the two
+  // halves of a row range read the same H1 rows; they are placed on the SAME XCD
+  // (workgroups go to the XCDs round robin: b and b + 8 meet) and are resident
+  // together, so the second read of a stage hits that XCD's L2 instead of HBM.
+  int wg_range = blockIdx.x, wg_half = 0;
+  const int wg_ranges = gridDim.x / G::NSPLIT;
+  if (G::NSPLIT == 2) {
+    const int b = blockIdx.x;
+#ifndef MLPW_GRAD_PLAIN_PAIRS
+    if (wg_ranges % 8 == 0) {
+      const int xcd = b & 7, slot = b >> 3;
+      wg_range = (slot >> 1) * 8 + xcd;
+      wg_half = slot & 1;
+    } else
+#endif
+    {
+      wg_range = b % wg_ranges;
+      wg_half = b / wg_ranges;
+    }
+  }
+  const int ubase = wg_half * G::UR;
   // rows of this workgroup: a multiple of KC per workgroup
-  int64_t per = (a.R + gridDim.x - 1) / gridDim.x;
+  int64_t per = (a.R + wg_ranges - 1) / wg_ranges;
   per = (per + KC - 1) / KC * KC;
-  const int64_t r_lo = blockIdx.x * per;
+  const int64_t r_lo = wg_range * per;
   const int64_t r_hi = tmin<int64_t>(a.R, r_lo + per);
 
   vacc acc2[NAT][NJ], acc1[NAT][NXT];
@@ -1079,7 +1099,7 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
   }
 
   // ---- slab sections W1, b1, W2, b2 (unit order) of this workgroup's units
-  real* out = a.partials + (int64_t)blockIdx.x * (a.P + 2);
+  real* out = a.partials + (int64_t)wg_range * (a.P + 2);
   real* oW1 = out;
   real* ob1 = out + (int64_t)H * din;
   real* oW2 = ob1 + H;
@@ -1221,7 +1241,7 @@ int mlpw_launch_act(WArgs<real> a, real* workspace, real* grad, real* stats, int
     hipLaunchKernelGGL((mlpw_chain_kernel<real, H, KPG, ACT, true>), dim3(cgrid), dim3(C::NT), lds,
                        st, a);
     TCE_LAUNCH_CHECK();
-    const dim3 ggrid(grid, GradCfg<real, H>::NSPLIT);
+    const dim3 ggrid(grid * GradCfg<real, H>::NSPLIT);
     const size_t glds = GradLds<real, H, KPG>::bytes();
     hipLaunchKernelGGL((mlpw_grad_kernel<real, H, KPG>), ggrid, dim3(512), glds, st, a);
     TCE_LAUNCH_CHECK();
