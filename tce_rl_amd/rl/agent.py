@@ -320,6 +320,10 @@ class TemporalCorrelatedAgent(AbstractAgent):
             "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
         self._lazy_done = []            # end-of-step events of the last steps
         self._split_probes = []         # events of the last steps the critic split is taken from
+        # epochs of slack on the split (a policy stream that outlasts them keeps
+        # the critic's remaining epochs waiting; measured at C2: 2 -> 1 epoch of
+        # slack is 0.4 ms per step, 0.5 no better)
+        self._split_margin = float(os.environ.get("TCE_SPLIT_MARGIN", "1"))
         self._critic_split = 0          # 0: all epochs beside the policy
         self._critic_stream = None
         self._policy_stream = None
@@ -512,7 +516,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 if self.adaptive_critic_split and cstream is None:
                     first_ms = pev[0].elapsed_time(pev[6]) / max(min(pn1, 6), 1)
                     side_ms = pev[2].elapsed_time(pev[5])
-                    self._critic_split = int(min(pE, side_ms / first_ms + 2))
+                    self._critic_split = int(min(pE, side_ms / first_ms + self._split_margin))
                 del self._split_probes[:i + 1]
                 break
         n1 = min(E, self._critic_split) if self._critic_split else E
@@ -564,7 +568,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         first_ms = ev[0].elapsed_time(ev[4]) / max(n1, 1)
         side_ms = ev[2].elapsed_time(ev[5])
         if self.adaptive_critic_split and cstream is None:
-            split = int(min(E, side_ms / first_ms + 2))
+            split = int(min(E, side_ms / first_ms + self._split_margin))
             if self.dist.active:
                 # every rank must issue its collectives in the same order (the
                 # critic's first part, the policy's, the critic's rest): agree
