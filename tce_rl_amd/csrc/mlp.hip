@@ -74,10 +74,47 @@ template <int KPGE>
 __device__ inline void stage_weights(const MlpArgs& a, const Lds<KPGE>& L, int tid, int nthreads) {
   constexpr int W1P = Lds<KPGE>::W1P;
   const int din = a.din;
-  for (int e = tid; e < HID * HID; e += nthreads) L.W2s[(e >> 7) * W2P + (e & 127)] = a.w2[e];
-  for (int e = tid; e < HID * 4 * KPGE; e += nthreads) {
-    const int q = e / (4 * KPGE), f = e - q * 4 * KPGE;
-    L.W1s[q * W1P + f] = f < din ? a.w1[u1_of(q) * din + f] : 0.f;
+  // W2 in 16-byte pieces, a batch of loads in flight per thread: staged element by
+  // element (64 dependent-latency round trips per thread in the 256-thread kernel)
+  // this loop WAS the policy net's forward on 4096 rows -- 146 us beside the critic
+  if ((reinterpret_cast<uintptr_t>(a.w2) & 15) == 0) {
+    const f32x4* w2v = reinterpret_cast<const f32x4*>(a.w2);
+    constexpr int NV = HID * HID / 4, BATCH = 8;
+    for (int e0 = tid; e0 < NV; e0 += BATCH * nthreads) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int e = e0 + b * nthreads;
+        v[b] = w2v[e < NV ? e : NV - 1];
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int e = e0 + b * nthreads;
+        if (e < NV) *reinterpret_cast<f32x4*>(L.W2s + (e >> 5) * W2P + 4 * (e & 31)) = v[b];
+      }
+    }
+  } else {
+    for (int e = tid; e < HID * HID; e += nthreads) L.W2s[(e >> 7) * W2P + (e & 127)] = a.w2[e];
+  }
+  {
+    constexpr int NW1 = HID * 4 * KPGE, BATCH = 8;       // (gathered: position order)
+    for (int e0 = tid; e0 < NW1; e0 += BATCH * nthreads) {
+      float v[BATCH];
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int e = e0 + b * nthreads < NW1 ? e0 + b * nthreads : NW1 - 1;
+        const int q = e / (4 * KPGE), f = e - q * 4 * KPGE;
+        v[b] = a.w1[u1_of(q) * din + (f < din ? f : din - 1)];
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int e = e0 + b * nthreads;
+        if (e < NW1) {
+          const int q = e / (4 * KPGE), f = e - q * 4 * KPGE;
+          L.W1s[q * W1P + f] = f < din ? v[b] : 0.f;
+        }
+      }
+    }
   }
   for (int e = tid; e < HID; e += nthreads) {
     L.Bs[e] = a.b1[u1_of(e)];
