@@ -641,10 +641,14 @@ __global__ __launch_bounds__(2 * MLP_BT, 1) void mlp_critic_bwd_kernel(MlpArgs a
   }
 }
 
+// (forward only: no [batch][hidden] images -- 93 KB instead of 160, so that a
+// forward workgroup can share its CU with another small workgroup of the policy
+// stream, e.g. the single-workgroup covariance projection that otherwise holds
+// the only free CU of a shader engine beside the critic grid)
 template <int KPGE>
-constexpr size_t mlp_lds_bytes() {
+constexpr size_t mlp_lds_bytes(bool bwd = true) {
   return sizeof(float) * ((size_t)HID * W2P + (size_t)HID * (4 * KPGE + 2) + 3 * HID +
-                          2 * (size_t)ROWS_PER_TILE * TPT);
+                          (bwd ? 2 * (size_t)ROWS_PER_TILE * TPT : 0));
 }
 
 template <int ACT, bool BWD, int KPGE>
@@ -660,8 +664,9 @@ void mlp_launch(const MlpArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((mlp_critic_bwd_kernel<ACT, KPGE, false>), dim3(grid), dim3(2 * MLP_BT), lds,
                        st, a);
   } else {
-    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>), (size_t)(lds));
-    hipLaunchKernelGGL((mlp_critic_fwd_kernel<ACT, KPGE>), dim3(grid), dim3(MLP_BT), lds, st, a);
+    constexpr size_t ldsf = mlp_lds_bytes<KPGE>(false);
+    tce_lds_limit(reinterpret_cast<const void*>(mlp_critic_fwd_kernel<ACT, KPGE>), (size_t)(ldsf));
+    hipLaunchKernelGGL((mlp_critic_fwd_kernel<ACT, KPGE>), dim3(grid), dim3(MLP_BT), ldsf, st, a);
   }
 }
 
