@@ -401,7 +401,13 @@ int tce_kl_shared_mat_f64(const double* L_new, const double* L_old, const double
  * elements; pair_work / basis_ws / flag_ws / proj_ctx / sur_ws / kl_ws as in
  * the separate calls (times_flags_fwd / _bwd: the times_flags of the two pair
  * log-prob calls).  proj_started != 0: see tce_policy_objective_begin_*;
- * defer_join != 0: see tce_policy_objective_end_*. */
+ * defer_join & 1: see tce_policy_objective_end_*; defer_join & 2 ("split", for
+ * the balance check of temporal_correlated_agent.py:447-522): nothing is added
+ * up -- grad_mean / grad_L receive the trust region loss's gradient alone, the
+ * surrogate's stays in ws (d / d mean_new at ws + 2 up4(N K); d / d L_new at
+ * ws + 3 up4(N K) + 2 up4(N P) + 2 up4(K K), complete once the library's side
+ * stream has been joined; the entropy term's d / d L_new one up4(K K) block
+ * behind it), up4 = rounded up to a multiple of 4. */
 int64_t tce_policy_objective_ws_len(int64_t N, int K, int P);
 /* n = 1: everything on the caller's stream (no second stream, no events); n = 2
  * (default): as described above.  A process that already drives more streams
@@ -534,6 +540,58 @@ int tce_policy_epoch_f32(
     float weight_decay, float clip_grad, float grad_scale, int do_adam, float* rec_row19,
     void* stream);
 
+/* The same epoch for every mean net the library has kernels for, float32 and
+ * float64, and for the epochs of a balance-check iteration.
+ * net_kind 0: the float32 D_in <= 40 -> 128 -> 128 -> K path above (hidden = 128,
+ * num_hidden = 2; partials / ol_ws as above); net_kind 1: the row kernels of
+ * csrc/pmlp.hip (tce_pmlp_supported(din, hidden, num_hidden, K, element size):
+ * box pushing's float64 128 x 2 net,
+ * mprl/config/box_push_random_init/tcp/entire/shared.yaml:7,75-78, table tennis's
+ * 256 x 1 tanh net, mprl/config/table_tennis_4d/tcp/entire/shared.yaml:78-81;
+ * partials: [tce_pmlp_max_slabs()][tce_pmlp_num_params(...)], ol_ws unused).
+ * param / grad / m / v: FLAT, the mean net's parameters in MLP.parameters()
+ * order, then the variance vector [nvec]; nparam = their total count.
+ * ws: [tce_policy_epoch2_ws_len(N, K, hidden, nparam)].
+ * balance != 0: the epoch of an iteration with num_iterations % balance_check
+ * == 1 (mprl/rl/agent/temporal_correlated_agent.py:447-522: there two extra
+ * forward / backward passes, one of the surrogate loss alone, one of the trust
+ * region loss alone, each followed by grad_norm_clip(0, params) for its norm).
+ * Here the objective is evaluated once with its gradient kept in two parts
+ * (tce_policy_objective_* with defer_join = 3); each part goes back through the
+ * mean net and the Cholesky head alone, bal2[0] / bal2[1] receive the norms of
+ * the surrogate's / the trust region loss's parameter gradient, and their sum
+ * (plus the entropy term's) is the gradient the optimizer step uses.  Requires
+ * do_adam (one process). */
+int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam);
+int tce_policy_epoch2_f32(
+    const float* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+    int net_kind, int act, int nvec, float min_std, float* param, float* grad,
+    const float* mean_old, const float* L_old, const float* traj, const float* logp_old,
+    const float* adv, const int64_t* pairs, const float* tab, int M, int nbg, float tau,
+    float delay, float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
+    int times_flags_fwd, int times_flags_bwd, const float* init_time, const float* init_pos,
+    const float* init_vel, float reg, float* basis_ws, int* flag_ws, float* pair_work,
+    float eps_mean, double eps_cov, const float* beta, int entropy_eq, double* proj_ctx,
+    float tr_coeff, int tr_include_cov, float ent_coef, double* sur_ws, double* kl_ws,
+    float* obj_ws, float* ws, float* partials, float* ol_ws, int T, int P, int dof, int K,
+    float* m, float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
+    float weight_decay, float clip_grad, float grad_scale, int do_adam, int balance,
+    float* rec_row19, float* bal2, void* stream);
+int tce_policy_epoch2_f64(
+    const double* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+    int net_kind, int act, int nvec, double min_std, double* param, double* grad,
+    const double* mean_old, const double* L_old, const double* traj, const double* logp_old,
+    const double* adv, const int64_t* pairs, const double* tab, int M, int nbg, double tau,
+    double delay, double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
+    int times_flags_fwd, int times_flags_bwd, const double* init_time, const double* init_pos,
+    const double* init_vel, double reg, double* basis_ws, int* flag_ws, double* pair_work,
+    double eps_mean, double eps_cov, const double* beta, int entropy_eq, double* proj_ctx,
+    double tr_coeff, int tr_include_cov, double ent_coef, double* sur_ws, double* kl_ws,
+    double* obj_ws, double* ws, double* partials, double* ol_ws, int T, int P, int dof, int K,
+    double* m, double* v, double* opt_state, double lr, double beta1, double beta2, double eps,
+    double weight_decay, double clip_grad, double grad_scale, int do_adam, int balance,
+    double* rec_row19, double* bal2, void* stream);
+
 /* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
  * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->
  * mprl/util/util_nn.py:225-246) -- on the kernels of the fused critic epoch.
@@ -656,6 +714,43 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
                          int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                          float* adam_state, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float adam_step, void* stream);
+
+/* ---- policy mean net on rows (float32 / float64, one or two hidden layers) ----
+ * D_in <= 64 -> hidden (-> hidden) -> D_out <= 64 over N rows, torch Linear
+ * layout, parameters FLAT in the order of MLP.parameters()
+ * (mprl/util/util_nn.py:75-160): W1 [hidden][D_in] | b1 | (W2 [hidden][hidden]
+ * | b2) | W3 [D_out][hidden] | b3.  The mean nets of
+ * mprl/config/box_push_random_init/tcp/entire/shared.yaml:7,75-78 (float64,
+ * 128 x 2) and mprl/config/table_tennis_4d/tcp/entire/shared.yaml:78-81
+ * (256 x 1, tanh) -- MLP.forward (util_nn.py:225-246) and what autograd does
+ * for it inside update_policy (temporal_correlated_agent.py:523-612) -- on the
+ * exact 16x16x4 matrix instructions.  act: 0 tanh, 1 relu, 2 leaky_relu, 3
+ * softplus (util_nn.py:16-25); no output activation.
+ * tce_pmlp_supported: hidden 128 with 1 or 2 hidden layers, hidden 256 with 1,
+ * element size 4 or 8.
+ * forward: out [N][D_out]; h1 / h2 (nullable; h2 only with two hidden layers)
+ * [N][hidden] receive the hidden activations the backward needs.
+ * backward: grad [P] = the gradient of sum(grad_out * out) w.r.t. every
+ * parameter (P = tce_pmlp_num_params); partials: [tce_pmlp_max_slabs()][P]
+ * scratch (per-workgroup slabs, added in a fixed order).  param, h1, h2 must be
+ * 16-byte aligned; x rows may be strided. */
+int tce_pmlp_supported(int din, int hidden, int num_hidden, int dout, int elem_size);
+int64_t tce_pmlp_num_params(int din, int hidden, int num_hidden, int dout);
+int tce_pmlp_max_slabs(void);
+int tce_pmlp_forward_f32(const float* x, int64_t x_stride, int64_t N, int din, int hidden,
+                         int num_hidden, int dout, int act, const float* param, float* h1,
+                         float* h2, float* out, void* stream);
+int tce_pmlp_forward_f64(const double* x, int64_t x_stride, int64_t N, int din, int hidden,
+                         int num_hidden, int dout, int act, const double* param, double* h1,
+                         double* h2, double* out, void* stream);
+int tce_pmlp_backward_f32(const float* x, int64_t x_stride, int64_t N, int din, int hidden,
+                          int num_hidden, int dout, int act, const float* param, const float* h1,
+                          const float* h2, const float* grad_out, float* partials, float* grad,
+                          void* stream);
+int tce_pmlp_backward_f64(const double* x, int64_t x_stride, int64_t N, int din, int hidden,
+                          int num_hidden, int dout, int act, const double* param,
+                          const double* h1, const double* h2, const double* grad_out,
+                          double* partials, double* grad, void* stream);
 
 /* ---- small two-hidden-layer networks (black-box agent) ----------------------
  * D_in <= 64 -> H -> H -> D_out (H in {32, 64}, D_out <= 64), fp32, torch

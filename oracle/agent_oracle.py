@@ -235,7 +235,32 @@ class OracleTCE:
                                 entropy_first=bool(p.get("entropy_first",
                                                          False)))
             return mean_new, L_new, pm, pL
+        # balance check (temporal_correlated_agent.py:447-522): in iterations
+        # with num_iterations % balance_check == 1 every epoch first runs the
+        # surrogate loss alone and the trust region loss alone, each with its
+        # own forward / backward pass, for the norm of its parameter gradient
+        bal = a.get("balance_check", 10)
+        check = isinstance(bal, int) and self.it % bal == 1
+        sur_gn, tr_gn = [], []
+
+        def grad_norm():
+            return float(sum(float(q.grad.norm(2)) ** 2 for q in pparams
+                             if q.grad is not None) ** 0.5)
         for _ in range(a["epochs_policy"]):
+            if check:
+                mean_new, L_new, pm, pL = project()
+                lp = pair_log_prob(self.mp, actions, pm, pL, times, t0, y0, v0,
+                                   pairs)
+                s_loss, _ = O.surrogate_loss(seg_adv, lp, lp_old)
+                self.p_opt.zero_grad(set_to_none=True)
+                s_loss.backward()
+                sur_gn.append(grad_norm())
+                mean_new, L_new, pm, pL = project()
+                tr = KO.trust_region_loss(mean_new, L_new, pm, pL,
+                                          p["trust_region_coeff"], include_cov)
+                self.p_opt.zero_grad(set_to_none=True)
+                tr.backward()
+                tr_gn.append(grad_norm())
             mean_new, L_new, pm, pL = project()
             lp = pair_log_prob(self.mp, actions, pm, pL, times, t0, y0, v0,
                                pairs)
@@ -251,6 +276,8 @@ class OracleTCE:
                     q.grad = torch.zeros_like(q)
             O.grad_norm_clip(clip_gn, [q.grad for q in pparams])
             self.p_opt.step()
+        self.last["surrogate_grad_norm"] = sur_gn
+        self.last["trust_region_grad_norm"] = tr_gn
         if set_var and not self.contextual:                 # :626-637
             with torch.no_grad():
                 _, _, _, pL = project()

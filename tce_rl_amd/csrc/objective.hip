@@ -274,7 +274,7 @@ inline ObjSide* obj_side() {
 
 inline int64_t obj_up4(int64_t n) { return (n + 3) / 4 * 4; }
 inline int64_t obj_ws_len(int64_t N, int K, int P) {
-  return 3 * obj_up4(N * K) + 2 * obj_up4(N * P) + 3 * obj_up4((int64_t)K * K);
+  return 3 * obj_up4(N * K) + 2 * obj_up4(N * P) + 4 * obj_up4((int64_t)K * K);
 }
 template <typename real>
 inline real* obj_proj_L(real* ws, int64_t N, int K, int P) {
@@ -298,6 +298,35 @@ __global__ __launch_bounds__(64) void obj_ent_diag_kernel(real* __restrict__ g,
                                                           real coef) {
   const int i = threadIdx.x;
   if (i < K) g[i * K + i] -= coef / L[i * K + i];
+}
+
+// g = the gradient of -coef * entropy(L) alone: -coef / L[i,i] on the diagonal
+template <typename real>
+__global__ __launch_bounds__(256) void obj_ent_only_kernel(real* __restrict__ g,
+                                                           const real* __restrict__ L, int K,
+                                                           real coef) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= K * K) return;
+  const int i = e / K, j = e - i * K;
+  g[e] = i == j ? -coef / L[e] : real(0);
+}
+// out[0] = |g|_2 over n elements (one workgroup; fixed order)
+template <typename real>
+__global__ __launch_bounds__(1024) void obj_norm_kernel(const real* __restrict__ g, int64_t n,
+                                                        real* __restrict__ out) {
+  __shared__ double red[16];
+  double sq = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) sq += (double)g[i] * (double)g[i];
+  sq = block_sum(sq, red);
+  if (threadIdx.x == 0) out[0] = (real)sqrt(sq);
+}
+// a[i] += b[i] (+ c[i])
+template <typename real>
+__global__ __launch_bounds__(256) void obj_add3_kernel(real* __restrict__ a,
+                                                       const real* __restrict__ b,
+                                                       const real* __restrict__ c, int64_t n) {
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < n) a[i] += c ? b[i] + c[i] : b[i];
 }
 
 template <typename real> struct ObjApi;
@@ -396,7 +425,8 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   OBJ_TRY(A::pl_bwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
                     rel_goal, times, flags_bwd, t0, y0, v0, reg, glp, g_pm, g_pL, basis_ws,
                     flag_ws, pl_work, N, T, P, dof, st));
-  if (ent_coef != real(0)) {
+  const bool split = (defer_join & 2) != 0;
+  if (ent_coef != real(0) && !split) {
     hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
                        ent_coef);
     TCE_LAUNCH_CHECK();
@@ -405,11 +435,25 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   // ---- back through the two projections, side by side
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[3], 0));
   OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p, 1, K, sd));
+  if (split && ent_coef != real(0)) {
+    // the entropy term's own way back (gL_p above is the surrogate's alone)
+    hipLaunchKernelGGL(obj_ent_only_kernel<real>, dim3((unsigned)ceil_div((int64_t)K * K, 256)),
+                       dim3(256), 0, sd, g_pL, pL, K, ent_coef);
+    TCE_LAUNCH_CHECK();
+    OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p + obj_up4((int64_t)K * K), 1,
+                        K, sd));
+  }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
   OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
                      nullptr, N, K, st));
   const int64_t n1 = N * K, n2 = (int64_t)K * K;
-  if (defer_join) {
+  if (split) {
+    // nothing is added: grad_mean / grad_L hold the trust region loss's gradient,
+    // ws the surrogate's (mean: gm_p; factor: gL_p once ev[4] has passed)
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
+    return 0;
+  }
+  if (defer_join & 1) {
     // grad_mean is complete after this; grad_L lacks the projection's part until
     // tce_policy_objective_end_* joins the side stream
     OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
@@ -653,6 +697,201 @@ __global__ __launch_bounds__(64) void policy_record_kernel(const real* __restric
   row19[i] = v;
 }
 
+
+// ---------------------------------------------------------------------------
+// One whole TCE policy epoch without autograd in ONE call (what
+// rl/objective.py:DirectEpoch.run issued as 12 separate calls: the epoch was
+// host-bound at 25 - 35 us per call): Cholesky head + covariance projection on
+// the second stream, mean net forward, the objective and its gradient (deferred
+// join), mean net backward into the flat gradient, join, Cholesky head
+// backward, flat Adam (do_adam; a sharded caller all-reduces first), record.
+// net_kind 0: D_in <= 40 -> 128 -> 128 -> K float32 on the fused MFMA kernels
+// of csrc/mlp.hip + the row kernel of the output layer; 1: any shape of
+// csrc/pmlp.hip (float32 / float64, one or two hidden layers).
+// balance != 0: the epoch of a balance-check iteration
+// (mprl/rl/agent/temporal_correlated_agent.py:447-522): the objective is
+// evaluated ONCE with its gradient split into the surrogate's and the trust
+// region loss's parts (the reference runs three forward / backward passes); each
+// part goes back through the mean net and the Cholesky head by itself and its
+// parameter-gradient norm is stored (bal2), their sum (+ the entropy term's) is
+// the epoch's gradient.
+// ---------------------------------------------------------------------------
+template <typename real> struct EpApi;
+template <> struct EpApi<float> {
+  static constexpr auto begin = tce_policy_objective_begin_f32;
+  static constexpr auto objective = tce_policy_objective_f32;
+  static constexpr auto chol_bwd = tce_chol_build_bwd_f32;
+  static constexpr auto adam = tce_adam_flat_f32;
+  static constexpr auto record = tce_policy_record_f32;
+  static constexpr auto pm_fwd = tce_pmlp_forward_f32;
+  static constexpr auto pm_bwd = tce_pmlp_backward_f32;
+};
+template <> struct EpApi<double> {
+  static constexpr auto begin = tce_policy_objective_begin_f64;
+  static constexpr auto objective = tce_policy_objective_f64;
+  static constexpr auto chol_bwd = tce_chol_build_bwd_f64;
+  static constexpr auto adam = tce_adam_flat_f64;
+  static constexpr auto record = tce_policy_record_f64;
+  static constexpr auto pm_fwd = tce_pmlp_forward_f64;
+  static constexpr auto pm_bwd = tce_pmlp_backward_f64;
+};
+
+inline int64_t epoch2_ws_len(int64_t N, int K, int H, int64_t nparam) {
+  return 2 * obj_up4(N * (int64_t)H) + 2 * obj_up4(N * (int64_t)K) +
+         3 * obj_up4((int64_t)K * K) + 32 + obj_up4(nparam);
+}
+
+// the fused 128 x 2 float32 kernels (net_kind 0) exist in float32 only
+inline int fast_fwd(const float* x, int64_t xs, int64_t N, int din, int act, const float* param,
+                    float* h2, float* mean, int K, void* st) {
+  const float* w1 = param;
+  const float* b1 = w1 + (int64_t)128 * din;
+  const float* w2 = b1 + 128;
+  const float* b2 = w2 + 128 * 128;
+  const float* w3 = b2 + 128;
+  const float* b3 = w3 + (int64_t)K * 128;
+  OBJ_TRY(tce_mlp_hidden_f32(x, 0, xs, (int)N, N, din, w1, b1, w2, b2, act, nullptr, h2, nullptr,
+                             nullptr, nullptr, st));
+  return tce_lin_rows_f32(h2, 128, N, 128, K, w3, 1, b3, mean, st);
+}
+inline int fast_fwd(const double*, int64_t, int64_t, int, int, const double*, double*, double*, int,
+                    void*) {
+  tce_set_error("policy_epoch: net_kind 0 is float32 only");
+  return 1;
+}
+inline int fast_bwd(const float* x, int64_t xs, int64_t N, int din, int act, const float* param,
+                    const float* h2, const float* g_mean, float* gh, float* partials, float* ol_ws,
+                    float* stats, float* grad, int K, void* st) {
+  const float* w1 = param;
+  const float* b1 = w1 + (int64_t)128 * din;
+  const float* w2 = b1 + 128;
+  const float* b2 = w2 + 128 * 128;
+  const float* w3 = b2 + 128;
+  const int64_t PH = (int64_t)128 * din + 128 + 128 * 128 + 128;
+  // (the hidden layers' launch fills [0, PH + 129): first)
+  OBJ_TRY(tce_lin_rows_f32(g_mean, K, N, K, 128, w3, 0, nullptr, gh, st));
+  OBJ_TRY(tce_mlp_hidden_f32(x, 0, xs, (int)N, N, din, w1, b1, w2, b2, act, gh, nullptr, partials,
+                             grad, stats, st));
+  return tce_out_layer_grad_f32(g_mean, h2, grad + PH, grad + PH + (int64_t)K * 128, ol_ws, N, K,
+                                128, st);
+}
+inline int fast_bwd(const double*, int64_t, int64_t, int, int, const double*, const double*,
+                    const double*, double*, double*, double*, double*, double*, int, void*) {
+  tce_set_error("policy_epoch: net_kind 0 is float32 only");
+  return 1;
+}
+
+template <typename real>
+int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+                  int net_kind, int act, int nvec, real min_std, real* param, real* grad,
+                  const real* mean_old, const real* L_old, const real* traj,
+                  const real* logp_old, const real* adv, const int64_t* pairs, const real* tab,
+                  int M, int nbg, real tau, real delay, real scaled_dt, real inv_scale_g,
+                  int rel_goal, const real* times, int times_flags_fwd, int times_flags_bwd,
+                  const real* init_time, const real* init_pos, const real* init_vel, real reg,
+                  real* basis_ws, int* flag_ws, real* pair_work, real eps_mean, double eps_cov,
+                  const real* beta, int entropy_eq, double* proj_ctx, real tr_coeff,
+                  int tr_include_cov, real ent_coef, double* sur_ws, double* kl_ws, real* obj_ws,
+                  real* ws, real* partials, real* ol_ws, int T, int P, int dof, int K, real* m,
+                  real* v, real* opt_state, real lr, real beta1, real beta2, real eps,
+                  real weight_decay, real clip_grad, real grad_scale, int do_adam, int balance,
+                  real* rec_row19, real* bal2, void* stream) {
+  typedef EpApi<real> E;
+  TCE_CHECK_ARG(x && param && grad && ws && partials && obj_ws && rec_row19 && N > 0 &&
+                    K == dof * nbg && K <= 64,
+                "policy_epoch: bad arguments");
+  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "policy_epoch: optimizer state missing");
+  TCE_CHECK_ARG(!balance || bal2, "policy_epoch: balance needs bal2");
+  const int H = hidden;
+  if (net_kind == 0)
+    TCE_CHECK_ARG(sizeof(real) == 4 && H == 128 && num_hidden == 2 && din >= 1 && din <= 40 &&
+                      ol_ws,
+                  "policy_epoch: net_kind 0 = float32 D_in <= 40 -> 128 -> 128 -> K");
+  else
+    TCE_CHECK_ARG(net_kind == 1 && tce_pmlp_supported(din, H, num_hidden, K, (int)sizeof(real)),
+                  "policy_epoch: net shape not built (tce_pmlp_supported)");
+  const int64_t PN = (int64_t)H * din + H + (num_hidden == 2 ? (int64_t)H * H + H : 0) +
+                     (int64_t)K * H + K;                      // mean net parameters
+  const int64_t n = PN + nvec;
+  real* var = param + PN;
+  real* g_var = grad + PN;
+  real* h2 = ws;                                   // top hidden layer
+  real* h1 = h2 + obj_up4(N * (int64_t)H);         // first hidden layer (pmlp, two layers) / gh
+  real* mean = h1 + obj_up4(N * (int64_t)H);
+  real* g_mean = mean + obj_up4(N * (int64_t)K);
+  real* L = g_mean + obj_up4(N * (int64_t)K);
+  real* g_L = L + obj_up4((int64_t)K * K);
+  real* sur2 = g_L + 2 * obj_up4((int64_t)K * K);
+  real* out16 = sur2 + 4;
+  real* stats = out16 + 16;
+  real* gtmp = stats + 12;                         // balance: the surrogate's parameter gradient
+  hipStream_t st = (hipStream_t)stream;
+  // net: forward / backward of a gradient w.r.t. the mean
+  auto net_fwd = [&]() -> int {
+    if (net_kind == 0) return fast_fwd(x, x_stride, N, din, act, param, h2, mean, K, stream);
+    // (pmlp: h1 = first hidden layer, h2 = second; one hidden layer: h1 only)
+    return E::pm_fwd(x, x_stride, N, din, H, num_hidden, K, act, param,
+                     num_hidden == 2 ? h1 : h2, num_hidden == 2 ? h2 : nullptr, mean, stream);
+  };
+  auto net_bwd = [&](const real* gm) -> int {
+    if (net_kind == 0)
+      return fast_bwd(x, x_stride, N, din, act, param, h2, gm, h1, partials, ol_ws, stats, grad, K,
+                      stream);
+    return E::pm_bwd(x, x_stride, N, din, H, num_hidden, K, act, param,
+                     num_hidden == 2 ? h1 : h2, num_hidden == 2 ? h2 : nullptr, gm, partials, grad,
+                     stream);
+  };
+  // ---- forward
+  OBJ_TRY(E::begin(var, nvec, min_std, L_old, eps_cov, beta, entropy_eq, proj_ctx, L, obj_ws, N, K,
+                   P, stream));
+  OBJ_TRY(net_fwd());
+  OBJ_TRY(E::objective(mean, L, mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau,
+                       delay, scaled_dt, inv_scale_g, rel_goal, times, times_flags_fwd,
+                       times_flags_bwd, init_time, init_pos, init_vel, reg, basis_ws, flag_ws,
+                       pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx, tr_coeff,
+                       tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16, N,
+                       T, P, dof, K, 1, balance ? 3 : 1, stream));
+  if (!balance) {
+    // ---- backward into the flat gradient
+    OBJ_TRY(net_bwd(g_mean));
+    OBJ_TRY(policy_objective_end<real>(g_L, obj_ws, N, K, P, st));
+  } else {
+    const bool single = g_obj_streams < 2;
+    ObjSide* S = single ? nullptr : obj_side();
+    TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+    const int64_t KK = obj_up4((int64_t)K * K);
+    real* gm_p = obj_ws + 2 * obj_up4(N * (int64_t)K);      // surrogate: d / d mean_new
+    real* gL_p = obj_proj_L(obj_ws, N, K, P) + 2 * KK;      //            d / d L_new
+    real* gL_e = gL_p + KK;                                 // entropy term: d / d L_new
+    // surrogate alone
+    OBJ_TRY(net_bwd(gm_p));
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+    OBJ_TRY(E::chol_bwd(var, gL_p, g_var, 1, K, nvec, stream));
+    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2);
+    TCE_LAUNCH_CHECK();
+    OBJ_HIP_ALWAYS(hipMemcpyAsync(gtmp, grad, sizeof(real) * PN, hipMemcpyDeviceToDevice, st));
+    // trust region loss alone
+    OBJ_TRY(net_bwd(g_mean));
+    OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
+    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2 + 1);
+    TCE_LAUNCH_CHECK();
+    // the epoch's gradient: their sum (+ the entropy term's way through the factor)
+    hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div(PN, 256)), dim3(256), 0, st,
+                       grad, gtmp, (const real*)nullptr, PN);
+    TCE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div((int64_t)K * K, 256)),
+                       dim3(256), 0, st, g_L, gL_p,
+                       ent_coef != real(0) ? (const real*)gL_e : (const real*)nullptr,
+                       (int64_t)K * K);
+    TCE_LAUNCH_CHECK();
+  }
+  OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
+  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
+  OBJ_TRY(E::adam(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps, weight_decay,
+                  clip_grad, grad_scale, stream));
+  return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -801,7 +1040,7 @@ DEFINE_KL_SHARED_MAT(f64, double)
 // [K][128] | b3 | variance vector [nvec] (the FlatAdam buffer of the policy).
 // ws: float [tce_policy_epoch_ws_len(N, K)].
 int64_t tce_policy_epoch_ws_len(int64_t N, int K) {
-  return 2 * obj_up4(N * 128) + 2 * obj_up4(N * (int64_t)K) + 2 * obj_up4((int64_t)K * K) + 32;
+  return tce_policy_epoch2_ws_len(N, K, 128, 0);
 }
 
 int tce_policy_epoch_f32(
@@ -817,56 +1056,45 @@ int tce_policy_epoch_f32(
     float* m, float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
     float weight_decay, float clip_grad, float grad_scale, int do_adam, float* rec_row19,
     void* stream) {
-  TCE_CHECK_ARG(x && param && grad && ws && partials && ol_ws && obj_ws && rec_row19 && N > 0 &&
-                    din >= 1 && din <= 40 && K == dof * nbg && K <= 64,
-                "policy_epoch: bad arguments");
-  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "policy_epoch: optimizer state missing");
-  const int H = 128;
-  float* w1 = param;
-  float* b1 = w1 + (int64_t)H * din;
-  float* w2 = b1 + H;
-  float* b2 = w2 + H * H;
-  float* w3 = b2 + H;
-  float* b3 = w3 + (int64_t)K * H;
-  float* var = b3 + K;
-  const int64_t PH = (int64_t)H * din + H + H * H + H;     // hidden-layer parameters
-  float* g_w3 = grad + PH;
-  float* g_b3 = g_w3 + (int64_t)K * H;
-  float* g_var = g_b3 + K;
-  float* h2 = ws;
-  float* gh = h2 + obj_up4(N * 128);
-  float* mean = gh + obj_up4(N * 128);
-  float* g_mean = mean + obj_up4(N * (int64_t)K);
-  float* L = g_mean + obj_up4(N * (int64_t)K);
-  float* g_L = L + obj_up4((int64_t)K * K);
-  float* sur2 = g_L + obj_up4((int64_t)K * K);
-  float* out16 = sur2 + 4;
-  float* stats = out16 + 16;
-  // ---- forward
-  OBJ_TRY(tce_policy_objective_begin_f32(var, nvec, min_std, L_old, eps_cov, beta, entropy_eq,
-                                         proj_ctx, L, obj_ws, N, K, P, stream));
-  OBJ_TRY(tce_mlp_hidden_f32(x, 0, x_stride, (int)N, N, din, w1, b1, w2, b2, act, nullptr, h2,
-                             nullptr, nullptr, nullptr, stream));
-  OBJ_TRY(tce_lin_rows_f32(h2, 128, N, 128, K, w3, 1, b3, mean, stream));
-  OBJ_TRY(tce_policy_objective_f32(
-      mean, L, mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau, delay, scaled_dt,
-      inv_scale_g, rel_goal, times, times_flags_fwd, times_flags_bwd, init_time, init_pos,
-      init_vel, reg, basis_ws, flag_ws, pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx,
-      tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16, N, T, P,
-      dof, K, 1, 1, stream));
-  // ---- backward into the flat gradient (the hidden layers' launch fills [0, PH + 129): first)
-  OBJ_TRY(tce_lin_rows_f32(g_mean, K, N, K, 128, w3, 0, nullptr, gh, stream));
-  OBJ_TRY(tce_mlp_hidden_f32(x, 0, x_stride, (int)N, N, din, w1, b1, w2, b2, act, gh, nullptr,
-                             partials, grad, stats, stream));
-  OBJ_TRY(tce_out_layer_grad_f32(g_mean, h2, g_w3, g_b3, ol_ws, N, K, 128, stream));
-  OBJ_TRY(tce_policy_objective_end_f32(g_L, obj_ws, N, K, P, stream));
-  OBJ_TRY(tce_chol_build_bwd_f32(var, g_L, g_var, 1, K, nvec, stream));
-  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
-  const int64_t n = PH + (int64_t)K * H + K + nvec;
-  OBJ_TRY(tce_adam_flat_f32(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps,
-                            weight_decay, clip_grad, grad_scale, stream));
-  return tce_policy_record_f32(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+  return tce_policy_epoch2_f32(
+      x, x_stride, N, din, 128, 2, 0, act, nvec, min_std, param, grad, mean_old, L_old, traj,
+      logp_old, adv, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g, rel_goal, times,
+      times_flags_fwd, times_flags_bwd, init_time, init_pos, init_vel, reg, basis_ws, flag_ws,
+      pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx, tr_coeff, tr_include_cov, ent_coef,
+      sur_ws, kl_ws, obj_ws, ws, partials, ol_ws, T, P, dof, K, m, v, opt_state, lr, beta1, beta2,
+      eps, weight_decay, clip_grad, grad_scale, do_adam, 0, rec_row19, nullptr, stream);
 }
+
+int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
+  return epoch2_ws_len(N, K, hidden, nparam);
+}
+
+#define DEFINE_POLICY_EPOCH2(SFX, REAL)                                                      \
+  int tce_policy_epoch2_##SFX(                                                               \
+      const REAL* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,       \
+      int net_kind, int act, int nvec, REAL min_std, REAL* param, REAL* grad,                \
+      const REAL* mean_old, const REAL* L_old, const REAL* traj, const REAL* logp_old,       \
+      const REAL* adv, const int64_t* pairs, const REAL* tab, int M, int nbg, REAL tau,      \
+      REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal, const REAL* times,         \
+      int times_flags_fwd, int times_flags_bwd, const REAL* init_time, const REAL* init_pos, \
+      const REAL* init_vel, REAL reg, REAL* basis_ws, int* flag_ws, REAL* pair_work,         \
+      REAL eps_mean, double eps_cov, const REAL* beta, int entropy_eq, double* proj_ctx,     \
+      REAL tr_coeff, int tr_include_cov, REAL ent_coef, double* sur_ws, double* kl_ws,       \
+      REAL* obj_ws, REAL* ws, REAL* partials, REAL* ol_ws, int T, int P, int dof, int K,     \
+      REAL* m, REAL* v, REAL* opt_state, REAL lr, REAL beta1, REAL beta2, REAL eps,          \
+      REAL weight_decay, REAL clip_grad, REAL grad_scale, int do_adam, int balance,          \
+      REAL* rec_row19, REAL* bal2, void* stream) {                                           \
+    return policy_epoch2<REAL>(                                                              \
+        x, x_stride, N, din, hidden, num_hidden, net_kind, act, nvec, min_std, param, grad,  \
+        mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau, delay, scaled_dt,     \
+        inv_scale_g, rel_goal, times, times_flags_fwd, times_flags_bwd, init_time, init_pos, \
+        init_vel, reg, basis_ws, flag_ws, pair_work, eps_mean, eps_cov, beta, entropy_eq,    \
+        proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, ws, partials,   \
+        ol_ws, T, P, dof, K, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,           \
+        clip_grad, grad_scale, do_adam, balance, rec_row19, bal2, stream);                   \
+  }
+DEFINE_POLICY_EPOCH2(f32, float)
+DEFINE_POLICY_EPOCH2(f64, double)
 
 int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
                           float ent_coef, float* row19, void* stream) {

@@ -13,7 +13,9 @@
 // state is passed between the launches except the histograms themselves.  The
 // last launch (one workgroup) walks all histograms, writes the element of rank
 // (n - 1) / 2 -- the lower median, torch.median's convention -- as a double and
-// zeroes the workspace for the next call.  NaNs order above +inf.
+// zeroes the workspace for the next call.  torch.median propagates NaN: pass 0
+// counts the NaN inputs (either sign; as keys they would sort above +inf /
+// below -inf) and the final launch writes NaN if there was one.
 #include "common.h"
 
 namespace {
@@ -84,20 +86,28 @@ __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict
     prefix |= (key)b << shift;
     mask |= (key)0xFF << shift;
   }
+  unsigned* nan_count = ghist + 8 * 256;
   if (pass == K::PASSES) {
-    if (t == 0) out[0] = (double)K::back(prefix);
+    if (t == 0) {
+      out[0] = *nan_count ? __longlong_as_double(0x7FF8000000000000ll) : (double)K::back(prefix);
+      *nan_count = 0;
+    }
     for (int q = 0; q < K::PASSES; ++q) ghist[q * 256 + t] = 0;    // ready for the next call
     return;
   }
   lh[t] = 0;
   __syncthreads();
   const int shift = 8 * (K::PASSES - 1 - pass);
+  unsigned nans = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += (int64_t)gridDim.x * 256) {
-    const key kk = K::of(x[i]);
+    const real v = x[i];
+    const key kk = K::of(v);
+    if (pass == 0 && v != v) ++nans;
     if ((kk & mask) == prefix) atomicAdd(&lh[(unsigned)(kk >> shift) & 255u], 1u);
   }
   __syncthreads();
   if (lh[t]) atomicAdd(&ghist[pass * 256 + t], lh[t]);
+  if (nans) atomicAdd(nan_count, nans);
 }
 
 template <typename real>
@@ -117,17 +127,17 @@ int median_launch(const real* x, int64_t n, double* out, unsigned* ws, hipStream
 
 extern "C" {
 
-int tce_median_ws_len(void) { return 8 * 256; }
+int tce_median_ws_len(void) { return 8 * 256 + 1; }
 
 int tce_median_f32(const float* x, int64_t n, double* out, unsigned* ws, void* stream) {
-  TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 32),
-                "median: null buffer / element count outside [1, 2^32)");
+  TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 31),
+                "median: null buffer / element count outside [1, 2^31)");
   return median_launch<float>(x, n, out, ws, (hipStream_t)stream);
 }
 
 int tce_median_f64(const double* x, int64_t n, double* out, unsigned* ws, void* stream) {
-  TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 32),
-                "median: null buffer / element count outside [1, 2^32)");
+  TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 31),
+                "median: null buffer / element count outside [1, 2^31)");
   return median_launch<double>(x, n, out, ws, (hipStream_t)stream);
 }
 

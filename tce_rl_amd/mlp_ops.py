@@ -3,7 +3,9 @@
 Library-GEMM path: the dense layers go through torch.nn.functional.linear
 (hipBLASLt / rocBLAS on ROCm -- plain library GEMMs) with torch autograd.  It is
 the reference-precision path for every MLP shape; the fused MFMA kernels of
-csrc/mlp.hip replace it for the critic's large-batch epochs (critic_ops).
+csrc/mlp.hip replace it for the critic's large-batch epochs (critic_ops), the
+row kernels of csrc/smlp.hip / csrc/pmlp.hip for the forward passes of the
+rollout (no autograd) of the small and of the policy-sized nets.
 """
 import torch
 import torch.nn.functional as F
@@ -56,6 +58,11 @@ def forward(mlp, x):
     if not torch.is_grad_enabled() and smlp_ops.supported(mlp) \
             and x.shape[-1] == mlp.dim_in:
         return smlp_ops.forward(mlp, x)           # csrc/smlp.hip row kernel
+    if not torch.is_grad_enabled() and x.dtype == mlp.dtype \
+            and x.shape[-1] == mlp.dim_in:
+        from . import pmlp_ops
+        if pmlp_ops.supported(mlp):
+            return pmlp_ops.forward(mlp, x)       # csrc/pmlp.hip row kernel
     layers = mlp.layers
     if critic_ops.hidden_supported(mlp, x) and not x.requires_grad \
             and mlp.act_func_last_type is None:

@@ -72,6 +72,8 @@ class AbstractAgent(ABC):
                 mk(self.critic_optimizer) if self.schedule_lr_critic else None)
 
     def save_agent(self, log_dir, epoch):
+        if hasattr(self, "flush_metrics"):
+            self.flush_metrics()        # deferred NaN checks before a checkpoint
         self.policy.save_weights(log_dir, epoch)
         self.critic.save_weights(log_dir, epoch)
         for name, opt in (("policy_optimizer", self.policy_optimizer),
@@ -334,13 +336,32 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 and not self.dist.active and self.device.type == "cuda"
                 and critic_ops.supported(self.critic.net))
 
+    def _retire_lazy_steps(self, keep):
+        """Lazy steps: the host runs at most `keep` iterations ahead of the
+        device.  An iteration that leaves the window has finished on the device
+        (its end event is waited for -- usually long past), and its metrics are
+        read HERE if the caller has not read them: that read carries the checks
+        the reference runs inside update_policy / update_critic in every
+        iteration (NaN losses, temporal_correlated_agent.py:569-577; the f16x2
+        critic's finiteness check), so a caller that never looks at the metrics
+        (MPExperiment.iterate at verbose_level 0) still stops on a NaN, two
+        iterations late at most, and before the next checkpoint
+        (``flush_metrics``)."""
+        done = self.__dict__.setdefault("_lazy_done", [])
+        while done and len(done) >= keep:
+            ev, metrics = done.pop(0)
+            ev.synchronize()
+            metrics.resolve()
+
+    def flush_metrics(self):
+        """Wait for every enqueued iteration and run its deferred checks."""
+        self._retire_lazy_steps(0)
+
     def _step_lazy(self):
         """step() without a host wait at its end (see lazy_metrics): phase
         times come from HIP events, the records are read when the metrics are."""
         self.num_iterations += 1
-        # at most one iteration ahead of the device
-        while len(self._lazy_done) >= 2:
-            self._lazy_done.pop(0).synchronize()
+        self._retire_lazy_steps(2)
         main = torch.cuda.current_stream()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(main)
@@ -361,7 +382,6 @@ class TemporalCorrelatedAgent(AbstractAgent):
         if self.schedule_lr_policy:
             self.policy_lr_scheduler.step()
         ev[3].record(main)
-        self._lazy_done.append(ev[3])
         steps = self.num_global_steps
         lr_p = self.policy_lr_scheduler.get_last_lr()[0] \
             if self.schedule_lr_policy else self.lr_policy
@@ -379,6 +399,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
                     "num_global_steps": steps, "lr_policy": lr_p,
                     "lr_critic": lr_c}
         result = util.LazyMetrics(resolve)
+        self._lazy_done.append((ev[3], result))
         if self.evaluation_interval and (
                 self.evaluation_interval == 1 or
                 self.num_iterations % self.evaluation_interval == 1):
@@ -555,6 +576,10 @@ class TemporalCorrelatedAgent(AbstractAgent):
             # the next split comes from this step's events once they are done
             # (looked at when the next update starts)
             self._split_probes = self._split_probes[-2:] + [(ev, n1, E)]
+            # every epoch is enqueued: the closure below must not keep the
+            # rollout buffer alive (x / returns / old_values are views of it;
+            # an unread LazyMetrics would pin ~0.25 GB per step at C2)
+            ce.x = ce.returns = ce.old_values = None
 
             def tail():
                 return ce.finish(), policy_loss_dict, \
@@ -751,15 +776,26 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 init_time=init_time, init_pos=init_pos, init_vel=init_vel,
                 pred_pairs=pred_pairs)
 
-        # per-epoch record: 7 loss/norm scalars, 12 KL terms, 3 NaN flags
+        # per-epoch record: 7 loss/norm scalars, 12 KL terms, 3 NaN flags, the
+        # two gradient norms of a balance-check epoch
         E = self.epochs_policy
-        rec_all = torch.zeros(E, 22, dtype=self.dtype, device=self.device)
+        rec_all = torch.zeros(E, 24, dtype=self.dtype, device=self.device)
         rec_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
         surr_gn, tr_gn = [], []
 
+        # the fused objective (one C call) where it applies; the epochs of a
+        # balance-check iteration need the whole epoch in C (DirectEpoch splits
+        # the objective's gradient), else they run op by op
+        use_fused = self.fused_policy_objective and \
+            objective.supported(self, dataset)
+        use_direct = use_fused and self.direct_policy_epoch and \
+            not self.graph_policy_update and \
+            objective.DirectEpoch.supported(self, states)
+        if self.check_policy_balance and not (use_direct and
+                                              not self.dist.active):
+            use_fused = use_direct = False
         fused_ctx = None
-        if self.fused_policy_objective and not self.check_policy_balance \
-                and objective.supported(self, dataset):
+        if use_fused:
             init = self.projection.initial_entropy
             sched = self.projection.entropy_schedule_type
             beta = None if sched in (None, False) else \
@@ -769,17 +805,17 @@ class TemporalCorrelatedAgent(AbstractAgent):
             fused_ctx = objective.Context(self, dataset, times, beta)
 
         direct = None
-        if fused_ctx is not None and self.direct_policy_epoch and \
-                not self.graph_policy_update and \
-                objective.DirectEpoch.supported(self, states):
+        if use_direct:
             direct = objective.DirectEpoch(self, states, fused_ctx)
         epoch_no = [0]
+        balance_direct = direct is not None and self.check_policy_balance
 
         def epoch_fused():
             if direct is not None:
                 # no autograd, no device-side record index: the epoch number
                 # is known on the host (NaN flags are derived on the host too)
-                direct.run(rec_all[epoch_no[0], :19])
+                row = rec_all[epoch_no[0]]
+                direct.run(row[:19], balance=balance_direct, bal=row[22:24])
                 epoch_no[0] += 1
                 return
             mean_new, L_new = self.policy.policy(states)
@@ -792,7 +828,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
                                          self.clip_grad_norm)
             rec = torch.cat([rec17[:5], torch.stack([g, gc]).to(rec17.dtype),
                              rec17[5:], torch.isnan(rec17[:3]).to(rec17.dtype)])
-            rec_all.index_copy_(0, rec_idx, rec[None])
+            rec_all[:, :22].index_copy_(0, rec_idx, rec[None])
             rec_idx.add_(1)
 
         def epoch():
@@ -840,7 +876,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
                                                   entropy.detach(), g, gc]),
                              kl_row.to(losses.dtype),
                              torch.isnan(losses).to(losses.dtype)])
-            rec_all.index_copy_(0, rec_idx, rec[None])
+            rec_all[:, :22].index_copy_(0, rec_idx, rec[None])
             rec_idx.add_(1)
 
         util.run_time_test(lock=True, key="projection", sync=False)
@@ -888,8 +924,11 @@ class TemporalCorrelatedAgent(AbstractAgent):
         out["projection_time"] = projection_time
         out["policy_epochs_device_time"] = ev_a.elapsed_time(ev_b) * 1e-3
         if self.check_policy_balance:
-            sg = torch.stack(surr_gn).cpu().numpy()
-            tg = torch.stack(tr_gn).cpu().numpy()
+            if balance_direct:
+                sg, tg = rec_host[:, 22], rec_host[:, 23]
+            else:
+                sg = torch.stack(surr_gn).cpu().numpy()
+                tg = torch.stack(tr_gn).cpu().numpy()
             out.update(util.generate_stats(sg, "surrogate_grad_norm"))
             out.update(util.generate_stats(tg, "trust_region_grad_norm"))
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -1062,9 +1101,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         (util.LazyMetrics; TemporalCorrelatedAgent.lazy_metrics): the row-kernel
         updates of both networks side by side, nothing waited for."""
         self.num_iterations += 1
-        done = self.__dict__.setdefault("_lazy_done", [])
-        while len(done) >= 2:
-            done.pop(0).synchronize()
+        self._retire_lazy_steps(2)
+        done = self._lazy_done
         main = torch.cuda.current_stream()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record(main)
@@ -1086,7 +1124,6 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         finish_policy = self.update_policy(dataset, defer=True)
         main.wait_stream(side)
         ev[2].record(main)
-        done.append(ev[2])
         steps = self.num_global_steps
 
         def resolve():
@@ -1097,6 +1134,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                     "num_global_steps": steps, "lr_policy": self.lr_policy,
                     "lr_critic": self.lr_critic}
         result = util.LazyMetrics(resolve)
+        done.append((ev[2], result))
         if self.evaluation_interval and (
                 self.evaluation_interval == 1 or
                 self.num_iterations % self.evaluation_interval == 1):

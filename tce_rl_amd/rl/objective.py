@@ -220,85 +220,102 @@ def policy_objective(mean_new, L_new, context):
 
 
 class DirectEpoch:
-    """One policy epoch of the fused objective WITHOUT autograd: forward of the
-    mean net (two 128-wide hidden layers in the fused MFMA kernel + the output
-    GEMM) and of the Cholesky head, ``evaluate`` (objective + its gradient),
-    then the parameter gradients written straight into the optimizer's flat
-    gradient buffer -- the output layer's two GEMMs, the hidden layers' fused
-    backward kernel, the Cholesky head's backward -- and the record row.  Same
-    arithmetic as the autograd path (``policy_objective`` + ``backward()``; the
-    parity tests run both), ~30 launches per epoch instead of ~56: the policy
-    epochs are bound by launch overhead.
+    """One policy epoch of the fused objective WITHOUT autograd, ONE C call
+    (tce_policy_epoch2_*): forward of the mean net and of the Cholesky head,
+    the objective and its gradient, then the parameter gradients written
+    straight into the optimizer's flat gradient buffer, the Cholesky head's
+    backward, flat Adam and the record row.  Same arithmetic as the autograd
+    path (``policy_objective`` + ``backward()``; the parity tests run both),
+    ~26 launches per epoch instead of ~56.
 
-    Applies to the configuration the fused objective itself applies to plus:
-    float32 mean net D_in <= 40 -> 128 -> 128 -> K without an output
-    activation, parameters in a ``FlatAdam`` in the order mean net, variance
-    variable."""
+    Mean nets (``kind``): 0 = float32 D_in <= 40 -> 128 -> 128 -> K on the fused
+    MFMA kernels of csrc/mlp.hip + the output layer's row kernel; 1 = the row
+    kernels of csrc/pmlp.hip (float32 / float64, one or two hidden layers:
+    box pushing's float64 128 x 2 net, table tennis's 256 x 1 tanh net).
+    Parameters in a ``FlatAdam`` in the order mean net, variance variable.
+
+    ``run(row, balance=True)``: the epoch of a balance-check iteration
+    (temporal_correlated_agent.py:447-522) -- the gradient norms of the
+    surrogate loss alone and of the trust region loss alone come from ONE
+    evaluation of the objective whose gradient is kept in two parts."""
 
     @staticmethod
-    def supported(agent, states):
-        from .. import critic_ops
+    def kind(agent, states):
+        import os
+        from .. import critic_ops, pmlp_ops
         from ..optim import FlatAdam
         pol, opt = agent.policy, agent.policy_optimizer
         net = pol.mean_net
-        if not isinstance(opt, FlatAdam) or pol.contextual_cov:
-            return False
-        if not (critic_ops.hidden_supported(net, states)
-                and net.act_func_last_type is None and states.dim() == 2):
-            return False
+        if not isinstance(opt, FlatAdam) or pol.contextual_cov or \
+                states.dim() != 2 or net.act_func_last_type is not None or \
+                states.dtype != net.dtype:
+            return None
         params = list(net.parameters()) + [pol.variance_net.variable]
-        return len(params) == len(opt._params) and \
-            all(a is b for a, b in zip(params, opt._params))
+        if len(params) != len(opt._params) or \
+                not all(a is b for a, b in zip(params, opt._params)):
+            return None
+        force = os.environ.get("TCE_POLICY_NET", "")
+        if critic_ops.hidden_supported(net, states) and force != "pmlp":
+            return 0
+        if pmlp_ops.supported(net) and opt.flat_param.data_ptr() % 16 == 0 \
+                and force != "library":
+            return 1
+        return None
+
+    @staticmethod
+    def supported(agent, states):
+        return DirectEpoch.kind(agent, states) is not None
 
     def __init__(self, agent, states, context):
-        from .. import critic_ops
+        from .. import critic_ops, pmlp_ops
         self.agent, self.c = agent, context
         pol = agent.policy
         self.net, self.opt = pol.mean_net, agent.policy_optimizer
+        self.net_kind = DirectEpoch.kind(agent, states)
         self.var = pol.variance_net.variable
         self.x = states if states.is_contiguous() else states.contiguous()
         self.N, self.din = self.x.shape
         self.K, self.min_std = pol.dim_out, float(pol.min_std)
         self.act = critic_ops._ACT[self.net.act_func_hidden_type]
-        dev, lib = self.x.device, _lib.load()
-        ls = self.net.layers
-        self.w = [ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias]
-        self.w3, self.b3 = ls[2].weight, ls[2].bias
-        # views of the flat gradient: hidden layers | W3 | b3 | variance vector
-        P = lib.tce_mlp_critic_num_params(self.din)
+        dev, dt, lib = self.x.device, self.x.dtype, _lib.load()
+        self.sfx = sfx(dt)
+        hl = list(self.net.hidden_layers)
+        self.H, self.NL = hl[0], len(hl)
         flat = self.opt.flat_grad
-        o3 = 128 * self.din + 128 + 128 * 128 + 128
-        o4 = o3 + self.K * 128
-        o5 = o4 + self.K
-        nvec = self.var.numel()
-        assert o5 + nvec == flat.numel() and o3 + 129 <= flat.numel()
-        self.P = P
-        self.g_w3 = flat[o3:o4].view(self.K, 128)
-        self.g_b3 = flat[o4:o5]
-        self.g_var = flat[o5:o5 + nvec]
-        self.nvec = nvec
-        self.partials = torch.empty(min(lib.tce_mlp_critic_grid(),
-                                        (self.N + 63) // 64), P + 2,
-                                    dtype=torch.float32, device=dev)
-        self.stats = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.ol_ws = torch.empty(lib.tce_out_layer_grad_ws_len(self.N, self.K,
-                                                               128),
-                                 dtype=torch.float32, device=dev)
-        # workspace of tce_policy_epoch_f32: h2 | gh | mean | g_mean | L | g_L |
-        # sur2 [4] | out16 [16] | stats
-        self.ws = torch.zeros(lib.tce_policy_epoch_ws_len(self.N, self.K),
-                              dtype=torch.float32, device=dev)
+        self.nvec = self.var.numel()
+        nparam = flat.numel()
+        if self.net_kind == 0:
+            P = lib.tce_mlp_critic_num_params(self.din)
+            assert nparam == 128 * self.din + 128 + 128 * 128 + 128 + \
+                self.K * 128 + self.K + self.nvec
+            self.partials = torch.empty(min(lib.tce_mlp_critic_grid(),
+                                            (self.N + 63) // 64), P + 2,
+                                        dtype=dt, device=dev)
+            self.ol_ws = torch.empty(
+                lib.tce_out_layer_grad_ws_len(self.N, self.K, 128), dtype=dt,
+                device=dev)
+        else:
+            P = lib.tce_pmlp_num_params(self.din, self.H, self.NL, self.K)
+            assert nparam == P + self.nvec
+            self.partials = torch.empty(lib.tce_pmlp_max_slabs() * P, dtype=dt,
+                                        device=dev)
+            self.ol_ws = None
+        # workspace of tce_policy_epoch2_*: h2 | h1 (gh) | mean | g_mean | L |
+        # g_L | - | sur2 [4] | out16 [16] | stats [12] | a parameter gradient
+        self.ws = torch.zeros(lib.tce_policy_epoch2_ws_len(self.N, self.K, self.H,
+                                                           nparam),
+                              dtype=dt, device=dev)
         up4 = lambda n: (n + 3) // 4 * 4
-        o = 2 * up4(self.N * 128) + 2 * up4(self.N * self.K) + \
-            2 * up4(self.K * self.K)
+        o = 2 * up4(self.N * self.H) + 2 * up4(self.N * self.K) + \
+            3 * up4(self.K * self.K)
         self.sur, self.out16 = self.ws[o:o + 2], self.ws[o + 4:o + 20]
 
-    def run(self, rec_row):
+    def run(self, rec_row, balance=False, bal=None):
         """One epoch; rec_row [19] receives {surrogate, entropy loss, trust
-        region loss, total, entropy, |g|, |g| clipped, 12 KL means}.  ONE C
-        call (tce_policy_epoch_f32: ~26 launches); a sharded run stops it in
-        front of the optimizer step, all-reduces the flat gradient, then steps
-        and records."""
+        region loss, total, entropy, |g|, |g| clipped, 12 KL means}; balance:
+        bal [2] receives the gradient norms of the surrogate / trust region
+        loss alone.  A sharded run stops the call in front of the optimizer
+        step, all-reduces the flat gradient, then steps and records."""
         c, ag, opt = self.c, self.agent, self.opt
         x, N, K = self.x, self.N, self.K
         mp = c.mp
@@ -310,25 +327,27 @@ class DirectEpoch:
         assert rec_row.is_contiguous() and rec_row.numel() == 19
         g = opt.param_groups[0]
         do_adam = not ag.dist.active
+        assert do_adam or not balance
         if do_adam:
             opt.host_step += 1
             opt._opt_called = True            # for LinearLR's order check
-        call("tce_policy_epoch_f32", ptr(x), x.stride(0), N, self.din,
-             self.act, self.nvec, self.min_std, ptr(opt.flat_param),
-             ptr(opt.flat_grad), ptr(c.mean_old), ptr(c.L_old), ptr(c.traj),
-             ptr(c.lp_old), ptr(c.adv), ptr(c.pairs), *mp.c_args(),
-             ptr(c.times), flags, c.general | 2 | 4, ptr(c.t0), ptr(c.y0),
-             ptr(c.v0), mp.cov_reg, ptr(B), ptr(flag), ptr(c.pl_work),
-             float(c.eps_mean), float(c.eps_cov), ptr(c.beta), c.entropy_eq,
-             ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov, c.ent_coef,
-             ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(self.ws),
+        call("tce_policy_epoch2_" + self.sfx, ptr(x), x.stride(0), N, self.din,
+             self.H, self.NL, self.net_kind, self.act, self.nvec, self.min_std,
+             ptr(opt.flat_param), ptr(opt.flat_grad), ptr(c.mean_old),
+             ptr(c.L_old), ptr(c.traj), ptr(c.lp_old), ptr(c.adv), ptr(c.pairs),
+             *mp.c_args(), ptr(c.times), flags, c.general | 2 | 4, ptr(c.t0),
+             ptr(c.y0), ptr(c.v0), mp.cov_reg, ptr(B), ptr(flag),
+             ptr(c.pl_work), float(c.eps_mean), float(c.eps_cov), ptr(c.beta),
+             c.entropy_eq, ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov,
+             c.ent_coef, ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(self.ws),
              ptr(self.partials), ptr(self.ol_ws), T, P, mp.num_dof, K,
              ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
              float(g["weight_decay"]), float(ag.clip_grad_norm), 1.0,
-             int(do_adam), ptr(rec_row), stream())
+             int(do_adam), int(balance), ptr(rec_row), ptr(bal), stream())
         if not do_adam:
             ag._optimizer_step(opt, ag.policy_net_params, ag.clip_grad_norm,
                                want_norms=False)
-            call("tce_policy_record_f32", ptr(self.sur), ptr(self.out16),
-                 ptr(opt.dev_state) + 4, c.ent_coef, ptr(rec_row), stream())
+            call("tce_policy_record_" + self.sfx, ptr(self.sur), ptr(self.out16),
+                 ptr(opt.dev_state) + opt.dev_state.element_size(),
+                 c.ent_coef, ptr(rec_row), stream())

@@ -252,17 +252,23 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
             # from pinned memory, without waiting for the stream: an upload from
             # pageable memory blocks the host until everything enqueued before
             # it has run (the previous iteration's critic epochs, see
-            # agent.lazy_metrics).  Three buffers in turn: the host is at most
-            # one iteration ahead of the device.
+            # agent.lazy_metrics).  A ring of buffers, each with the event of its
+            # last upload: a buffer is rewritten only after that copy has run,
+            # however far the host is ahead (the lazy step keeps it within two
+            # iterations, so the wait is normally over long before).
             ring = self.__dict__.setdefault("_pairs_pinned", [])
-            if len(ring) < 3 or ring[0].shape != pairs.shape:
-                ring[:] = [torch.empty(pairs.shape, dtype=torch.long).pin_memory()
-                           for _ in range(3)]
+            if len(ring) < 3 or ring[0][0].shape != pairs.shape:
+                ring[:] = [[torch.empty(pairs.shape, dtype=torch.long).pin_memory(),
+                            None] for _ in range(3)]
                 self._pairs_turn = 0
-            buf = ring[self._pairs_turn % 3]
+            slot = ring[self._pairs_turn % len(ring)]
             self._pairs_turn += 1
-            buf.copy_(pairs)
-            self.pred_pairs = buf.to(self.device, non_blocking=True)
+            if slot[1] is not None:
+                slot[1].synchronize()
+            slot[0].copy_(pairs)
+            self.pred_pairs = slot[0].to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
         else:
             self.pred_pairs = pairs.to(self.device)
         # env shards of one job use the SAME segments: rank 0's draw

@@ -3,6 +3,7 @@
 Integer / RNG logic (pair selection) is reproduced exactly on the host; tensor
 math goes through ``tce_rl_amd.ops`` (HIP kernels).
 """
+import collections.abc
 import random
 import time
 
@@ -167,42 +168,76 @@ def device_stats_async(tensors, name):
     return finish
 
 
-class LazyMetrics(dict):
+class LazyMetrics(collections.abc.MutableMapping):
     """The metrics of an iteration whose device work may still be running: a
-    dict that fills itself (one blocking read of the device-side records) on
+    mapping that fills itself (one blocking read of the device-side records) on
     first access.  `agent.step()` returns it so that the host can enqueue the
     next rollout behind the critic epochs instead of waiting for them and then
-    leaving the GPU idle while it prepares ~50 small launches."""
+    leaving the GPU idle while it prepares ~50 small launches.
+
+    Deliberately NOT a dict subclass: C-level consumers of a dict (the json
+    encoder, ``dict(**m)`` fast paths) look at the underlying storage and would
+    see an empty dict while the read is pending.  ``resolve()`` returns the
+    plain dict (what the reference's ``step()`` returns); ``json.dumps`` of the
+    mapping itself raises TypeError instead of printing "{}"; pickling resolves
+    and stores the plain dict.  The read also runs the checks the reference
+    runs inside the update (NaN losses): if the resolver raises, it stays in
+    place and every later access raises again."""
 
     def __init__(self, resolver):
-        super().__init__()
         self._resolver = resolver
+        self._data = {}
+        self._extra = {}                # set while pending: on top of the read values
 
     def resolve(self):
-        r, self._resolver = self._resolver, None
+        r = self._resolver
         if r is not None:
-            dict.update(self, r())
-        return self
+            data = dict(r())            # may raise: then the resolver is kept
+            data.update(self._extra)
+            self._data, self._extra, self._resolver = data, {}, None
+        return self._data
 
     @property
     def pending(self):
         return self._resolver is not None
 
+    def __getitem__(self, k):
+        return self.resolve()[k]
 
-def _lazy_method(name):
-    base = getattr(dict, name)
+    def __setitem__(self, k, v):
+        (self._extra if self.pending else self._data)[k] = v
 
-    def f(self, *a, **k):
-        self.resolve()
-        return base(self, *a, **k)
-    f.__name__ = name
-    return f
+    def __delitem__(self, k):
+        del self.resolve()[k]
 
+    def __iter__(self):
+        return iter(self.resolve())
 
-for _n in ("__getitem__", "__contains__", "__iter__", "__len__", "__repr__", "__eq__",
-           "__ne__", "get", "keys", "items", "values", "copy", "update", "pop",
-           "setdefault", "__setitem__", "__delitem__", "__or__", "__ror__"):
-    setattr(LazyMetrics, _n, _lazy_method(_n))
+    def __len__(self):
+        return len(self.resolve())
+
+    def __contains__(self, k):
+        return k in self.resolve()
+
+    def __repr__(self):
+        return repr(self.resolve())
+
+    def __eq__(self, other):
+        if isinstance(other, LazyMetrics):
+            other = other.resolve()
+        return self.resolve() == other
+
+    def __or__(self, other):
+        return {**self.resolve(), **other}
+
+    def __ror__(self, other):
+        return {**other, **self.resolve()}
+
+    def copy(self):
+        return dict(self.resolve())
+
+    def __reduce__(self):
+        return (dict, (self.resolve(),))
 
 
 def rewrite_dict(d, prefix):
