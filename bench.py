@@ -42,6 +42,33 @@ def build_agent(num_env, seed):
     return exp.agent, cfg
 
 
+def time_balance_iteration(agent, sync):
+    """Wall time (ms, synchronised on both sides) of ONE iteration with the
+    policy balance check (num_iterations % balance_check == 1: every policy
+    epoch also reports the gradient norms of the surrogate and of the trust
+    region loss alone, mprl/rl/agent/temporal_correlated_agent.py:447-522).
+    The reference's YAMLs set balance_check 25, so one iteration in 25 is of
+    this kind; the timed window of the default command (iterations 6 - 25)
+    holds none.  The check is triggered for the next iteration by a temporary
+    balance_check = num_iterations ((n + 1) % n == 1)."""
+    keep = agent.balance_check
+    out = []
+    for _ in range(2):
+        agent.balance_check = agent.num_iterations
+        assert (agent.num_iterations + 1) % agent.balance_check == 1
+        sync()
+        t = time.perf_counter()
+        res = agent.step()
+        sync()
+        out.append((time.perf_counter() - t) * 1e3)
+        assert "balance_ratio" in res, "not a balance-check iteration"
+        agent.balance_check = None
+        agent.step()                       # an ordinary iteration in between
+    agent.balance_check = keep
+    sync()
+    return min(out)
+
+
 def kernel_time_us(fn, launches=20):
     """Average device time of `fn`'s kernel(s) with HIP events on the stream
     they are launched on.  The launches are queued behind a busy-wait kernel so
@@ -372,6 +399,18 @@ OTHER_CONFIGS = [
         dtype="float32",
         workload="BASELINE.json configs[4] as worded (ProDMP 8 basis, K 63), "
                  "otherwise as above")),
+    # the multi-GPU configs at their FULL size on this one GPU (they fit: 288 GB):
+    # the denominators of the strong-scaling curves (N GPUs x N-th of the envs)
+    ("C4_bbrl_full_16384", dict(
+        kind="bbrl", num_env=16384, epochs=100, dtype="float32",
+        workload="BASELINE.json configs[3] at its full size on ONE GPU: BBRL, "
+                 "16384 envs, otherwise as C4_bbrl_shard")),
+    ("C5_table_tennis_nb3_full_32768", dict(
+        kind="tce", env="table_tennis", num_env=32768, num_basis=3, epochs=50,
+        dtype="float32", steps=2, warmup=2,
+        workload="BASELINE.json configs[4] at its full size on ONE GPU: TCE, "
+                 "32768 envs x T 350 (11.5 M critic rows per epoch), "
+                 "otherwise as C5_table_tennis_nb3_shard")),
 ]
 
 
@@ -393,6 +432,11 @@ def build_config_agent(spec, seed=0):
 
 
 def run_config(name, spec, steps, warmup):
+    steps, warmup = spec.get("steps", steps), spec.get("warmup", warmup)
+    return _run_config(name, spec, steps, warmup)
+
+
+def _run_config(name, spec, steps, warmup):
     """One entry of the `configs` block: W untimed + K timed agent.step()s of
     one BASELINE config on this GPU, synchronised wall time, plus the roofline
     of its dominant kernel from the device time (HIP events on the critic's
@@ -416,12 +460,20 @@ def run_config(name, spec, steps, warmup):
         pol += res.get("update_policy_time", 0.0)
         samp += res.get("sampling_time", 0.0)
     E = spec["epochs"]
+    bal_ms = None
+    if spec["kind"] == "tce" and isinstance(agent.balance_check, int):
+        bal_ms = time_balance_iteration(agent, torch.cuda.synchronize)
     out = {"workload": spec["workload"], "num_env": N, "num_times": T,
            "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],
            "steps": steps, "warmup": warmup,
            "ms_per_step": round(el / steps * 1e3, 2),
            "env_steps_per_sec": round(N * T * steps / el, 1),
            "sampling_ms": round(samp / steps * 1e3, 2)}
+    if bal_ms is not None:
+        bc = agent.balance_check
+        out["balance_check_iteration_ms"] = round(bal_ms, 2)
+        out["ms_per_step_amortised"] = round(
+            ((bc - 1) * out["ms_per_step"] + bal_ms) / bc, 2)
     net = agent.critic.net
     hs = [l.weight.shape[0] for l in net.layers[:-1]]
     din = net.dim_in
@@ -469,13 +521,25 @@ def run_config(name, spec, steps, warmup):
     return out
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline():
     """The CPU oracle (torch-CPU restatement of the reference path, kind
-    'port') on a bounded sample: 128 envs, full 50 + 50 epochs; one untimed
-    warm-up step, then the median of three timed steps."""
+    'port') on a bounded sample: 64 envs (the reference's own cluster runs use
+    16 - 38), full 50 + 50 epochs; three untimed warm-up steps, then the median
+    of ten timed steps.  ~20 s of CPU work."""
     from tce_rl_amd.config import tce_config
     from oracle.agent_oracle import OracleTCE      # checker / baseline only
-    n = 128
+    n = 64
     # host cores this process may use (the GPU box gives 16 per GPU); torch
     # with more threads than cores thrashes on the small ops
     try:
@@ -489,18 +553,21 @@ def cpu_baseline():
     cfg = tce_config("metaworld", num_env=n, num_basis=NUM_BASIS,
                      epochs=EPOCHS, device="cpu")
     o = OracleTCE(cfg["params"], n)
-    steps = o.step()                                # warm-up
-    ts = []
     for _ in range(3):
+        steps = o.step()                            # warm-up
+    ts = []
+    for _ in range(10):
         t = time.perf_counter()
         steps = o.step()
         ts.append(time.perf_counter() - t)
-    dt = sorted(ts)[1]
+    dt = sorted(ts)[len(ts) // 2]
     return {"value": round(steps / dt, 1), "unit": "env-steps/s",
-            "cores": threads, "kind": "port",
+            "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "visible_cores": avail,
             "sample": "torch-CPU oracle agent.step() at %d envs (T 500, 50 "
-                      "critic + 50 policy epochs): 1 warm-up step, median of "
-                      "3 timed steps = %.2f s" % (n, dt)}
+                      "critic + 50 policy epochs): 3 warm-up steps, median of "
+                      "10 timed steps = %.2f s (min %.2f, max %.2f)"
+                      % (n, dt, min(ts), max(ts))}
 
 
 def _kill_tree(proc):
@@ -703,6 +770,11 @@ def main():
         crit_time += res["update_critic_time"]      # device time (HIP events)
     coll = dict(tdist.STATS)
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
+    # one iteration in `balance_check` (25) carries the policy balance check:
+    # timed by itself, outside the K steps
+    bal_ms = None
+    if isinstance(agent.balance_check, int):
+        bal_ms = over_ranks([time_balance_iteration(agent, barrier)])[0][0]
 
     # the same K steps (after W warm-up steps) with the critic epochs on the
     # split-f16 kernel (agent option critic_arith="f16x2"), reported beside
@@ -742,6 +814,14 @@ def main():
             "iterations_per_sec": round(args.steps / elapsed, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            # the K timed steps are ordinary iterations; the reference runs its
+            # balance check in 1 of `balance_check` iterations (25 in every
+            # shipped YAML): that iteration alone, and the average over a cycle
+            "balance_check_iteration_ms": None if bal_ms is None
+            else round(bal_ms, 2),
+            "ms_per_step_amortised": None if bal_ms is None else round(
+                ((agent.balance_check - 1) * elapsed / args.steps * 1e3 +
+                 bal_ms) / agent.balance_check, 2),
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -183,6 +183,11 @@ int tce_pair_logprob_bwd_f64(
  * default).  The pair log-prob fast path trades latency for wave-instructions
  * only when most of the chip is free; results do not depend on it. */
 int tce_set_cu_budget(int compute_units);
+/* on = 0: the shared-covariance pair kernels take their general form (runtime
+ * dof / basis count, per-env vectors in LDS) for every shape instead of the
+ * register form built for the shipped (dof, num_basis + 1) combinations
+ * (4, 6), (4, 9), (7, 9), (7, 4); default 1.  For A / B runs and tests. */
+int tce_pair_env_static(int on);
 /* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
  * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M);

@@ -17,6 +17,7 @@
 //     dmean += H_p^T dmu,   dL += H_p^T (G M)       (lower triangle)
 // Small-matrix VALU/LDS work, not HBM-bound: L_n (K^2) is read once per env.
 #include "prodmp.h"
+#include "mfma16.h"
 
 namespace {
 
@@ -274,6 +275,7 @@ inline int64_t tce_sum_dim0_slices_impl(int64_t N, int64_t M) {
 }
 
 struct PFShape { int K, R, P, nbg, dof; };
+int g_pair_env_static = 1;  // tce_pair_env_static(0): the general kernel for every shape (A / B, tests)
 int g_cu_budget = 0;       // tce_set_cu_budget: compute units the caller expects to be free (0: all)
 inline int pl_cu_count() {
   static int n = 0;
@@ -370,10 +372,20 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
 }
 
 // Block = EB (<= 64) envs x NW waves (blockDim / 64, <= 16); wave q takes the
-// pairs q, q + NW, ...; lane
-// = env.  The per-pair reduction S_p over the block's envs runs inside the
-// wave (alpha goes through a wave-private LDS slab, no block barrier), the
-// pair-sum of dmean over the waves through LDS at the end.
+// pairs q, q + NW, ...; lane = env.  What is the same for every env of a pair
+// -- the two basis rows, the init-condition coefficients, the inverse Cholesky
+// factor of the pair covariance (pair_prep_kernel's record) -- is read with
+// SCALAR loads straight from that record (the pair index is made wave-uniform):
+// the FMAs take it as their scalar operand and no LDS instruction is issued
+// for it (round 3 kept the record in LDS: 460 of the ~1600 LDS operations per
+// env and pair were broadcast reads of it).  The per-pair reduction
+// S_p = sum_env g alpha alpha^T over the block's envs is a [R x EB] x [EB x R]
+// product on the exact 16x16x4 matrix instruction: alpha goes through a
+// wave-private LDS slab (pitch 17, columns R..15 zero), EB / 4 steps of
+// {2 LDS reads, 1 MFMA} per pair (round 3: 3 EB LDS reads and 2 EB FMAs per
+// lane, four times per pair -- half of the backward kernel).  The pair-sum of
+// dmean over the waves goes through LDS at the end.
+constexpr int PE_RP = 17;               // pitch of the alpha slab
 template <typename real, bool BWD>
 __global__ __launch_bounds__(1024) void pair_env_kernel(
     const real* __restrict__ traj, const real* __restrict__ mean,
@@ -386,45 +398,38 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int K = s.K, R = s.R, P = s.P, nbg = s.nbg, dof = s.dof;
-  const int KP = pl_pitch(K), RP = R + 1;
+  const int KP = pl_pitch(K);
   const int wsp = pf_ws_pair(s);
-  real* Ws = smem;                               // [P][2 nbg + 4 + R*R + 1] compact
-  const int cw = 2 * nbg + 4 + R * R + 1;
-  real* ms = Ws + P * cw;                        // [EB][KP]      mean_n
+  real* ms = smem;                               // [EB][KP]      mean_n
   const int NW = blockDim.x >> 6, NT = blockDim.x;
   real* gmp = ms + EB * KP;                      // [NW][EB][KP]  grad mean per wave (BWD)
-  real* Ab = gmp + (BWD ? NW * EB * KP : 0);     // [NW][EB][RP]  alpha of the wave's current pair
-  real* gs = Ab + (BWD ? NW * EB * RP : 0);      // [NW][EB]
+  real* Ab = gmp + (BWD ? NW * EB * KP : 0);     // [NW][EB][PE_RP] alpha of the wave's current pair
+  real* gs = Ab + (BWD ? NW * EB * PE_RP : 0);   // [NW][EB]
   const int tid = threadIdx.x, q = tid >> 6, e = tid & 63;
   const int64_t n0 = (int64_t)blockIdx.x * EB;
   const int64_t n = n0 + e;
   const bool act = e < EB;
   const bool ok = act && n < N;
   const int64_t nc = n < N ? n : N - 1;
-  for (int i = tid; i < P * cw; i += NT) {
-    const int p = i / cw, j = i - p * cw;
-    const real* w = ws + (int64_t)p * wsp;
-    real v;
-    if (j < 2 * nbg + 4) v = w[j];
-    else if (j < 2 * nbg + 4 + R * R) v = w[2 * nbg + 4 + R * K + (j - 2 * nbg - 4)];       // Linv
-    else v = w[2 * nbg + 4 + R * K + 2 * R * R];                                            // logdet
-    Ws[i] = v;
-  }
   for (int i = tid; i < EB * K; i += NT) {
     const int en = i / K, k = i - en * K;
     const int64_t nn = n0 + en < N ? n0 + en : N - 1;
     ms[en * KP + k] = mean[nn * K + k];
   }
-  if (BWD)
+  if (BWD) {
     for (int i = tid; i < NW * EB * KP; i += NT) gmp[i] = 0;
+    for (int i = tid; i < NW * EB * PE_RP; i += NT) Ab[i] = 0;
+  }
   __syncthreads();
   real* gmq = gmp + q * EB * KP + e * KP;
-  real* Abq = Ab + q * EB * RP;
+  real* Abq = Ab + q * EB * PE_RP;
   real* gsq = gs + q * EB;
-  for (int p = q; p < P; p += NW) {
-    const real* Hs = Ws + p * cw;
-    const real* cs = Hs + 2 * nbg;
-    const real* Li = cs + 4;
+  const int qu = __builtin_amdgcn_readfirstlane(q);
+  for (int p = qu; p < P; p += NW) {
+    const real* __restrict__ Hs = ws + (int64_t)p * wsp;      // scalar loads from here on
+    const real* __restrict__ cs = Hs + 2 * nbg;
+    const real* __restrict__ Li = cs + 4 + R * K;
+    real g = 0;
     if (act) {
       real d[PL_MAXR], z[PL_MAXR];
       const int64_t ta = pairs[2 * p], tb = pairs[2 * p + 1];
@@ -454,10 +459,10 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
         }
       }
       if (!BWD) {
-        if (ok) logp[n * P + p] = real(-0.5) * quad - Hs[cw - 1] -
+        if (ok) logp[n * P + p] = real(-0.5) * quad - Li[2 * R * R] -
                                   real(0.5) * (real)R * real(1.8378770664093453);
       } else {
-        const real g = ok ? gout[n * P + p] : real(0);
+        g = ok ? gout[n * P + p] : real(0);
 #pragma unroll
         for (int r = 0; r < PL_MAXR; ++r) {
           if (r < R) {
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
 #pragma unroll
             for (int m = 0; m < PL_MAXR; ++m)
               if (m >= r && m < R) al += Li[m * R + r] * z[m];
-            Abq[e * RP + r] = al;
+            Abq[e * PE_RP + r] = al;
             const int dd = r >> 1, j = r & 1;
             const real* h = Hs + j * nbg;
             const real ga = g * al;
@@ -480,17 +485,22 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      real* out = spart + ((int64_t)blockIdx.x * P + p) * (R * R + 1);
-      for (int i = e; i < R * R + 1; i += 64) {
-        real acc = 0;
-        if (i < R * R) {
-          const int r = i / R, c = i - r * R;
-          for (int m = 0; m < EB; ++m) acc += gsq[m] * Abq[m * RP + r] * Abq[m * RP + c];
-        } else {
-          for (int m = 0; m < EB; ++m) acc += gsq[m];
-        }
-        out[i] = acc;
+      // S[r][c] = sum_env g alpha_r alpha_c: A[m = r][k = env] = g alpha, B[k = env][n = c] = alpha
+      typename Mfma16<real>::acc S = {0, 0, 0, 0};
+      const int x = e & 15, kq = e >> 4;
+      for (int ks = 0; ks < EB / 4; ++ks) {
+        const int en = 4 * ks + kq;
+        const real b = Abq[en * PE_RP + x];
+        S = mfma16(b * gsq[en], b, S);
       }
+      const real sg = sizeof(real) == 8 ? (real)wave_sum_f64((double)g) : (real)wave_sum(g);
+      real* out = spart + ((int64_t)blockIdx.x * P + p) * (R * R + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = mfma16_row<real>(kq, i);
+        if (r < R && x < R) out[r * R + x] = S[i];
+      }
+      if (e == 0) out[R * R] = sg;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -508,6 +518,160 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
       }
     }
   }
+}
+
+// The same kernel for the (dof, num_basis + 1) combinations the shipped configs
+// use, with every per-env vector in REGISTERS: the mean parameters of the lane's
+// env (K values), and -- backward -- its accumulated mean gradient.  In the
+// general kernel above both live in LDS and the gradient is a chain of
+// R (nbg) dependent LDS read-modify-writes per pair (the compiler cannot tell
+// the runtime-indexed addresses apart): 126 round trips per env and pair at
+// dof 7 / 9 basis rows, which is what its 0.57 ms per K 63 epoch were.  Here a
+// pair costs ~460 register FMAs, 14 gathered loads and the EB / 4 MFMA steps of
+// the S_p reduction.
+template <typename real, bool BWD, int DOF, int NBG>
+__global__ __launch_bounds__(256) void pair_env_static_kernel(
+    const real* __restrict__ traj, const real* __restrict__ mean,
+    const int64_t* __restrict__ pairs, const int* __restrict__ nonuniform,
+    const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
+    real* __restrict__ logp, const real* __restrict__ gout, real* __restrict__ gmean,
+    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, int P, int EB) {
+  if (*nonuniform != 0) return;
+  constexpr int R = 2 * DOF, K = DOF * NBG, KP = (K + 1) | 1;
+  constexpr int wsp = 2 * NBG + 4 + R * K + 2 * R * R + 1;          // pf_ws_pair
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  const int NW = blockDim.x >> 6, NT = blockDim.x;
+  real* gmp = smem;                              // [NW][EB][KP]: mean rows first, per-wave gradients last (BWD)
+  real* Ab = gmp + (BWD ? NW : 1) * EB * KP;     // [NW][EB][PE_RP] alpha of the wave's current pair (BWD)
+  real* gs = Ab + (BWD ? NW * EB * PE_RP : 0);   // [NW][EB]
+  const int tid = threadIdx.x, q = tid >> 6, e = tid & 63;
+  const int64_t n0 = (int64_t)blockIdx.x * EB;
+  const int64_t n = n0 + e;
+  const bool act = e < EB;
+  const bool ok = act && n < N;
+  const int64_t nc = n < N ? n : N - 1;
+  // the block's mean rows through LDS (coalesced), then each lane's own row
+  for (int i = tid; i < EB * K; i += NT) {
+    const int en = i / K, k = i - en * K;
+    const int64_t nn = n0 + en < N ? n0 + en : N - 1;
+    gmp[en * KP + k] = mean[nn * K + k];
+  }
+  if (BWD)
+    for (int i = tid; i < NW * EB * PE_RP; i += NT) Ab[i] = 0;
+  __syncthreads();
+  real mn[K], gm[BWD ? K : 1];
+#pragma unroll
+  for (int k = 0; k < K; ++k) mn[k] = act ? gmp[e * KP + k] : real(0);
+  if (BWD) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) gm[k] = 0;
+  }
+  real yi[DOF], vi[DOF];
+#pragma unroll
+  for (int d = 0; d < DOF; ++d) { yi[d] = y0[nc * DOF + d]; vi[d] = v0[nc * DOF + d]; }
+  __syncthreads();                                 // gmp is reused for the gradients
+  real* Abq = Ab + q * EB * PE_RP;
+  real* gsq = gs + q * EB;
+  const int qu = __builtin_amdgcn_readfirstlane(q);
+  for (int p = qu; p < P; p += NW) {
+    const real* __restrict__ Hs = ws + (int64_t)p * wsp;      // scalar loads
+    const real* __restrict__ cs = Hs + 2 * NBG;
+    const real* __restrict__ Li = cs + 4 + R * K;
+    const int64_t ta = pairs[2 * p], tb = pairs[2 * p + 1];
+    real d[R], z[R];
+#pragma unroll
+    for (int dd = 0; dd < DOF; ++dd)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        real mu = cs[2 * j] * yi[dd] + cs[2 * j + 1] * vi[dd];
+#pragma unroll
+        for (int b = 0; b < NBG; ++b) mu += Hs[j * NBG + b] * mn[dd * NBG + b];
+        const real y = traj[(nc * T + (j ? tb : ta)) * (int64_t)R + dd];
+        d[2 * dd + j] = y - mu;
+      }
+    real quad = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      real acc = 0;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) acc += Li[r * R + c] * d[c];
+      z[r] = acc;
+      quad += acc * acc;
+    }
+    if (!BWD) {
+      if (ok) logp[n * P + p] = real(-0.5) * quad - Li[2 * R * R] -
+                                real(0.5) * (real)R * real(1.8378770664093453);
+    } else {
+      const real g = ok ? gout[n * P + p] : real(0);
+      real ga[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        real al = 0;
+#pragma unroll
+        for (int m = r; m < R; ++m) al += Li[m * R + r] * z[m];
+        if (act) Abq[e * PE_RP + r] = al;
+        ga[r] = g * al;
+      }
+#pragma unroll
+      for (int dd = 0; dd < DOF; ++dd)
+#pragma unroll
+        for (int b = 0; b < NBG; ++b)
+          gm[dd * NBG + b] += Hs[b] * ga[2 * dd] + Hs[NBG + b] * ga[2 * dd + 1];
+      if (act) gsq[e] = g;
+      // wave-private slab: LDS operations of one wave complete in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      typename Mfma16<real>::acc S = {0, 0, 0, 0};
+      const int x = e & 15, kq = e >> 4;
+      for (int ks = 0; ks < EB / 4; ++ks) {
+        const int en = 4 * ks + kq;
+        const real b = Abq[en * PE_RP + x];
+        S = mfma16(b * gsq[en], b, S);
+      }
+      const real sg = sizeof(real) == 8 ? (real)wave_sum_f64((double)g) : (real)wave_sum(g);
+      real* out = spart + ((int64_t)blockIdx.x * P + p) * (R * R + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = mfma16_row<real>(kq, i);
+        if (r < R && x < R) out[r * R + x] = S[i];
+      }
+      if (e == 0) out[R * R] = sg;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (BWD) {
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) gmp[(q * EB + e) * KP + k] = gm[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < EB * K; i += NT) {
+      const int en = i / K, k = i - en * K;
+      if (n0 + en < N) {
+        const real* g0 = gmp + en * KP + k;
+        real acc = 0;
+        for (int w = 0; w < NW; ++w) acc += g0[w * EB * KP];
+        gmean[(n0 + en) * K + k] = acc;
+      }
+    }
+  }
+}
+
+// the (dof, nbg) combinations with a register kernel: Metaworld 5 / 8 basis
+// functions (dof 4), box pushing and table tennis 8 (dof 7), table tennis 3
+template <typename real, bool BWD>
+void* pair_env_static(int dof, int nbg) {
+#define PE_CASE(D, B) if (dof == D && nbg == B) return reinterpret_cast<void*>(pair_env_static_kernel<real, BWD, D, B>)
+  PE_CASE(4, 6);
+  PE_CASE(4, 9);
+  PE_CASE(7, 9);
+  PE_CASE(7, 4);
+#undef PE_CASE
+  return nullptr;
 }
 
 // One block per pair: contribution of pair p to dL, gLp[p] [K,K] (the caller
@@ -622,10 +786,9 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
   // workspace carve (shared L only): fast-path scratch | per-env dL | sum scratch
   PFShape f{K, 2 * dof, P, nbg, dof};
   // envs per block of the fast path: as many as the LDS budget allows
-  const int cw = 2 * nbg + 4 + f.R * f.R + 1;
   auto env_lds_w = [&](int eb, int nw) {
-    return ((size_t)P * cw + (size_t)eb * pl_pitch(K) * (bwd ? 1 + nw : 1) +
-            (bwd ? nw * ((size_t)eb * (f.R + 1) + eb) : 0)) * sizeof(real);
+    return ((size_t)eb * pl_pitch(K) * (bwd ? 1 + nw : 1) +
+            (bwd ? nw * ((size_t)eb * PE_RP + eb) : 0)) * sizeof(real);
   };
   auto env_lds = [&](int eb) { return env_lds_w(eb, 4); };
   // up to 64 envs (one lane each) per block of 4 waves; fewer when the four
@@ -667,13 +830,33 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     }
     const size_t lds = env_lds_w(EB, NWV);
     TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: fast path LDS");
+    void* stat = g_pair_env_static ? (bwd ? pair_env_static<real, true>(dof, nbg)
+                                           : pair_env_static<real, false>(dof, nbg)) : nullptr;
+    if (stat) {
+      typedef void (*kern_t)(const real*, const real*, const int64_t*, const int*, const real*,
+                             const real*, const real*, real*, const real*, real*, real*, int64_t,
+                             int, int, int);
+      kern_t kern = reinterpret_cast<kern_t>(stat);
+      // four waves per block (one per SIMD: a lane holds up to 2 K + 3 R values;
+      // __launch_bounds__(256)).  LDS: the per-wave gradient rows [4][EB][KP]
+      // double as the staging of the mean rows; the forward needs the latter only
+      const int NWS = 4;
+      const size_t lds_s = ((size_t)(bwd ? NWS : 1) * EB * pl_pitch(K) +
+                            (bwd ? NWS * ((size_t)EB * PE_RP + EB) : 0)) * sizeof(real);
+      tce_lds_limit(reinterpret_cast<const void*>(kern), lds_s);
+      hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NWS), lds_s, stream, traj, mean, pairs, flag,
+                         y0, v0, (const real*)wsp, logp, gout, gmean, spart, N, T, P, EB);
+      TCE_LAUNCH_CHECK();
+    }
     if (bwd) {
+      if (!stat) {
       if (lds > 48 * 1024)
         tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, true>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
                          f, EB);
       TCE_LAUNCH_CHECK();
+      }
       real* gLp = spart + (int64_t)nblk * P * (f.R * f.R + 1);   // [P][K][K]
       hipLaunchKernelGGL(pair_final_kernel<real>, dim3(P), dim3(256),
                          (size_t)f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gLp,
@@ -683,7 +866,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
       hipLaunchKernelGGL(sum_dim0_kernel<real>, dim3((unsigned)ceil_div((int64_t)K * K, 64)),
                          dim3(256), 0, stream, gLp, gL, (int64_t)P, (int64_t)K * K,
                          (int64_t)P, (const int*)nullptr, flag);
-    } else {
+    } else if (!stat) {
       if (lds > 48 * 1024)
         tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, false>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(64 * NWV), lds, stream,
@@ -750,6 +933,11 @@ int64_t tce_sum_dim0_slices(int64_t N, int64_t M) { return tce_sum_dim0_slices_i
 
 int tce_set_cu_budget(int compute_units) {
   g_cu_budget = compute_units;
+  return 0;
+}
+
+int tce_pair_env_static(int on) {
+  g_pair_env_static = on ? 1 : 0;
   return 0;
 }
 

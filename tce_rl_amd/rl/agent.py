@@ -327,6 +327,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # slack is 0.4 ms per step, 0.5 no better)
         self._split_margin = float(os.environ.get("TCE_SPLIT_MARGIN", "1"))
         self._critic_split = 0          # 0: all epochs beside the policy
+        self._critic_split_bal = 0      # the same for balance-check iterations
         self._critic_stream = None
         self._policy_stream = None
 
@@ -528,19 +529,29 @@ class TemporalCorrelatedAgent(AbstractAgent):
                            dataset["step_returns"],
                            dataset["step_values"][:, :-1])
         E = ce.E
-        # (lazy steps) the newest earlier step whose events are complete gives the
-        # split; with all epochs beside the policy its critic event is the END of
-        # that step's epochs, which the host may be ahead of -- then an older one
-        for i in range(len(self._split_probes) - 1, -1, -1):
-            pev, pn1, pE = self._split_probes[i]
+        # (lazy steps) the earlier steps whose events are complete give the
+        # split; with all epochs beside the policy the critic event of a step is
+        # the END of its epochs, which the host may be ahead of -- such a probe
+        # stays for the next look.  Iterations with the policy balance check
+        # (1 in `balance_check`) have a longer policy phase and their own split.
+        bal = self._balance_iteration()
+        waiting = []
+        for probe in self._split_probes:
+            pev, pn1, pE, pbal = probe
             if pev[6].query() and pev[5].query():
                 if self.adaptive_critic_split and cstream is None:
                     first_ms = pev[0].elapsed_time(pev[6]) / max(min(pn1, 6), 1)
                     side_ms = pev[2].elapsed_time(pev[5])
-                    self._critic_split = int(min(pE, side_ms / first_ms + self._split_margin))
-                del self._split_probes[:i + 1]
-                break
-        n1 = min(E, self._critic_split) if self._critic_split else E
+                    split = int(min(pE, side_ms / first_ms + self._split_margin))
+                    if pbal:
+                        self._critic_split_bal = split
+                    else:
+                        self._critic_split = split
+            else:
+                waiting.append(probe)
+        self._split_probes = waiting[-3:]
+        cur = self._critic_split_bal if bal else self._critic_split
+        n1 = min(E, cur) if cur else E
         ev[0].record(main)
         cs = main if cstream is None else cstream
         wg = self.critic_workgroups if cstream is None \
@@ -575,7 +586,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
             # nothing is read here: the caller's metrics resolve `tail` later;
             # the next split comes from this step's events once they are done
             # (looked at when the next update starts)
-            self._split_probes = self._split_probes[-2:] + [(ev, n1, E)]
+            self._split_probes = self._split_probes[-2:] + [(ev, n1, E, bal)]
             # every epoch is enqueued: the closure below must not keep the
             # rollout buffer alive (x / returns / old_values are views of it;
             # an unread LazyMetrics would pin ~0.25 GB per step at C2)
@@ -603,10 +614,20 @@ class TemporalCorrelatedAgent(AbstractAgent):
                 t = torch.tensor([split], device=self.device)
                 all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
                 split = int(t.item())
-            self._critic_split = split
+            if bal:
+                self._critic_split_bal = split
+            else:
+                self._critic_split = split
         return critic_loss_dict, policy_loss_dict, \
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
+
+    def _balance_iteration(self):
+        """Is the current iteration one with the policy balance check
+        (temporal_correlated_agent.py:447-451)?"""
+        return isinstance(self.balance_check, int) and \
+            not isinstance(self.balance_check, bool) and \
+            self.num_iterations % self.balance_check == 1
 
     def _objective_streams(self):
         """The fused objective's second stream only where hardware queues are
@@ -761,8 +782,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
             ent0 = self.policy.entropy([mean_old, L_old]).mean()
             self.projection.initial_entropy = self.dist.mean_scalar(ent0)
 
-        self.check_policy_balance = isinstance(self.balance_check, int) and \
-            self.num_iterations % self.balance_check == 1
+        self.check_policy_balance = self._balance_iteration()
 
         def forward():
             mean_new, L_new = self.policy.policy(states)

@@ -198,16 +198,31 @@ def test_pair_logprob_golden_plumbing(ops, golden):
             (err_ours, err_ref)
 
 
-@pytest.mark.parametrize("name", ["metaworld", "box_push", "table_tennis"])
+@pytest.fixture
+def pair_form(request):
+    """"static": the register kernels built for the shipped (dof, basis count)
+    combinations (default); "general": the runtime-shape kernel for every shape."""
+    from tce_rl_amd._lib import call
+    call("tce_pair_env_static", int(request.param == "static"))
+    yield request.param
+    call("tce_pair_env_static", 1)
+
+
+@pytest.mark.parametrize("name", ["metaworld", "metaworld_nb5", "box_push",
+                                  "table_tennis"])
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("uniform_t0", [True, False])
 @pytest.mark.parametrize("N", [6, 300])      # 300: shared-L fast path (N >= 256)
-def test_pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N):
+@pytest.mark.parametrize("pair_form", ["static", "general"], indirect=True)
+def test_pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N,
+                                        pair_form):
     dtype = torch.float64
     mp, oracle = make(name, dtype)
     T = HORIZON[name]
     if N > 6 and not shared:
         pytest.skip("large-N case targets the shared-L fast path")
+    if pair_form == "general" and not (N > 6 and shared and uniform_t0):
+        pytest.skip("the two forms differ on the shared-L fast path only")
     mean, L, eps, t0, y0, v0 = inputs(name, N, dtype, 3, uniform_t0)
     if shared:
         L = L[:1].expand(N, -1, -1).contiguous()
@@ -315,3 +330,36 @@ def test_basis_table_cache_is_invalidated_by_new_or_modified_times():
     d = ops.prodmp_traj(mp, times1, w, t1, y0, v0)
     d_ref = ops.prodmp_traj(mp2, times2, w, t1, y0, v0)
     assert torch.equal(d, d_ref)
+
+
+@pytest.mark.parametrize("name", ["metaworld_nb5", "box_push"])
+def test_pair_kernel_forms_agree_in_float32(ops, name):
+    """fp32, 1000 envs (several blocks, a ragged last one): the register form of
+    the shared-covariance pair kernels against the general form."""
+    from tce_rl_amd._lib import call
+    dtype = torch.float32
+    mp, oracle = make(name, dtype)
+    N, T = 1000, HORIZON[name]
+    mean, L, eps, t0, y0, v0 = inputs(name, N, dtype, 5)
+    tg = ops.times(t0.cuda(), CFGS[name]["dt"], T)
+    Lb = L[0].cuda()
+    w = ops.mvn_rsample(mean.cuda(), ops.expand_shared(Lb, N), eps.cuda())
+    traj = ops.prodmp_traj(mp, tg, w, t0.cuda(), y0.cuda(), v0.cuda())
+    torch.manual_seed(0)
+    pairs = O.get_time_pairs(T, dict(num_select=25, fixed_interval=True)).cuda()
+    wgt = torch.randn(N, pairs.shape[0], device="cuda")
+    out = []
+    try:
+        for form in (1, 0):
+            call("tce_pair_env_static", form)
+            m = mean.cuda().requires_grad_(True)
+            Lg = Lb.clone().requires_grad_(True)
+            lp = ops.pair_log_prob(mp, traj, m, ops.expand_shared(Lg, N), tg,
+                                   t0.cuda(), y0.cuda(), v0.cuda(), pairs)
+            (lp * wgt).sum().backward()
+            out.append((lp.detach(), m.grad, Lg.grad))
+    finally:
+        call("tce_pair_env_static", 1)
+    for a, b in zip(*out):
+        scale = float(b.abs().max())
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale)
