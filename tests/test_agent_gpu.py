@@ -188,9 +188,9 @@ def test_agent_step_matches_cpu_oracle_split_f16_critic(overlap):
 
 
 def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32",
-                     iterations=1, rel_scale=1.0, **kw):
+                     iterations=1, rel_scale=1.0, num_env=16, epochs=3, **kw):
     from oracle.agent_oracle import OracleTCE
-    N, EPOCHS = 16, 3
+    N, EPOCHS = num_env, epochs
     agent, cfg = build(N, EPOCHS, overlap, env=env, num_basis=nb, dtype=dtype,
                        fused_policy_objective=fused,
                        graph_policy_update=graph, **kw)
@@ -292,6 +292,29 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32",
               1e-6 if f64 else 3e-5)
     assert np.isfinite(res["critic_loss_mean"])
     return agent, oracle, res
+
+
+@pytest.mark.parametrize("env,nb,dtype,N,iters", [
+    ("metaworld", 5, "float32", 4096, 2), ("box_push", 8, "float64", 2048, 1)])
+def test_large_batch_step_matches_cpu_oracle(env, nb, dtype, N, iters,
+                                             monkeypatch):
+    """The oracle comparison at sizes where the large-grid code paths run
+    (every other oracle case is 16 - 24 envs): BASELINE
+    configs[1] at its full 4096 envs x T 500 -- 2 M critic rows on the
+    224-workgroup persistent grid with several tiles per workgroup, per-workgroup
+    gradient slabs, 64-env blocks of the pair kernels, the adaptive critic split
+    taken from the first iteration's events in the second -- and the box-pushing
+    shape in float64 at 2048 envs (205 k rows on the two-launch wide critic, the
+    float64 128 x 2 policy net on csrc/pmlp.hip with 64 row tiles), 2 + 2 epochs,
+    overlapped updates.  Same tolerances as the small cases (x 2 for the second
+    iteration)."""
+    spy = _PathSpy(monkeypatch)
+    agent, oracle, res = _agent_vs_oracle(
+        True, True, False, env, nb, dtype, iterations=iters, num_env=N, epochs=2,
+        rel_scale=float(iters))
+    assert (spy.direct, spy.node) == (2 * iters, 0)
+    if iters > 1:
+        assert 0 < agent._critic_split <= 2 or agent._critic_split == 0
 
 
 @pytest.mark.parametrize("env,nb", [("metaworld", 5), ("table_tennis", 3)])
