@@ -633,6 +633,20 @@ int tce_adam_flat_f64(double* param, const double* grad, double* m, double* v, i
                       double beta2, double eps, double weight_decay, double clip,
                       double grad_scale, void* stream);
 
+/* The same step (grad_norm_clip + Adam) as ONE launch for buffers of at most
+ * 2^17 elements -- what a sharded update runs behind each of its ~100 gradient
+ * all-reduces per iteration.  step: the step count INCLUDING this update, kept
+ * by the caller (stored to state[0]); norms_out (nullable) [2] receives {|g|
+ * before, |g| after clipping} (also in state[1:3]). */
+int tce_adam_once_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                      float* state, float* norms_out, float step, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float clip, float grad_scale,
+                      void* stream);
+int tce_adam_once_f64(double* param, const double* grad, double* m, double* v, int64_t n,
+                      double* state, double* norms_out, double step, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, double clip,
+                      double grad_scale, void* stream);
+
 /* ---- fused critic MLP epoch (exact-fp32 MFMA) ----------------------------
  * Forward (+ value loss + backward when `partials` != NULL) of the value
  * network D_in -> 128 -> 128 -> 1 (ValueFunction.critic ->

@@ -84,6 +84,11 @@ class MPExperiment:
         self.sampler = sampler_factory(cfg["sampler"]["type"],
                                        cpu_cores=cw_config.get("cpu_cores"),
                                        **s_args)
+        if dc.active:
+            for rms in (getattr(self.sampler, "obs_rms", None),
+                        getattr(self.sampler, "rwd_rms", None)):
+                if rms is not None:
+                    rms.equal_shards = True       # num_env_train / world each
         self.policy = policy_factory(cfg["policy"]["type"],
                                      dim_in=get_dim_in(cfg, self.sampler),
                                      dim_out=dim_policy_out(cfg),

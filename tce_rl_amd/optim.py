@@ -89,6 +89,27 @@ class FlatAdam(torch.optim.Optimizer):
              float(grad_scale), stream())
         return self.dev_state[1], self.dev_state[2]
 
+    @torch.no_grad()
+    def step_once(self, clip=0.0, grad_scale=1.0, norms_out=None):
+        """``step`` as ONE launch (tce_adam_once_*: buffers of <= 2^17 elements;
+        larger ones take ``step``): the step count comes from the host mirror.
+        norms_out: [2] device tensor for {|g|, |g| clipped}."""
+        n = self.flat_param.numel()
+        if n > (1 << 17):
+            self.step(clip, grad_scale=grad_scale)
+            if norms_out is not None:
+                norms_out.copy_(self.dev_state[1:3])
+            return
+        g = self.param_groups[0]
+        self.sync_grads()
+        self.host_step += 1
+        call("tce_adam_once_" + sfx(self.flat_param.dtype), ptr(self.flat_param),
+             ptr(self.flat_grad), ptr(self.m), ptr(self.v), n,
+             ptr(self.dev_state), ptr(norms_out), float(self.host_step),
+             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+             float(g["eps"]), float(g["weight_decay"]), float(clip),
+             float(grad_scale), stream())
+
     def state_dict(self):
         sd = super().state_dict()
         for st in sd["state"].values():          # detach from the flat buffers

@@ -149,6 +149,9 @@ class AbstractAgent(ABC):
             self.dist.allreduce_flat(
                 opt.flat_grad, self._policy_group
                 if opt is self.policy_optimizer else None, average=False)
+        if self.dist.active and not want_norms:
+            opt.step_once(clip, grad_scale=1.0 / self.dist.world)
+            return None                         # the caller reads dev_state[1:3]
         opt.step(clip, grad_scale=1.0 / self.dist.world)   # mean over ranks
         if not want_norms:                      # the caller reads dev_state[1:3]
             return None
@@ -252,11 +255,15 @@ class _CriticEpochs:
                               adam=opt if self.fuse_adam else None)
             if not self.fuse_adam:
                 if ag.dist.active:
+                    # sum over the shards, then clip + Adam + the two norms of
+                    # the record in ONE launch (tce_adam_once_*)
                     ag.dist.allreduce_flat(opt.flat_grad, average=False)
-                    opt.step(ag.clip_grad_norm, grad_scale=1.0 / ag.dist.world)
+                    opt.step_once(ag.clip_grad_norm,
+                                  grad_scale=1.0 / ag.dist.world,
+                                  norms_out=rows[e, 2:4])
                 else:                   # |g|^2 comes with the reduction
                     opt.step(ag.clip_grad_norm, sumsq=rows[e, 1:2])
-                rows[e, 2:4].copy_(opt.dev_state[1:3])
+                    rows[e, 2:4].copy_(opt.dev_state[1:3])
             self.done = e + 1
 
     def finish(self):
@@ -328,13 +335,15 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self._split_margin = float(os.environ.get("TCE_SPLIT_MARGIN", "1"))
         self._critic_split = 0          # 0: all epochs beside the policy
         self._critic_split_bal = 0      # the same for balance-check iterations
+        self._local_split = [0, 0]      # this rank's estimates (lazy steps)
+        self._split_exchanges = []      # (event, pinned result) of the MAX all-reduces in flight
         self._critic_stream = None
         self._policy_stream = None
 
     def _lazy_step_possible(self):
         from .. import critic_ops
         return (self.lazy_metrics and self._can_overlap()
-                and not self.dist.active and self.device.type == "cuda"
+                and self.device.type == "cuda"
                 and critic_ops.supported(self.critic.net))
 
     def _retire_lazy_steps(self, keep):
@@ -543,13 +552,12 @@ class TemporalCorrelatedAgent(AbstractAgent):
                     first_ms = pev[0].elapsed_time(pev[6]) / max(min(pn1, 6), 1)
                     side_ms = pev[2].elapsed_time(pev[5])
                     split = int(min(pE, side_ms / first_ms + self._split_margin))
-                    if pbal:
-                        self._critic_split_bal = split
-                    else:
-                        self._critic_split = split
+                    self._local_split[1 if pbal else 0] = split
             else:
                 waiting.append(probe)
         self._split_probes = waiting[-3:]
+        if lazy:
+            self._adopt_split()
         cur = self._critic_split_bal if bal else self._critic_split
         n1 = min(E, cur) if cur else E
         ev[0].record(main)
@@ -621,6 +629,45 @@ class TemporalCorrelatedAgent(AbstractAgent):
         return critic_loss_dict, policy_loss_dict, \
             ev[0].elapsed_time(ev[1]) * 1e-3, \
             ev[2].elapsed_time(ev[3]) * 1e-3, side_result
+
+    def _adopt_split(self):
+        """Lazy steps: this rank's own estimate of the split (from its events)
+        becomes the split -- directly in one process; with the envs sharded over
+        ranks every rank must issue its collectives in the same order (the
+        critic's first part, the policy's, the critic's rest), so the ranks
+        agree on the LARGEST estimate without the host waiting for anything:
+        each lazy step puts one MAX all-reduce of the two estimates (ordinary /
+        balance-check iterations) on the main stream, followed by a copy into
+        pinned host memory, and adopts the result of the exchange issued TWO
+        steps earlier -- that step has been retired (its end event waited for),
+        so the values are there, and every rank adopts the same exchange at the
+        same step.  (Round 3: a blocking MAX all-reduce + .item() at the end of
+        every step, and no lazy step at all in sharded runs.)"""
+        if not self.dist.active:
+            if self._local_split[0]:
+                self._critic_split = self._local_split[0]
+            if self._local_split[1]:
+                self._critic_split_bal = self._local_split[1]
+            return
+        import torch.distributed as dist
+        from ..dist import all_reduce
+        q = self._split_exchanges
+        if len(q) >= 2:
+            ev, host = q.pop(0)
+            ev.synchronize()                    # long done (two steps ago)
+            a, b = int(host[0]), int(host[1])
+            if a:
+                self._critic_split = a
+            if b:
+                self._critic_split_bal = b
+        t = torch.tensor(self._local_split, dtype=torch.int32).pin_memory() \
+            .to(self.device, non_blocking=True)
+        all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
+        host = torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append((ev, host))
 
     def _balance_iteration(self):
         """Is the current iteration one with the policy balance check

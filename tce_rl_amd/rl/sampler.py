@@ -78,8 +78,15 @@ class RunningMeanStd:
         M2 = var * self.count + var_g * n_g + delta ** 2 * self.count * n_g / tot
         self.mean.copy_(new_mean.reshape(self.mean.shape))
         self.var.copy_((M2 / tot).reshape(self.var.shape))
-        self.count = self.count + float(sum(float(c) for c in
-                                            allr[:, -1].tolist()))
+        if getattr(self, "equal_shards", False):
+            # (MPExperiment's shards are equal -- it checks the divisibility --
+            # so the global row count needs no host read of the gathered counts:
+            # that read made the host wait for the whole previous iteration in
+            # every rollout of a sharded run)
+            self.count = self.count + float(n_loc) * w
+        else:
+            self.count = self.count + float(sum(float(c) for c in
+                                                allr[:, -1].tolist()))
 
     def save(self, log_dir, epoch):
         path = util.get_training_state_save_path(log_dir, self.name, epoch)

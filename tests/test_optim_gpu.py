@@ -16,7 +16,10 @@ def _params(dtype, seed):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("wd,clip", [(0.0, 0.0), (1e-3, 0.0), (0.0, 0.5),
                                      (1e-2, 5.0)])
-def test_flat_adam_matches_torch_adam(dtype, wd, clip):
+@pytest.mark.parametrize("once", [False, True])
+def test_flat_adam_matches_torch_adam(dtype, wd, clip, once):
+    """once: the single-launch form (tce_adam_once_*, what a sharded update runs
+    behind its all-reduces)."""
     from tce_rl_amd.optim import FlatAdam
     ref = [torch.nn.Parameter(p.clone()) for p in _params(dtype, 0)]
     mine = [torch.nn.Parameter(p.clone().cuda()) for p in _params(dtype, 0)]
@@ -38,7 +41,13 @@ def test_flat_adam_matches_torch_adam(dtype, wd, clip):
             torch.nn.utils.clip_grad_norm_(ref, clip)
         after = torch.sqrt(sum((p.grad ** 2).sum() for p in ref))
         o_ref.step()
-        nb, na = o_mine.step(clip)
+        if once:
+            norms = torch.zeros(2, dtype=dtype, device="cuda")
+            o_mine.step_once(clip, norms_out=norms)
+            nb, na = norms[0], norms[1]
+            assert torch.equal(norms, o_mine.dev_state[1:3])
+        else:
+            nb, na = o_mine.step(clip)
         tol = 1e-5 if dtype == torch.float32 else 1e-12
         assert nb.item() == pytest.approx(before.item(), rel=tol)
         assert na.item() == pytest.approx(after.item(), rel=10 * tol)
