@@ -47,6 +47,15 @@ for _ in range(3):
     big.fill_(1.0)
     runw64.epoch(xw64, rw64, rw64, 0.0)
 del xw64, rw64
+# round 4: the float64 128 x 2 policy mean net of box pushing on csrc/pmlp.hip (8192 rows)
+from tce_rl_amd import pmlp_ops
+pnet = MLP("policy", 22, 63, [128, 128], "orthogonal", 0.01, "leaky_relu", None, torch.float64, torch.device("cuda"))
+xp = torch.randn(8192, 22, device="cuda", generator=g, dtype=torch.float64); gp = torch.randn(8192, 63, device="cuda", generator=g, dtype=torch.float64)
+for _ in range(3):
+    big.fill_(1.0)
+    keep = {}
+    pmlp_ops.forward(pnet, xp, keep=keep)
+    pmlp_ops.backward(pnet, keep, gp)
 acts = torch.randn(N, T, 8, device="cuda", generator=g); obs0 = torch.randn(N, 48, device="cuda", generator=g); shift = torch.zeros(48, device="cuda")
 for _ in range(3):
     big.fill_(1.0)

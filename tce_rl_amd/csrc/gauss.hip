@@ -16,10 +16,13 @@
 // the closed-form implicit gradient in the eigenbasis.
 #include "smallmat.h"
 #include "lanevec.h"
+#include "klproj2.h"
 
 namespace {
 
 constexpr double LOG_2PI = 1.8378770664093453;
+int g_klp_impl = 2;                 // tce_kl_proj_impl: 0 Jacobi, 1 Newton, 2 by size
+inline bool klp_newton(int K) { return g_klp_impl == 1 || (g_klp_impl == 2 && K > 32); }
 
 // ---------------------------------------------------------------------------
 // Cholesky head: vec [B, K (+ K(K-1)/2)] -> L [B, K, K]
@@ -312,7 +315,8 @@ __host__ __device__ inline int64_t klp_ctx_len(int K) { return (int64_t)K * K + 
 #define KLP_T(k) { __syncthreads(); if (threadIdx.x == 0) { const long long tn_ = __builtin_readcyclecounter(); stamp_[k] = (double)(tn_ - t0_); t0_ = tn_; } }
 #define KLP_T0() long long t0_ = __builtin_readcyclecounter(); double* stamp_ = cb + (int64_t)K * K + K + 4;
 #else
-__host__ __device__ inline int64_t klp_ctx_len(int K) { return (int64_t)K * K + K + 4; }
+// (the context also has to hold what the eigen-free kernels of klproj2.h keep)
+__host__ __device__ inline int64_t klp_ctx_len(int K) { return 4 * (int64_t)K * K + K + 8; }
 #define KLP_T(k)
 #define KLP_T0()
 #endif
@@ -603,6 +607,17 @@ extern "C" {
 
 int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
 
+// 2 (default): by size -- the eigen-decomposition-free kernels of klproj2.h for
+// K > 32 (their images are 64 x 64 whatever K is: at K 24 the Jacobi kernels
+// are still faster, 40 / 16 us against 54 / 24), the Jacobi kernels above
+// otherwise; 1 / 0: force one form.  A context written by one form must not be
+// read by the other (forward and backward of one evaluation, and a warm start,
+// use one form).
+int tce_kl_proj_impl(int impl) {
+  g_klp_impl = impl < 0 || impl > 2 ? 2 : impl;
+  return 0;
+}
+
 #define DEFINE_GAUSS(SFX, REAL)                                                   \
   int tce_chol_build_fwd_##SFX(const REAL* vec, REAL* L, int64_t B, int K,        \
                                int nvec, REAL min_std, void* stream) {            \
@@ -669,6 +684,15 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
                                 void* stream) {                                   \
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && B > 0 && K > 0 && K <= 64,       \
                   "kl_cov_proj: bad arguments (K <= 64)");                        \
+    if (klp_newton(K)) {                                                          \
+      set_lds(klp2::fwd_kernel<REAL>, klp2::LDS_BYTES);                           \
+      hipLaunchKernelGGL(klp2::fwd_kernel<REAL>, dim3((unsigned)B),               \
+                         dim3(klp2::BT), klp2::LDS_BYTES, (hipStream_t)stream, L, \
+                         L_old, L_old_stride, eps_cov, beta, entropy_eq, proj_L,  \
+                         ctx, K, warm_start);                                     \
+      TCE_LAUNCH_CHECK();                                                         \
+      return 0;                                                                   \
+    }                                                                             \
     const size_t lds = 4 * (size_t)K * sm_pitch(K) * sizeof(double);                  \
     set_lds(kl_cov_proj_fwd_kernel<REAL>, lds);                                   \
     hipLaunchKernelGGL(kl_cov_proj_fwd_kernel<REAL>, dim3((unsigned)B),           \
@@ -685,6 +709,14 @@ int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && grad_proj && grad_L && B > 0 &&  \
                       K > 0 && K <= 64,                                           \
                   "kl_cov_proj_bwd: bad arguments (K <= 64)");                    \
+    if (klp_newton(K)) {                                                          \
+      set_lds(klp2::bwd_kernel<REAL>, klp2::LDS_BYTES);                           \
+      hipLaunchKernelGGL(klp2::bwd_kernel<REAL>, dim3((unsigned)B),               \
+                         dim3(klp2::BT), klp2::LDS_BYTES, (hipStream_t)stream, L, \
+                         L_old, L_old_stride, proj_L, ctx, grad_proj, grad_L, K); \
+      TCE_LAUNCH_CHECK();                                                         \
+      return 0;                                                                   \
+    }                                                                             \
     const size_t lds = 4 * (size_t)K * sm_pitch(K) * sizeof(double);                  \
     set_lds(kl_cov_proj_bwd_kernel<REAL>, lds);                                   \
     hipLaunchKernelGGL(kl_cov_proj_bwd_kernel<REAL>, dim3((unsigned)B),           \
