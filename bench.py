@@ -108,8 +108,9 @@ def kernel_time_cold_us(fn, launches=5):
     return sorted(ts)[len(ts) // 2]
 
 
-PMC_TAGS = ("r03", "r02", "r01e", "r01c")
-STATS_CSV = ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv")
+PMC_TAGS = ("r04", "r03", "r02", "r01e", "r01c")
+STATS_CSV = ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv",
+             "r02_bench_kernel_stats.csv")
 
 
 def pmc_lookup(kernel):
@@ -122,6 +123,21 @@ def pmc_lookup(kernel):
             rel = os.path.join("profiles", tag + "_pmc.json")
             with open(os.path.join(REPO, rel)) as f:
                 return json.load(f)["kernels"][kernel]["traffic_bytes"], rel
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def mfma_busy(kernel):
+    """(matrix-pipe utilisation of `kernel` alone on the chip, source file) from
+    the COMMITTED counter pass profiles/r04_pmc_mfma.json
+    (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD) -- read from
+    the file, not measured in this run; (None, None) if absent."""
+    for tag in ("r04",):
+        try:
+            rel = os.path.join("profiles", tag + "_pmc_mfma.json")
+            with open(os.path.join(REPO, rel)) as f:
+                return json.load(f)["kernels"][kernel]["mfma_busy"], rel
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -233,6 +249,8 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
                   "us_per_launch": round(us_c, 1),
                   "achieved": round(flops / us_c / 1e6, 2),
                   "frac": round(flops / us_c / 1e6 / F32_MFMA_PEAK_TF, 4)},
+              "mfma_busy": mfma_busy("mlp_critic_bwd_kernel")[0],
+              "mfma_busy_source": mfma_busy("mlp_critic_bwd_kernel")[1],
               "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel")[0],
               "rocprof_source": profiled_us("mlp_critic_bwd_kernel")[1],
               "algorithmic_flops": flops_step,
@@ -354,6 +372,11 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
             "traffic": wide_traffic(tag, n3 * t3)[0],
             "traffic_source": wide_traffic(tag, n3 * t3)[1],
             "us_per_epoch": round(us_w, 1), "algorithmic_flops": fl,
+            "mfma_busy": {"chain": mfma_busy("mlpw_chain_kernel<" + (
+                "float" if tag == "f32" else "double"))[0],
+                "grad": mfma_busy("mlpw_grad_kernel<" + (
+                    "float" if tag == "f32" else "double"))[0],
+                "source": mfma_busy("mlpw_chain_kernel<float")[1]},
             "workload": "BASELINE configs[2] critic: 8192 envs x T 100 rows, "
                         "D_in 22 -> 256 -> 256 -> 1, leaky_relu",
             "dtype": tag + (" (v_mfma_f32_16x16x4_f32)" if tag == "f32"
@@ -508,14 +531,39 @@ def _run_config(name, spec, steps, warmup):
         out["update_ms_last_step"] = round(upd * 1e3, 2)
         out["policy_updates_per_sec"] = round(
             E / max(upd, 1e-9), 2) if upd else None
+        # the floor of the dependent chain: the same update on ONE workgroup's
+        # worth of rows (64 envs = one 64-row tile per row kernel): every kernel
+        # of an epoch then is its own critical path -- 3 layers forward, the
+        # head, 3 layers backward, the slab reduction, the finish -- plus the
+        # launch boundaries between them; nothing is throughput-bound
+        floor_us = None
+        if spec.get("chain_floor", True):
+            del agent
+            torch.cuda.empty_cache()
+            tiny = build_config_agent(dict(spec, num_env=64))
+            for _ in range(3):
+                tiny.step()
+            ups = []
+            for _ in range(5):
+                r2 = tiny.step()
+                ups.append(r2.get("update_time", 0.0))
+            floor_us = sorted(ups)[len(ups) // 2] / E * 1e6
+            agent = tiny
         out["roofline"] = {
             "kernel": "critic + policy epochs (%d -> %d -> %d nets, %d rows)"
                       % (din, hs[0], hs[1], rows),
             "bound": "latency",
             "us_per_epoch_pair": round(upd / E * 1e6, 1) if upd else None,
+            "chain_floor_us_per_epoch_pair": None if floor_us is None
+            else round(floor_us, 1),
+            "frac_of_chain_floor": None if not (floor_us and upd)
+            else round(floor_us / (upd / E * 1e6), 3),
             "algorithmic_flops_per_epoch": flops,
             "note": "2 x %d dependent epochs of a few small kernels each: "
-                    "launch / dependency latency, neither HBM nor MFMA" % E}
+                    "launch / dependency latency, neither HBM nor MFMA.  "
+                    "chain_floor = the same update measured at 64 envs (one "
+                    "workgroup per kernel: the bare dependent chain of an "
+                    "epoch incl. its launch boundaries)" % E}
     del agent
     torch.cuda.empty_cache()
     return out
