@@ -292,14 +292,23 @@ __host__ __device__ inline int pf_ws_pair(const PFShape& s) {          // reals 
   return 2 * s.nbg + 4 + s.R * s.K + 2 * s.R * s.R + 1;
 }
 
+// (L and M = H_p L are staged in LDS: read from global memory inside the product
+// loops -- as until round 3 -- every term was an L2 round trip of its own, K of
+// them in a row per element of C; the kernel sits on the critical path of every
+// policy epoch: 67 us at K 24, 91 us at K 63 beside the critic)
 template <typename real>
 __global__ __launch_bounds__(256) void pair_prep_kernel(
     const real* __restrict__ L, const int64_t* __restrict__ pairs, const real* __restrict__ B,
     const int* __restrict__ nonuniform, real reg, real* __restrict__ ws, PFShape s) {
   if (*nonuniform != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char prep_raw[];
   __shared__ real C[PL_MAXR][PL_MAXR + 1];
   __shared__ real X[PL_MAXR][PL_MAXR + 1];
+  __shared__ real Hl[2 * TCE_MAXB];
   const int K = s.K, R = s.R, nbg = s.nbg;
+  const int KP = pl_pitch(K);
+  real* Ls = reinterpret_cast<real*>(prep_raw);     // [K][KP]
+  real* Ms = Ls + K * KP;                            // [R][KP]
   const int p = blockIdx.x, tid = threadIdx.x;
   real* w = ws + (int64_t)p * pf_ws_pair(s);
   real* Hs = w;                       // [2][nbg]
@@ -308,9 +317,15 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
   real* Li = M + R * K;               // [R][R]
   real* Ci = Li + R * R;              // [R][R]
   real* ld = Ci + R * R;              // logdet
+  for (int e = tid; e < K * K; e += 256) {
+    const int r = e / K, c = e - r * K;
+    Ls[r * KP + c] = L[e];
+  }
   if (tid < 2 * nbg) {
     const int j = tid / nbg, b = tid - j * nbg;
-    Hs[tid] = B[pairs[2 * p + j] * (4 + 2 * nbg) + 4 + b];
+    const real h = B[pairs[2 * p + j] * (4 + 2 * nbg) + 4 + b];
+    Hs[tid] = h;
+    Hl[tid] = h;
   }
   if (tid < 4) cs[tid] = B[pairs[2 * p + (tid >> 1)] * (4 + 2 * nbg) + (tid & 1)];
   __syncthreads();
@@ -320,15 +335,16 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
     real acc = 0;
     for (int b = 0; b < nbg; ++b) {
       const int row = d * nbg + b;
-      if (k <= row) acc += Hs[j * nbg + b] * L[row * K + k];
+      if (k <= row) acc += Hl[j * nbg + b] * Ls[row * KP + k];
     }
+    Ms[r * KP + k] = acc;
     M[e] = acc;
   }
   __syncthreads();
   for (int e = tid; e < R * R; e += 256) {
     const int r = e / R, c = e - r * R;
     real acc = 0;
-    for (int k = 0; k < K; ++k) acc += M[r * K + k] * M[c * K + k];
+    for (int k = 0; k < K; ++k) acc += Ms[r * KP + k] * Ms[c * KP + k];
     C[r][c] = acc + (r == c ? reg : real(0));
   }
   __syncthreads();
@@ -686,11 +702,13 @@ __global__ __launch_bounds__(256) void pair_final_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* GM = reinterpret_cast<real*>(smem_raw);      // [R][K]
   const int K = s.K, R = s.R, P = s.P, nbg = s.nbg;
+  real* Ms = GM + R * K;                             // [R][K]: M of the pair's record
   const int tid = threadIdx.x, p = blockIdx.x;
   const real* w = ws + (int64_t)p * pf_ws_pair(s);
   const real* Hs = w;
   const real* M = w + 2 * nbg + 4;
   const real* Ci = M + R * K + R * R;
+  for (int e = tid; e < R * K; e += 256) Ms[e] = M[e];
   // S_p and sg_p: sum the per-block partials (4 groups of blocks in parallel)
   const int nv = R * R + 1;
   for (int e = tid; e < 4 * nv; e += 256) {
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(256) void pair_final_kernel(
   for (int e = tid; e < R * K; e += 256) {
     const int r = e / K, k = e - r * K;
     real a = 0;
-    for (int c = 0; c < R; ++c) a += G[r][c] * M[c * K + k];
+    for (int c = 0; c < R; ++c) a += G[r][c] * Ms[c * K + k];
     GM[e] = a;
   }
   __syncthreads();
@@ -824,7 +842,8 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     real* wsp = work;                                      // [P][pf_ws_pair]
     real* spart = wsp + (int64_t)P * pf_ws_pair(f);        // [nblk][P][R*R+1]
     if (!prep_ready) {
-      hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256), 0, stream, L, pairs, B,
+      hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256),
+                         (size_t)(K + f.R) * pl_pitch(K) * sizeof(real), stream, L, pairs, B,
                          flag, reg, wsp, f);
       TCE_LAUNCH_CHECK();
     }
@@ -859,7 +878,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
       }
       real* gLp = spart + (int64_t)nblk * P * (f.R * f.R + 1);   // [P][K][K]
       hipLaunchKernelGGL(pair_final_kernel<real>, dim3(P), dim3(256),
-                         (size_t)f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gLp,
+                         (size_t)2 * f.R * K * sizeof(real), stream, spart, nblk, flag, wsp, gLp,
                          f);
       TCE_LAUNCH_CHECK();
       // dL = sum_p gLp[p]  (runs only when the fast path did: flag == 0)

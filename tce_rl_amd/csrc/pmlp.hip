@@ -109,8 +109,11 @@ __host__ __device__ inline size_t pm_fwd_lds(int din) {
                          (size_t)H * PM_WP);
 }
 
+// (two workgroups per CU: while one waits for a weight chunk the other multiplies)
+// (its LDS -- 153 KB -- allows one workgroup per CU only for float64 x 256)
 template <typename real, int H, int NL>
-__global__ __launch_bounds__(PM_BT) void pmlp_fwd_kernel(PmArgs<real> a) {
+__global__ __launch_bounds__(PM_BT, (sizeof(real) * H > 1024 ? 1 : 2)) void pmlp_fwd_kernel(
+    PmArgs<real> a) {
   typedef typename PT<real>::acc acc_t;
   typedef typename PT<real>::v2 v2;
   constexpr int NBH = H / 64;                   // unit blocks per wave of a hidden layer

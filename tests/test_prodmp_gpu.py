@@ -198,31 +198,30 @@ def test_pair_logprob_golden_plumbing(ops, golden):
             (err_ours, err_ref)
 
 
-@pytest.fixture
-def pair_form(request):
-    """"static": the register kernels built for the shipped (dof, basis count)
-    combinations (default); "general": the runtime-shape kernel for every shape."""
+_PL_NAMES = ["metaworld", "metaworld_nb5", "box_push", "table_tennis"]
+# (name, shared, uniform_t0, N, form): N 300 = the shared-L fast path (N >= 256),
+# whose two kernel forms -- "static": registers, built for the shipped (dof,
+# basis count) shapes; "general": runtime shapes -- differ there only
+_PL_CASES = [(n, sh, u, 6, "static") for n in _PL_NAMES for sh in (False, True)
+             for u in (True, False)] + \
+    [(n, True, u, 300, "static") for n in _PL_NAMES for u in (True, False)] + \
+    [(n, True, True, 300, "general") for n in _PL_NAMES]
+
+
+@pytest.mark.parametrize("name,shared,uniform_t0,N,form", _PL_CASES)
+def test_pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N, form):
     from tce_rl_amd._lib import call
-    call("tce_pair_env_static", int(request.param == "static"))
-    yield request.param
-    call("tce_pair_env_static", 1)
+    call("tce_pair_env_static", int(form == "static"))
+    try:
+        _pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N)
+    finally:
+        call("tce_pair_env_static", 1)
 
 
-@pytest.mark.parametrize("name", ["metaworld", "metaworld_nb5", "box_push",
-                                  "table_tennis"])
-@pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("uniform_t0", [True, False])
-@pytest.mark.parametrize("N", [6, 300])      # 300: shared-L fast path (N >= 256)
-@pytest.mark.parametrize("pair_form", ["static", "general"], indirect=True)
-def test_pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N,
-                                        pair_form):
+def _pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N):
     dtype = torch.float64
     mp, oracle = make(name, dtype)
     T = HORIZON[name]
-    if N > 6 and not shared:
-        pytest.skip("large-N case targets the shared-L fast path")
-    if pair_form == "general" and not (N > 6 and shared and uniform_t0):
-        pytest.skip("the two forms differ on the shared-L fast path only")
     mean, L, eps, t0, y0, v0 = inputs(name, N, dtype, 3, uniform_t0)
     if shared:
         L = L[:1].expand(N, -1, -1).contiguous()
