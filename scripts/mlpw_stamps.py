@@ -43,6 +43,6 @@ for it in range(3):
 dy1 = ws[2 * H * H + 2 * R * H:]
 st = dy1[:8].cpu().tolist()
 names = ["layer1+h1 store", "fwd: barrier", "loss+dY2", "bwd panels", "fwd: fetch+mma", "fwd: stash", "fwd: epilogue", "tile head"]
-tiles = (R + (64 if f64 else 128) - 1) // (64 if f64 else 128) / lib.tce_mlpw_grid()
+tiles = (R + 127) // 128 / lib.tce_mlpw_grid()
 print("tiles per workgroup %.1f; cycles per tile:" % tiles, {n: int(v / tiles) for n, v in zip(names, st) if n != "-"},
       "total/tile", int(sum(st) / tiles))

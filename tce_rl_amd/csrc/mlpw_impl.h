@@ -232,9 +232,12 @@ struct ChainLds {
   // the tile's X rows [TILE][4 KPG features], pitch odd
   static constexpr int XP = 4 * KPG + 1;
   static constexpr int XS = WFuse<real, H, KPG>::on ? WCfg<real>::TILE * XP : 0;
+  // PARK (fp64): the signs of the tile's H1, one bit per element -- a byte per
+  // thread and pair of unit blocks
+  static constexpr int SG = sizeof(real) == 8 ? WCfg<real>::NT * (H / 32) / 8 : 0;
   static constexpr size_t bytes(bool bwd) {
     return sizeof(real) * ((size_t)H * W1P + 3 * H + 2 * PANEL +
-                           (bwd ? (size_t)WCfg<real>::NACC * H + T1 + XS : 0)) + 64;
+                           (bwd ? (size_t)WCfg<real>::NACC * H + T1 + XS + SG : 0)) + 64;
   }
 };
 
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   real* gacc = pan + 2 * LD::PANEL;                          // [NACC][H] dw3 (positions)
   real* t1buf = gacc + C::NACC * H;                          // [2][TILE][TP1] dY1 of a panel (FUSE)
   real* xs = t1buf + LD::T1;                                 // [TILE][XP] X rows of the tile (FUSE)
+  unsigned char* h1m = reinterpret_cast<unsigned char*>(xs + LD::XS);   // [H / 32][NT] sign bits of H1 (PARK)
   constexpr int XP = LD::XP;
   constexpr bool FUSE = BWD && WFuse<real, H, KPG>::on;
   constexpr int TP1 = LD::TP1;
@@ -523,9 +527,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       rt = a.ret[rok ? r : a.R - 1];
       if (a.clip > real(0)) ov = a.old_v[rok ? r : a.R - 1];
     }
-    // (FUSE: the next tile's rows are requested in the last backward step --
-    // eight registers less through the tile)
-    if (more && !FUSE) load_x(tile + gridDim.x, xn);
+    // (FUSE / every backward build: the next tile's rows are requested in the
+    // last backward step -- KPG registers (fp64: twice that) less through the tile)
+#ifndef MLPW_XLATE
+#define MLPW_XLATE 1
+#endif
+    constexpr bool XLATE = MLPW_XLATE && BWD;
+    if (more && !(FUSE || XLATE)) load_x(tile + gridDim.x, xn);
     // one turn: dW1 tile (panel sp, my_at, my_xt) += dY1[rows][positions]^T X[rows][features]
     // over the TILE rows (A from the transpose buffer sp & 1, B = X from L2; the
     // feature D_in is a column of ones: db1)
@@ -556,6 +564,16 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       }
     };
 
+    // PARK with a piecewise-linear activation: act'(H1) is one bit per element
+    // (h > 0).  The 64 bits of a lane wait in the LDS (held in two registers
+    // they cost 90 spilled ones) instead of a second pass over the H1 rows in
+    // the backward panels: - 1.7 GB of reads per C3 epoch, 5.98 -> 5.95 ms
+    // (with nothing in their place: 5.82)
+#ifndef MLPW_MASK1
+#define MLPW_MASK1 1
+#endif
+    constexpr bool SIGN1 = MLPW_MASK1 && BWD && sizeof(real) == 8 && C::WAVES == 8 &&
+                           (ACT == W_RELU || ACT == W_LEAKY);
     // ---- layer 1: H1^T = act(W1 X^T + b1), two row blocks at a time
     // (go: the lane group, opaque per tile -- the forward-only kernel has no LDS
     // stores in its loop, and the compiler would otherwise keep every bias, w3
@@ -579,10 +597,26 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         c0 = wmfma(a0[1], xb[s + 1], c0);
         c1 = wmfma(a1[1], xb[s + 1], c1);
       }
+      if (SIGN1) {
+        // (y > 0 and act(y) > 0 are the same predicate for both activations:
+        // one compare serves the activation and the bit)
+        const real slope = ACT == W_RELU ? real(0) : real(0.01);
+        unsigned bits = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        c0[i] = wact<real, ACT>(c0[i]);
-        c1[i] = wact<real, ACT>(c1[i]);
+        for (int i = 0; i < 4; ++i) {
+          const bool p0 = c0[i] > real(0), p1 = c1[i] > real(0);
+          c0[i] = p0 ? c0[i] : slope * c0[i];
+          c1[i] = p1 ? c1[i] : slope * c1[i];
+          bits |= p0 ? 1u << i : 0u;
+          bits |= p1 ? 16u << i : 0u;
+        }
+        h1m[(J >> 1) * NT + tid] = (unsigned char)bits;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c0[i] = wact<real, ACT>(c0[i]);
+          c1[i] = wact<real, ACT>(c1[i]);
+        }
       }
       h1[J] = c0;
       h1[J + 1] = c1;
@@ -595,10 +629,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     // (the workspaces hold whole tiles: rows past R are written and read like
     // the others -- no data-dependent branch around a store, so the waits on
     // the shared load / store counter stay countable -- and never used)
-    if (BWD) {
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) *reinterpret_cast<v4*>(ph + 16 * J) = h1[J];
-    }
+    // (the H1 rows are stored behind the first panel fetch below)
 
     WSTAMP(0)
     // ---- layer 2 through the W2 panels: H2^T = act(W2 H1^T + b2).  Their
@@ -644,6 +675,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         if (GLDS) dma(last ? 0 : s + 1, (s & 1) ^ 1);
         else fetch(last ? 0 : s + 1);
       }
+      // H1 for the gradient kernel: behind the panel fetch, so that nothing
+      // the fetch needs (the fp64 build reloads a spilled lane offset for it)
+      // waits for these 2 KiB per row to be acknowledged
+      if (BWD && s == 0) {
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) *reinterpret_cast<v4*>(ph + 16 * J) = h1[J];
+      }
 #pragma unroll
       for (int jj = 0; jj < NTILE; ++jj) facc[s & 1][jj] = (vacc){0, 0, 0, 0};
       // the other buffer is free since the last barrier: the next panel goes
@@ -666,6 +704,17 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
               for (int n = HK::lo(h); n < HK::lo(h + 1); ++n) fwd_elem(s - 1, n, b2r, w3r);
             }
           });
+#ifndef MLPW_PARK_EARLY
+#define MLPW_PARK_EARLY 1
+#endif
+      // PARK, last forward panel: H1 was the B operand for the last time -- the
+      // parked H2 tiles come back into its registers behind the panel's
+      // MFMAs instead of behind the loss (the last panel's own tiles never
+      // leave the registers)
+      if (MLPW_PARK_EARLY && PARK && s == NP - 1) {
+#pragma unroll
+        for (int J = 0; J < NJ - NTILE; ++J) dy2[J] = *reinterpret_cast<const v4*>(pd + 16 * J);
+      }
       WSTAMP(4)
       // (v pinned here: where a step ends in a branch -- the register-staged
       // build -- the compiler otherwise sinks every panel's epilogue to the end
@@ -680,7 +729,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         }
 #pragma unroll
         for (int n = 0; n < 4 * NTILE; ++n) fwd_elem(s, n, b2r, w3r);
-        if (PARK) {
+        if (PARK && !(MLPW_PARK_EARLY && s == NP - 1)) {
 #pragma unroll
           for (int jj = 0; jj < NTILE; ++jj)
             *reinterpret_cast<v4*>(a.dy2s + r * H + 4 * g + 16 * (s * NTILE + jj)) = park_t[jj];
@@ -727,12 +776,18 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
       // panels; dw3 = sums over the 16 batch lanes of a row (db2 and db1 are
       // column sums of the dY2 / dY1 rows: the gradient kernel takes them from
       // its A fragments for free)
-      if (PARK) {
+      if (PARK && MLPW_PARK_EARLY) {
+#pragma unroll
+        for (int jj = 0; jj < NTILE; ++jj) dy2[NJ - NTILE + jj] = park_t[jj];
+      } else if (PARK) {
         // H2 back from the workspace into the image H1 occupied (its last use as
         // the B operand was the last forward panel)
 #pragma unroll
         for (int J = 0; J < NJ; ++J) dy2[J] = *reinterpret_cast<const v4*>(pd + 16 * J);
       }
+#ifndef MLPW_DY2_GROUP
+#define MLPW_DY2_GROUP 4
+#endif
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
         const v4 w3v = *reinterpret_cast<const v4*>(Bs + 2 * H + 16 * J + 4 * g);
@@ -756,7 +811,9 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
             else q3[i] += t3[i];
           }
         }
-        wfence();
+        // (the tiles of a group overlap: LDS reads, cross-lane sums and the
+        // read-modify-write of the dw3 slab are latency chains)
+        if (J % MLPW_DY2_GROUP == MLPW_DY2_GROUP - 1) wfence();
       }
       WSTAMP(2)
       // ---- dH1^T = W2^T dY2^T through the W2^T panels; dY1 = dH1 act'(H1)
@@ -768,12 +825,16 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
           if (GLDS) dma(last ? 0 : NP + s + 1, ((NP + s) & 1) ^ 1);
           else fetch(last ? 0 : NP + s + 1);
         }
-        if (FUSE && last && more) load_x(tile + gridDim.x, xn);
+        if ((FUSE || XLATE) && last && more) load_x(tile + gridDim.x, xn);
         vacc h1p[NTILE];                                       // PARK: this panel's H1 tile, from the workspace
-        if (PARK) {
+        unsigned h1b[NTILE];                                   // ... or its sign bits
+        if (PARK && !SIGN1) {
 #pragma unroll
           for (int jj = 0; jj < NTILE; ++jj)
             h1p[jj] = *reinterpret_cast<const v4*>(ph + 16 * (s * NTILE + jj));
+        } else if (SIGN1) {
+#pragma unroll
+          for (int jj = 0; jj < NTILE; ++jj) h1b[jj] = h1m[((s * NTILE + jj) >> 1) * NT + tid];
         }
         vacc acc[NTILE];
 #pragma unroll
@@ -788,8 +849,13 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
         for (int jj = 0; jj < NTILE; ++jj) {
           const int J = s * NTILE + jj;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[jj][i] *= wact_d<real, ACT>(PARK ? h1p[jj][i] : h1[J][i]);
+          for (int i = 0; i < 4; ++i) {
+            if (SIGN1)
+              acc[jj][i] *= ((h1b[jj] >> (4 * (J & 1) + i)) & 1u)
+                                ? real(1) : (ACT == W_RELU ? real(0) : real(0.01));
+            else
+              acc[jj][i] *= wact_d<real, ACT>(PARK ? h1p[jj][i] : h1[J][i]);
+          }
           if (FUSE)
             *reinterpret_cast<v4*>(t1buf + (s & 1) * C::TILE * TP1 + (wave * 16 + m) * TP1 +
                                    16 * jj + 4 * g) = acc[jj];
