@@ -18,7 +18,7 @@ if "--build" in sys.argv or not os.path.exists(so):
               if f.endswith(".o") and f != "smlp.o"]
     st_o = os.path.join(os.path.dirname(so), "smlp_stamp.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3",
-                           "-fPIC", "-std=c++17", "-DSMLP_STAMP", "-c",
+                           "-fPIC", "-std=c++17", "-DSMLP_STAMP"] + (["-DSMLP_STAMP_HEAD"] if "--head" in sys.argv else []) + ["-c",
                            os.path.join(CS, "smlp.hip"), "-o", st_o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950",
                            "-shared", "-fPIC", "-o", so, st_o] + others)

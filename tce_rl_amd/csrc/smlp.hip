@@ -96,6 +96,27 @@ __device__ inline float s_actd(float h, int rt) {
   }
 }
 
+// diagnostic build (scripts/smlp_stamps.py): cycles per phase of the row kernel;
+// SMLP_STAMP_HEAD: the sections of the register policy head instead
+#ifdef SMLP_STAMP
+#define SMLP_T0() long long t0_ = __builtin_readcyclecounter(); long long stamp_[5] = {0, 0, 0, 0, 0};
+#define SMLP_T(k) { const long long tn_ = __builtin_readcyclecounter(); stamp_[k] += tn_ - t0_; t0_ = tn_; }
+#else
+#define SMLP_T0()
+#define SMLP_T(k)
+#endif
+#ifdef SMLP_STAMP_HEAD
+#define SMLP_HARGS_DECL , long long* stamp_, long long& t0_
+#define SMLP_HARGS , stamp_, t0_
+#define SMLP_TH(k) SMLP_T(k)
+#define SMLP_TK(k)
+#else
+#define SMLP_HARGS_DECL
+#define SMLP_HARGS
+#define SMLP_TH(k)
+#define SMLP_TK(k) SMLP_T(k)
+#endif
+
 // LDS map (offsets in floats, all multiples of 4)
 struct SLds {
   int w1t, w2, w2t, w3, b1, b2, b3;      // weight images
@@ -138,8 +159,8 @@ __host__ __device__ inline SLds s_lds(int din, int H, int dout, int head) {
   const int kk = kp * kp;
   L.lo = o; o += pol ? kk : 0;
   L.lp = o; o += pol ? kk : 0;
-  L.rdo = o; o += pol ? L.doutp : 0;
-  L.rdp = o; o += pol ? L.doutp : 0;
+  L.rdo = o; o += pol ? kp : 0;           // (kp entries: the diagonal head reads its padded length)
+  L.rdp = o; o += pol ? kp : 0;
   const bool inv = pol && kp <= 32;       // the register head (K <= 32) works with the inverses
   L.lio = o; o += inv ? kk : 0;
   L.liot = o; o += inv ? kk : 0;
@@ -232,6 +253,108 @@ __device__ inline void s_load_x(const SLds& L, float* S, const SNet& n, int64_t 
     S[L.xs + r * L.xp + c] = v;
   }
 }
+
+// The same images by LDS-DMA (global_load_lds_dword: one wave instruction moves
+// 64 floats from per-lane global addresses to 64 consecutive LDS floats): no
+// data registers, no store pass, and every load of the weights AND of the
+// first tile is in flight before anything is waited for -- ONE round trip to
+// memory, where the loops above are a dependent round trip per image (23 000
+// of the policy row kernel's 81 000 cycles at 4096 rows).  (Staged through
+// register arrays instead, the compiler copied the loaded values to AGPRs as
+// they arrived -- a wait per batch -- and the predicates were 4 000
+// instructions.)  Chunk t of an image = its floats [64 t, 64 t + 64), lane =
+// float; the waves take chunks in turn; the source address is clamped instead
+// of predicated (pad columns / rows past N hold copies of valid elements:
+// the zero pad rows of W1^T, written behind the wait, and the heads' row masks
+// make them harmless).  e / d for a run-time d and e < 2^15 / d is exact as
+// (e * ceil(2^20 / d)) >> 20.
+typedef const __attribute__((address_space(1))) void* s_gvp;
+typedef __attribute__((address_space(3))) void* s_lvp;
+__device__ __forceinline__ void s_dma64(const float* src, float* lds_chunk) {
+  __builtin_amdgcn_global_load_lds((s_gvp)src, (s_lvp)lds_chunk, 4, 0, 0);
+}
+__device__ __forceinline__ unsigned s_magic(int d) { return ((1u << 20) + (unsigned)d - 1u) / (unsigned)d; }
+
+template <int H>
+__device__ __forceinline__ void s_dma_weights(const SLds& L, float* S, const SNet& n, int wave,
+                                              unsigned lane) {
+  const float* __restrict__ W1 = n.param;
+  const float* __restrict__ B1 = W1 + H * n.din;
+  const float* __restrict__ W2 = B1 + H;
+  const float* __restrict__ B2 = W2 + H * H;
+  const float* __restrict__ W3 = B2 + H;
+  const float* __restrict__ B3 = W3 + n.dout * H;
+  const unsigned din = (unsigned)n.din;
+  // W1^T image [dinp][H]: float a = i H + j  <-  W1[j][min(i, din - 1)]
+  for (int t = wave; t < L.dinp * H / 64; t += SNW) {
+    const unsigned a = 64u * t + lane, i = a / H, j = a % H;
+    s_dma64(W1 + j * din + (i < din ? i : din - 1u), S + L.w1t + 64 * t);
+  }
+  // W2 as is, and transposed: w2t[i H + j] = W2[j][i]
+  for (int t = wave; t < H * H / 64; t += SNW) {
+    const unsigned a = 64u * t + lane;
+    s_dma64(W2 + a, S + L.w2 + 64 * t);
+    s_dma64(W2 + (a % H) * H + a / H, S + L.w2t + 64 * t);
+  }
+  const unsigned n3 = (unsigned)(n.dout * H) - 1u;
+  for (int t = wave; t < L.doutp * H / 64; t += SNW) {
+    const unsigned a = 64u * t + lane;
+    s_dma64(W3 + (a < n3 ? a : n3), S + L.w3 + 64 * t);
+  }
+  // (H <= 64, doutp <= 64: one masked chunk each)
+  if (wave == 0 && lane < H) s_dma64(B1 + lane, S + L.b1);
+  if (wave == 1 && lane < H) s_dma64(B2 + lane, S + L.b2);
+  if (wave == 2 && lane < (unsigned)L.doutp)
+    s_dma64(B3 + (lane < (unsigned)n.dout ? lane : (unsigned)n.dout - 1u), S + L.b3);
+}
+// behind the wait for the DMA: the pad rows of W1^T (inputs din .. dinp - 1) are zero
+template <int H>
+__device__ __forceinline__ void s_zero_w1_pad(const SLds& L, float* S, const SNet& n) {
+  for (int e = n.din * H + threadIdx.x; e < L.dinp * H; e += SBT) S[L.w1t + e] = 0.f;
+}
+
+// a tile: x rows into [64][xp] (pad columns: copies of the last input), and --
+// policy -- the old means and the sampled parameters into [k][64]
+template <bool POL, bool ROWMAJOR>
+__device__ __forceinline__ void s_dma_tile(const SLds& L, float* S, const SNet& n,
+                                           const SPolicyHead& ph, int64_t r0, int wave,
+                                           unsigned lane) {
+  const unsigned last = (unsigned)(n.N - r0 < SR ? n.N - r0 : SR) - 1u;   // last valid row of the tile
+  const float* __restrict__ xb = n.x + r0 * n.x_stride;
+  const unsigned stride = (unsigned)n.x_stride, xp = (unsigned)L.xp, cl = (unsigned)n.din - 1u;
+  const unsigned mx = s_magic(L.xp);
+  for (int t = wave; t < L.xp; t += SNW) {                   // 64 xp floats = xp chunks
+    const unsigned a = 64u * t + lane, r = (a * mx) >> 20, c = a - r * xp;
+    s_dma64(xb + (r < last ? r : last) * stride + (c < cl ? c : cl), S + L.xs + 64 * t);
+  }
+  if (POL) {
+    const unsigned K = (unsigned)n.dout;
+    const float* __restrict__ mob = ph.mean_old + r0 * K;
+    const float* __restrict__ acb = ph.actions + r0 * K;
+    const int VS = L.doutp * SR;
+    if (ROWMAJOR) {
+      // the diagonal head reads them as rows: the tile's [64][K] blocks as they are
+      // (coalesced), and logp_old / adv of the rows into slot 4
+      const unsigned top = (last + 1u) * K - 1u;
+      for (int t = wave; t < n.dout; t += SNW) {             // 64 K floats = K chunks
+        const unsigned a = 64u * t + lane, o = a < top ? a : top;
+        s_dma64(mob + o, S + L.vec + VS + 64 * t);
+        s_dma64(acb + o, S + L.vec + 2 * VS + 64 * t);
+      }
+      const unsigned rr = lane < last ? lane : last;
+      if (wave == 3) s_dma64(ph.logp_old + r0 + rr, S + L.vec + 4 * VS);
+      if (wave == 2) s_dma64(ph.adv + r0 + rr, S + L.vec + 4 * VS + SR);
+    } else {
+      const unsigned ro = (lane < last ? lane : last) * K;
+      for (int k = wave; k < n.dout; k += SNW) {
+        s_dma64(mob + ro + k, S + L.vec + VS + k * SR);
+        s_dma64(acb + ro + k, S + L.vec + 2 * VS + k * SR);
+      }
+    }
+  }
+}
+// all LDS-DMA of this wave has landed (the barrier that follows publishes it)
+__device__ __forceinline__ void s_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // forward of the 64 rows of the tile: h1 / h2 (this wave's H/4 units of its
 // lane's row, after the activation) stay in registers for the backward pass,
@@ -621,10 +744,23 @@ __device__ __forceinline__ void s_trimv(float (&out)[NV][KP], const float (&in)[
 // and the triangular solves as products with the explicit inverses of the two
 // shared factors (Li_old = L_old^-1, Li_proj = L_proj^-1, computed once per
 // update / once per epoch in double precision): six small dense layers.
-template <int KP>
+// DG (diagonal factors, the reference's std_only configuration): every product
+// with a factor's inverse is an elementwise product with the reciprocal
+// diagonal (S + L.rdo / L.rdp, zero past K) -- the six dense K x K products
+// were 22 800 of the row kernel's 81 000 cycles at K = 20.
+template <int KP, bool DG>
+__device__ __forceinline__ void s_diag_mv(float* out, const float* in, const float* rd) {
+#pragma unroll
+  for (int q = 0; q < KP; q += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(rd + q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[q + i] = t[i] * in[q + i];
+  }
+}
+template <int KP, bool DG>
 __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyHead& h,
                                          int64_t r0, int64_t N, int K, int lane, float logdet_p,
-                                         double (&sums)[5]) {
+                                         double (&sums)[5] SMLP_HARGS_DECL) {
   const int VS = L.doutp * SR;
   const float* MU = S + L.vec;
   const float* MO = MU + VS;
@@ -644,7 +780,9 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
     d[0][r] = mu[r] - mo[r];
   }
   // z = L_old^-1 (mu - mu_old)
-  s_trimv<KP, 1, true>(z, d, S + L.liot, K);
+  SMLP_TH(1)
+  if (DG) s_diag_mv<KP, DG>(z[0], d[0], S + L.rdo);
+  else s_trimv<KP, 1, true>(z, d, S + L.liot, K);
   float quad = 0.f;
 #pragma unroll
   for (int r = 0; r < KP; ++r) quad += z[0][r] * z[0][r];
@@ -664,13 +802,19 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
     ab[0][r] -= pm;
     ab[1][r] = mu[r] - pm;
   }
-  s_trimv<KP, 2, true>(yw, ab, S + L.lipt, K);
+  if (DG) {
+    s_diag_mv<KP, DG>(yw[0], ab[0], S + L.rdp);
+    s_diag_mv<KP, DG>(yw[1], ab[1], S + L.rdp);
+  } else {
+    s_trimv<KP, 2, true>(yw, ab, S + L.lipt, K);
+  }
   float quady = 0.f, maha2 = 0.f;
 #pragma unroll
   for (int r = 0; r < KP; ++r) {
     quady += yw[0][r] * yw[0][r];
     maha2 += yw[1][r] * yw[1][r];
   }
+  SMLP_TH(2)
   const float logp = -0.5f * quady - logdet_p - S_HALF_LOG_2PI * (float)K;
   const float ratio = expf(logp - lpo);
   const float ra = ratio * adv;
@@ -679,7 +823,12 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
   for (int r = 0; r < KP; ++r)
     if (r < K) S[L.ys + lane * L.gp + r] = yw[0][r];
   // u = L_proj^-T y, q = L_proj^-T w; t = L_old^-T z
-  s_trimv<KP, 2, false>(uq, yw, S + L.lip, K);
+  if (DG) {
+    s_diag_mv<KP, DG>(uq[0], yw[0], S + L.rdp);
+    s_diag_mv<KP, DG>(uq[1], yw[1], S + L.rdp);
+  } else {
+    s_trimv<KP, 2, false>(uq, yw, S + L.lip, K);
+  }
 #pragma unroll
   for (int r = 0; r < KP; ++r)
     if (r < K) S[L.gus + lane * L.gp + r] = g * uq[0][r];
@@ -689,7 +838,8 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
   float t[1][KP];
 #pragma unroll
   for (int r = 0; r < KP; ++r) t[0][r] = 0.f;
-  if (__builtin_amdgcn_ballot_w64(active) != 0)        // no row of the wave projected: skip
+  if (DG) s_diag_mv<KP, DG>(t[0], z[0], S + L.rdo);
+  else if (__builtin_amdgcn_ballot_w64(active) != 0)   // no row of the wave projected: skip
     s_trimv<KP, 1, false>(t, z, S + L.lio, K);
   const float coef = active ? gd / (2.f * h.eps_mean * sc * sc * sc) : 0.f;
   const float trc = rok ? h.tr_coeff / (float)N : 0.f;
@@ -703,12 +853,124 @@ __device__ inline void s_policy_head_reg(const SLds& L, float* S, const SPolicyH
       S[L.g3s + lane * L.gp + r] = gm;
     }
   }
+  SMLP_TH(3)
   const double f = rok ? 1.0 : 0.0;
   sums[0] = wave_sum_f64(f * (double)ra);
   sums[1] = wave_sum_f64(f * (double)ratio);
   sums[2] = wave_sum_f64(f * (double)quad);
   sums[3] = wave_sum_f64(f * (double)maha2);
   sums[4] = wave_sum_f64(f * (double)quad / ((double)den * (double)den));
+  SMLP_TH(4)
+}
+
+// Diagonal factors, ALL FOUR waves: wave w takes rows 16 w .. 16 w + 15 of the
+// tile, lane = (row, k-group kg = lane / 16) with the elements k = kg + 4 j,
+// j < KP / 4; a sum over k is a sum over a lane's elements and over the four
+// lanes of a row (two cross-lane steps).  One wave walking all K elements of
+// its 64 rows was issue-bound: 11 600 of the row kernel's 56 000 cycles, with
+// three waves waiting at the barrier.  Inputs: MU [k][64] (the forward pass),
+// MO / AC row-major [64][K] and logp_old / adv in slot 4 (s_dma_tile); the
+// gradient goes to slot 3 as [k][64] for the backward pass (not over AC: other
+// waves still read their rows of it).  part: [SNW][5] doubles, the waves' sums.
+template <int KP>
+__device__ inline void s_policy_head_diag(const SLds& L, float* S, const SPolicyHead& h,
+                                          int64_t r0, int64_t N, int K, int lane, int wave,
+                                          float logdet_p, double* part) {
+  constexpr int KQ = KP / 4;
+  const int VS = L.doutp * SR;
+  const float* MU = S + L.vec;
+  const float* MO = MU + VS;
+  const float* AC = MU + 2 * VS;
+  float* G = S + L.vec + 3 * VS;
+  const int rt = 16 * wave + (lane & 15), kg = lane >> 4;
+  const int64_t row = r0 + rt;
+  const bool rok = row < N;
+  const float lpo = S[L.vec + 4 * VS + rt], adv = S[L.vec + 4 * VS + SR + rt];
+  auto ksum = [](float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  };
+  float mu[KQ], mo[KQ], ac[KQ], ro[KQ], rp[KQ], d[KQ], z[KQ];
+  bool live[KQ];
+  float quad = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) {
+    const int k = kg + 4 * j;
+    live[j] = k < K;
+    const int kk = live[j] ? k : K - 1;
+    const float lv = live[j] ? 1.f : 0.f;
+    mu[j] = lv * MU[kk * SR + rt];
+    mo[j] = lv * MO[rt * K + kk];
+    ac[j] = lv * AC[rt * K + kk];
+    ro[j] = S[L.rdo + k];                           // (zero past K)
+    rp[j] = S[L.rdp + k];
+    d[j] = mu[j] - mo[j];
+    z[j] = d[j] * ro[j];                            // z = L_old^-1 (mu - mu_old)
+    quad += z[j] * z[j];
+  }
+  quad = ksum(quad);
+  const float m = 0.5f * quad;
+  const bool active = m > h.eps_mean;
+  const float sc = active ? sqrtf(m / h.eps_mean) : 1.f;
+  const float om = sc - 1.f;
+  const float den = 1.f + om + 1e-16f;
+  float y[KQ], w[KQ];
+  float quady = 0.f, maha2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) {
+    const int k = kg + 4 * j;
+    const float pm = active ? (mu[j] + om * mo[j]) / den : mu[j];
+    if (live[j] && rok) {
+      if (h.pmean_out) h.pmean_out[row * K + k] = pm;
+      if (h.mean_out) h.mean_out[row * K + k] = mu[j];
+    }
+    y[j] = (ac[j] - pm) * rp[j];                    // y = L_proj^-1 (a - proj_mean)
+    w[j] = (mu[j] - pm) * rp[j];                    // w = L_proj^-1 (mu - proj_mean)
+    quady += y[j] * y[j];
+    maha2 += w[j] * w[j];
+  }
+  quady = ksum(quady);
+  maha2 = ksum(maha2);
+  const float logp = -0.5f * quady - logdet_p - S_HALF_LOG_2PI * (float)K;
+  const float ratio = expf(logp - lpo);
+  const float ra = ratio * adv;
+  const float g = rok ? -ra / (float)N : 0.f;
+  float gu[KQ];
+  float gd = 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) {
+    const int k = kg + 4 * j;
+    gu[j] = g * (y[j] * rp[j]);                     // g u, u = L_proj^-T y
+    gd += gu[j] * d[j];
+    if (live[j]) {
+      S[L.ys + rt * L.gp + k] = y[j];
+      S[L.gus + rt * L.gp + k] = gu[j];
+    }
+  }
+  gd = ksum(gd);
+  const float coef = active ? gd / (2.f * h.eps_mean * sc * sc * sc) : 0.f;
+  const float trc = rok ? h.tr_coeff / (float)N : 0.f;
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) {
+    const int k = kg + 4 * j;
+    if (live[j]) {
+      float gm = active ? gu[j] / sc - coef * (z[j] * ro[j]) : gu[j];   // t = L_old^-T z
+      gm += trc * (w[j] * rp[j]);                                       // q = L_proj^-T w
+      G[k * SR + rt] = gm;
+      S[L.g3s + rt * L.gp + k] = gm;
+    }
+  }
+  const double f = rok && kg == 0 ? 1.0 : 0.0;
+  const double s0 = wave_sum_f64(f * (double)ra);
+  const double s1 = wave_sum_f64(f * (double)ratio);
+  const double s2 = wave_sum_f64(f * (double)quad);
+  const double s3 = wave_sum_f64(f * (double)maha2);
+  const double s4 = wave_sum_f64(f * (double)quad / ((double)den * (double)den));
+  if (lane == 0) {
+    double* p = part + 5 * wave;
+    p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3; p[4] = s4;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -737,25 +999,33 @@ __host__ __device__ inline int s_forward_lds_floats(int din, int H, int dout) {
   return L.vec + s_up4(dout) * SR + 16;
 }
 
-#ifdef SMLP_STAMP
-#define SMLP_T0() long long t0_ = __builtin_readcyclecounter(); long long stamp_[5] = {0, 0, 0, 0, 0};
-#define SMLP_T(k) { const long long tn_ = __builtin_readcyclecounter(); stamp_[k] += tn_ - t0_; t0_ = tn_; }
-#else
-#define SMLP_T0()
-#define SMLP_T(k)
-#endif
-
-template <int H, int ACT, int HEAD, int KP>
+template <int H, int ACT, int HEAD, int KP, bool DG>
 __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, SPolicyHead ph,
                                                         SReduce rd) {
   extern __shared__ __attribute__((aligned(16))) float S[];
   const SLds L = s_lds(n.din, H, n.dout, HEAD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = n.dout;
+  constexpr bool POL = HEAD == HEAD_BB_POLICY;
   SMLP_T0()
-  s_load_weights<H>(L, S, n);
+  // weights, the first tile and (diagonal factors) the two diagonals: one round trip
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  s_dma_weights<H>(L, S, n, wave_u, (unsigned)lane);
+  s_dma_tile<POL, POL && DG>(L, S, n, ph, (int64_t)blockIdx.x * SR, wave_u, (unsigned)lane);
   float logdet_p = 0.f;
-  if (HEAD == HEAD_BB_POLICY) {
+  float dol = 1.f, dpl = 1.f;
+  if (POL && DG && lane < K) {                         // (every wave runs the head)
+    dol = ph.L_old[lane * K + lane];
+    dpl = ph.L_proj[lane * K + lane];
+  }
+  if (POL && DG) {
+    if (tid < KP) {
+      S[L.rdo + tid] = tid < K ? 1.f / dol : 0.f;
+      S[L.rdp + tid] = tid < K ? 1.f / dpl : 0.f;
+    }
+    logdet_p = wave_sum(lane < K ? logf(dpl) : 0.f);
+  }
+  if (POL && !DG) {
     const int LP = s_kpad(K);
     for (int e = tid; e < LP * LP; e += SBT) {
       const int i = e / LP, j = e - i * LP;
@@ -784,31 +1054,35 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
   double acc_d[5] = {0, 0, 0, 0, 0};
   bool first = true;
   float* vecs = S + L.vec;
+  s_dma_wait();
+  s_zero_w1_pad<H>(L, S, n);
   for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < n.N; r0 += (int64_t)gridDim.x * SR) {
-    __syncthreads();
-    s_load_x(L, S, n, r0);
-    if (HEAD == HEAD_BB_POLICY) {
-      const int VS = L.doutp * SR;
-      for (int e = tid; e < SR * K; e += SBT) {
-        const int r = e / K, k = e - r * K;
-        const int64_t row = r0 + r < n.N ? r0 + r : n.N - 1;
-        vecs[VS + k * SR + r] = ph.mean_old[row * K + k];
-        vecs[2 * VS + k * SR + r] = ph.actions[row * K + k];
-      }
+    if (!first) {
+      __syncthreads();
+      s_dma_tile<POL, POL && DG>(L, S, n, ph, r0, wave_u, (unsigned)lane);
+      s_dma_wait();
     }
     __syncthreads();
     float h1[H / SNW], h2[H / SNW];
     SMLP_T(0)
     s_forward<H, ACT>(L, S, K, lane, wave, h1, h2, vecs, n.act);
-    SMLP_T(1)
+    SMLP_TK(1)
+    SMLP_TH(0)
     const float* g;
     if (HEAD == HEAD_VALUE) {
       if (wave == 0) acc_d[0] += s_value_head(L, S, vh, r0, n.N, lane, vecs, vecs + SR);
       g = vecs + SR;
+    } else if (DG) {
+      // (the K x K image slots are free with diagonal factors: the waves' sums)
+      double* part = reinterpret_cast<double*>(S + L.lo);
+      s_policy_head_diag<(KP > 0 ? KP : 4)>(L, S, ph, r0, n.N, K, lane, wave, logdet_p, part);
+      g = vecs + 3 * L.doutp * SR;
     } else {
       if (wave == 0) {
         double s5[5];
-        if (KP > 0) s_policy_head_reg<(KP > 0 ? KP : 4)>(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
+        if (KP > 0)
+          s_policy_head_reg<(KP > 0 ? KP : 4), false>(L, S, ph, r0, n.N, K, lane, logdet_p,
+                                                      s5 SMLP_HARGS);
         else s_policy_head(L, S, ph, r0, n.N, K, lane, logdet_p, s5);
 #pragma unroll
         for (int i = 0; i < 5; ++i) acc_d[i] += s5[i];
@@ -816,13 +1090,20 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
       g = vecs + 2 * L.doutp * SR;                     // AC slot
     }
     __syncthreads();
-    SMLP_T(2)
+    if (POL && DG && tid == 0) {
+      const double* part = reinterpret_cast<const double*>(S + L.lo);
+#pragma unroll
+      for (int w = 0; w < SNW; ++w)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc_d[i] += part[5 * w + i];
+    }
+    SMLP_TK(2)
     s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g, n.act);
-    SMLP_T(3)
+    SMLP_TK(3)
     s_param_grads<H>(L, S, n.din, K, slab, !first,
                      HEAD == HEAD_BB_POLICY ? slab + rd.P : nullptr);
     first = false;
-    SMLP_T(4)
+    SMLP_TK(4)
   }
   if (tid == 0) {
 #pragma unroll
@@ -1287,13 +1568,13 @@ inline size_t s_lds_bytes(int din, int H, int dout, int head) {
   return sizeof(float) * (size_t)s_lds(din, H, dout, head).total;
 }
 
-template <int H, int ACT, int HEAD, int KP>
+template <int H, int ACT, int HEAD, int KP, bool DG = false>
 int s_launch_epoch(const SNet& n, const SValueHead& vh, const SPolicyHead& ph, const SReduce& rd,
                    hipStream_t st) {
   const size_t lds = s_lds_bytes(n.din, H, n.dout, HEAD);
-  tce_lds_limit(reinterpret_cast<const void*>(smlp_epoch_kernel<H, ACT, HEAD, KP>), lds);
-  hipLaunchKernelGGL((smlp_epoch_kernel<H, ACT, HEAD, KP>), dim3(s_grid(n.N)), dim3(SBT), lds, st,
-                     n, vh, ph, rd);
+  tce_lds_limit(reinterpret_cast<const void*>(smlp_epoch_kernel<H, ACT, HEAD, KP, DG>), lds);
+  hipLaunchKernelGGL((smlp_epoch_kernel<H, ACT, HEAD, KP, DG>), dim3(s_grid(n.N)), dim3(SBT), lds,
+                     st, n, vh, ph, rd);
   TCE_LAUNCH_CHECK();
   return 0;
 }
@@ -1310,11 +1591,18 @@ int s_dispatch_value(int H, int act, const SNet& n, const SValueHead& vh, const 
   tce_set_error("smlp: unsupported hidden width / activation");
   return 1;
 }
-int s_dispatch_policy(int H, const SNet& n, const SPolicyHead& ph, const SReduce& rd,
+int s_dispatch_policy(int H, const SNet& n, const SPolicyHead& ph, const SReduce& rd, bool diag,
                       hipStream_t st) {
   const SValueHead vh{};
   const int K = n.dout;
   const int kp = K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : K <= 32 ? 32 : 0;
+  // diagonal factors (K <= 32): the head without the K x K images
+#define S_CASE(HH, KK) \
+  if (diag && H == HH && kp == KK) \
+    return s_launch_epoch<HH, ACT_RT, HEAD_BB_POLICY, KK, true>(n, vh, ph, rd, st);
+  S_CASE(32, 8) S_CASE(32, 16) S_CASE(32, 24) S_CASE(32, 32)
+  S_CASE(64, 8) S_CASE(64, 16) S_CASE(64, 24) S_CASE(64, 32)
+#undef S_CASE
 #define S_CASE(HH, KK) \
   if (H == HH && kp == KK) return s_launch_epoch<HH, ACT_RT, HEAD_BB_POLICY, KK>(n, vh, ph, rd, st);
   S_CASE(32, 8) S_CASE(32, 16) S_CASE(32, 24) S_CASE(32, 32) S_CASE(32, 0)
@@ -1394,7 +1682,7 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
   TCE_CHECK_ARG(!(clip_critic > 0.f) || old_values, "smlp_critic_epochs: old values missing");
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "smlp_critic_epochs: optimizer state missing");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, 1, HEAD_VALUE), "smlp_critic_epochs: unsupported shape");
-  TCE_CHECK_ARG(x_stride >= din, "smlp_critic_epochs: row stride < din");
+  TCE_CHECK_ARG(x_stride >= din && x_stride < (1 << 24), "smlp_critic_epochs: row stride outside [din, 2^24)");
   TCE_CHECK_ARG(do_adam || epochs == 1, "smlp_critic_epochs: epochs > 1 needs the Adam step");
   hipStream_t st = (hipStream_t)stream;
   const SNet n{x, x_stride, N, din, 1, param, act};
@@ -1446,7 +1734,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   TCE_CHECK_ARG(nvec == K || nvec == K + K * (K - 1) / 2, "bb_policy_epochs: bad variance vector");
   TCE_CHECK_ARG(!diag || (nvec == K && beta == nullptr),
                 "bb_policy_epochs: the diagonal path needs std_only and no entropy bound");
-  TCE_CHECK_ARG(x_stride >= din, "bb_policy_epochs: row stride < din");
+  TCE_CHECK_ARG(x_stride >= din && x_stride < (1 << 24), "bb_policy_epochs: row stride outside [din, 2^24)");
   TCE_CHECK_ARG(do_adam || epochs == 1, "bb_policy_epochs: epochs > 1 needs the Adam step");
   hipStream_t st = (hipStream_t)stream;
   const int P = s_nparams(din, H, K);
@@ -1502,7 +1790,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                          eps_mean, tr_coeff,
                          ent_coef, lastep ? mean_new_out : nullptr,
                          lastep ? proj_mean_out : nullptr};
-    rc = s_dispatch_policy(H, n, ph, rd, st);
+    rc = s_dispatch_policy(H, n, ph, rd, diag != 0, st);
     if (rc) return rc;
     SFinish f{};
     f.slabs = rd.slabs; f.dpart = rd.dpart; f.nparts = g; f.PS = rd.PS; f.P = P; f.KK = K * K;
