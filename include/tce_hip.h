@@ -188,6 +188,11 @@ int tce_set_cu_budget(int compute_units);
  * register form built for the shipped (dof, num_basis + 1) combinations
  * (4, 6), (4, 9), (7, 9), (7, 4); default 1.  For A / B runs and tests. */
 int tce_pair_env_static(int on);
+/* on = 1: tce_bb_policy_epochs_f32 ends every epoch with its general finish
+ * kernel also for diagonal factors (default 0: the single-round-trip kernel
+ * written for them, bb_diag_finish_kernel in csrc/smlp.hip).  For A / B runs
+ * and tests; results agree to rounding. */
+void tce_bb_finish_general(int on);
 /* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
  * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M);

@@ -522,6 +522,83 @@ __device__ inline void s_outer_block(const float* A, int pa, const float* B, int
     }
 }
 
+// The same sums on the matrix cores (exact fp32 MFMA 16x16x4): unit = (weight
+// matrix, block of 16 of its rows); per four tile rows one A fragment
+// (A[r][m0 + i], a ds_read_b32 per lane), up to four B fragments and as many
+// MFMAs, plus one MFMA against a fragment of ones -- the bias gradient (column
+// sums of A) for free.  Fragments past a matrix's columns read whatever
+// follows in the LDS (initialised tiles: finite) into outputs that are never
+// stored.  The waves take the units in turn.  As 4 x 4 register blocks per
+// thread (above) the pass was 1024 FMAs + 128 LDS reads per thread: 12 000 -
+// 14 000 of the row kernel's cycles; this is ~3 000.
+typedef float s_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s_grad_unit(const float* A, int pa, const float* B, int pb, int M,
+                                            int N, int m0, float* gW, float* gB, bool accumulate,
+                                            int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  const int NT = (N + 15) >> 4;                               // <= 4
+  s_f32x4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (s_f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* a = A + lk * pa + m0 + li;
+  const float* b = B + lk * pb + li;
+#pragma unroll 4
+  for (int r = 0; r < SR; r += 4) {
+    const float av = a[r * pa];
+    float bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[t] = t < NT ? b[r * pb + 16 * t] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+    if (gB) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.f, accb, 0, 0, 0);
+  }
+  // D: register i of lane l = D[4 (l / 16) + i][l % 16]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * lk + i;
+    if (m < M) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int col = 16 * t + li;
+        if (t < NT && col < N) {
+          float* dst = gW + m * N + col;
+          *dst = accumulate ? *dst + acc[t][i] : acc[t][i];
+        }
+      }
+      if (gB && li == 0) gB[m] = accumulate ? gB[m] + accb[i] : accb[i];
+    }
+  }
+}
+template <int H>
+__device__ inline void s_param_grads_mfma(const SLds& L, const float* S, int din, int dout,
+                                          float* slab, bool accumulate, float* gpl, int wave,
+                                          int lane) {
+  float* gW1 = slab;
+  float* gB1 = gW1 + H * din;
+  float* gW2 = gB1 + H;
+  float* gB2 = gW2 + H * H;
+  float* gW3 = gB2 + H;
+  float* gB3 = gW3 + dout * H;
+  constexpr int MH = H / 16;                                  // row blocks of W1 / W2
+  const int M3 = (dout + 15) >> 4;                            // of W3 / the K x K sum
+  // units in an order that spreads the long ones (W1: up to 4 + 1 MFMAs per step)
+  const int nu = 2 * MH + M3 + (gpl ? M3 : 0);
+  for (int u = wave; u < nu; u += SNW) {
+    if (u < MH)
+      s_grad_unit(S + L.d1s, L.hp, S + L.xs, L.xp, H, din, 16 * u, gW1, gB1, accumulate, lane);
+    else if (u < MH + M3 && gpl)
+      s_grad_unit(S + L.gus, L.gp, S + L.ys, L.gp, dout, dout, 16 * (u - MH), gpl, nullptr,
+                  accumulate, lane);
+    else if (u < 2 * MH + (gpl ? M3 : 0))
+      s_grad_unit(S + L.d2s, L.hp, S + L.h1s, L.hp, H, H, 16 * (u - MH - (gpl ? M3 : 0)), gW2,
+                  gB2, accumulate, lane);
+    else
+      s_grad_unit(S + L.g3s, L.gp, S + L.h2s, L.hp, dout, H, 16 * (u - 2 * MH - (gpl ? M3 : 0)),
+                  gW3, gB3, accumulate, lane);
+  }
+}
+
 // the weight / bias gradients of the tile into `slab` (accumulate: a later
 // tile of the same workgroup adds to it)
 template <int H>
@@ -1100,8 +1177,13 @@ __global__ __launch_bounds__(SBT) void smlp_epoch_kernel(SNet n, SValueHead vh, 
     SMLP_TK(2)
     s_backward<H, ACT>(L, S, K, lane, wave, h1, h2, g, n.act);
     SMLP_TK(3)
+#ifdef SMLP_GRADS_VALU
     s_param_grads<H>(L, S, n.din, K, slab, !first,
                      HEAD == HEAD_BB_POLICY ? slab + rd.P : nullptr);
+#else
+    s_param_grads_mfma<H>(L, S, n.din, K, slab, !first,
+                          HEAD == HEAD_BB_POLICY ? slab + rd.P : nullptr, wave_u, lane);
+#endif
     first = false;
     SMLP_TK(4)
   }
@@ -1473,6 +1555,234 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
   }
 }
 
+// The finish of an epoch with DIAGONAL factors and the Adam step, written for
+// the length of its dependent chain (bb_policy_finish_kernel above is general
+// and, at 21 us per call, was the second longest link of a black-box epoch: six
+// barrier-separated passes, each a round trip to memory, and a bracket + Newton
+// search of ~10 double-precision steps):
+//  * everything the kernel reads -- the gradient, the parameters, both
+//    moments, the K-vectors -- is requested at the top: ONE round trip;
+//  * the gradient and the parameters stay in registers from the norm to the
+//    Adam step; the new variance parameters go from the Adam step to the next
+//    epoch's projection in wave 0's registers;
+//  * the multiplier eta of the covariance projection by Newton steps on
+//    h(eta)^-1/2 - eps^-1/2 (nearly linear in eta: 2 - 4 steps from eta = 0,
+//    no bracket search), safeguarded by the interval the signs have shown;
+//  * the next epoch's matrices: only their diagonals are rewritten (the first
+//    launch of the update, bb_diag_fwd_kernel, has zeroed the rest).
+// P <= 256 * FD_NPT.  Same record row, state vector and out16 as the
+// general kernel.
+// (NPT: parameters per thread.  The loads are unconditional with clamped
+// addresses and the values selected afterwards: element assignments under a
+// branch make the compiler copy the whole register array at every step.)
+constexpr int FD_NPT = 16;
+template <int NPT>
+__global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
+    const float* __restrict__ g_pL, const float* __restrict__ gL_tr,
+    const float* __restrict__ L_proj, const float* __restrict__ L_old,
+    const double* __restrict__ dctx, const double* __restrict__ dsum, int64_t N, int K, int P,
+    float tr_coeff, int include_cov, float ent_coef, float* __restrict__ param,
+    float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ state, float lr, float b1, float b2, float eps, float wd, float clip_grad,
+    float gscale, float* __restrict__ out16, float* __restrict__ rec, int next_fwd, float min_std,
+    double eps_cov, float* __restrict__ L_new_w, float* __restrict__ L_proj_w,
+    float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w, double* __restrict__ dctx_w) {
+  __shared__ float red[SNW];
+  __shared__ float coef_s;
+  const int tid = threadIdx.x;
+  // ---- requests
+  float gr[NPT], pw[NPT], pm[NPT], pv[NPT];
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int p = tid + q * SBT, pc = p < P ? p : P - 1;
+    const float g0 = grad[pc];
+    gr[q] = p < P ? g0 : 0.f;
+    pw[q] = param[pc];
+    pm[q] = m[pc];
+    pv[q] = v[pc];
+  }
+  const bool w0 = tid < 64, live = tid < K;
+  const int kk = live ? tid * K + tid : 0;
+  float gp_raw = 0.f, gtr = 0.f, lpj = 1.f, so_f = 1.f, var = 0.f, mv = 0.f, vv = 0.f;
+  double lam = 1, mu = 1, eta = 0, act_d = 0, ds0 = 0, ds2 = 0, ds3 = 0, ds4 = 0;
+  float o5 = 0.f, o12 = 0.f;
+  const float step = state[0] + 1.f;
+  if (w0) {
+    if (live) {
+      gp_raw = g_pL[kk];
+      gtr = gL_tr[kk];
+      lpj = L_proj[kk];
+      so_f = L_old[kk];
+      lam = dctx[tid];
+      mu = dctx[K + tid];
+      var = param[P + tid];
+      mv = m[P + tid];
+      vv = v[P + tid];
+    }
+    eta = dctx[2 * K];
+    act_d = dctx[2 * K + 1];
+    ds0 = dsum[0]; ds2 = dsum[2]; ds3 = dsum[3]; ds4 = dsum[4];
+    o5 = out16[5];
+    o12 = out16[12];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const double invN = 1.0 / (double)N;
+  // ---- wave 0: d / d L_proj on the diagonal, projection backward, Cholesky head backward
+  float gvar = 0.f;
+  if (w0) {
+    const float sum_g = (float)(-ds0 * invN);
+    const bool active = act_d != 0.0;
+    double gpd = 0, gmu = 0, dl = 0, de = 0, hm = 0, scale = 0;
+    if (live) {
+      gpd = (double)(gp_raw - (sum_g + ent_coef) / lpj);
+      if (active) {
+        const double so = (double)so_f, pl = (double)lpj;
+        const double w = 1.0 / (eta * lam + 1.0);
+        gmu = gpd * pl / (2.0 * mu);
+        dl = (eta + 1.0) * w * w;
+        de = lam * (1.0 - lam) * w * w;
+        hm = 0.5 * (1.0 - 1.0 / mu);
+        scale = 2.0 * sqrt(lam) / so;
+      }
+    }
+    const double h_eta = wave_sum_f64(hm * de);
+    const double gde = wave_sum_f64(gmu * de);
+    double gs = gpd;
+    if (active) gs = (gmu * dl - gde * (hm * dl) / h_eta) * scale;
+    if (live) {
+      const float sig = var > 20.f ? 1.f : 1.f / (1.f + expf(-var));
+      gvar = (gtr + (float)gs) * sig;
+      grad[P + tid] = gvar;
+    }
+  }
+  // ---- global norm, clip factor
+  float sq = gvar * gvar;
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) sq += gr[q] * gr[q];
+  sq = block_sum(sq, red);
+  const float before = sqrtf(sq) * gscale;
+  float cf = 1.f;
+  if (clip_grad > 0.f) cf = fminf(clip_grad / (before + 1e-6f), 1.f);
+  const float coef = cf * gscale;
+  if (tid == 0) {
+    state[0] = step;
+    state[1] = before;
+    state[2] = before * cf;
+    state[3] = coef;
+    double mp1 = 0;
+    const double dsq[3] = {ds2, ds3, ds4};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double mp = 0.5 * dsq[q] * invN;
+      out16[4 * q] = (float)mp;
+      if (q == 1) mp1 = mp;
+    }
+    const double tr = (double)tr_coeff * (mp1 + (include_cov ? (double)o5 : 0.0));
+    out16[13] = (float)tr;
+    const float sur = (float)(-ds0 * invN);
+    const float entl = ent_coef == 0.f ? 0.f : -ent_coef * o12;
+    rec[0] = sur;
+    rec[1] = entl;
+    rec[2] = (float)tr;
+    rec[3] = ent_coef == 0.f ? sur + (float)tr : sur + (float)tr + entl;
+    rec[4] = o12;
+    rec[5] = before;
+    rec[6] = before * cf;
+  }
+  // ---- Adam on the registers
+  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
+  const float step_size = lr / bc1;
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int p = tid + q * SBT;
+    float g = gr[q] * coef;
+    if (wd != 0.f) g += wd * pw[q];
+    const float mi = b1 * pm[q] + (1.f - b1) * g;
+    const float vi = b2 * pv[q] + (1.f - b2) * g * g;
+    const float wn = pw[q] - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    if (p < P) {
+      param[p] = wn;
+      m[p] = mi;
+      v[p] = vi;
+    }
+  }
+  if (!w0) return;
+  float var_n = var;
+  if (live) {
+    float g = gvar * coef;
+    if (wd != 0.f) g += wd * var;
+    mv = b1 * mv + (1.f - b1) * g;
+    vv = b2 * vv + (1.f - b2) * g * g;
+    var_n = var - step_size * mv / (sqrtf(vv) / bc2s + eps);
+    param[P + tid] = var_n;
+    m[P + tid] = mv;
+    v[P + tid] = vv;
+  }
+  if (!next_fwd) return;
+  // ---- the next epoch's Cholesky head and covariance projection (wave 0)
+  double sig = 1, so = 1;
+  if (live) {
+    sig = (double)((var_n > 20.f ? var_n : log1pf(expf(var_n))) + min_std);
+    so = (double)so_f;
+  }
+  const double a = sig / so, lm = a * a;
+  const double kl0 = 0.5 * wave_sum_f64(live ? lm - 1.0 - log(lm) : 0.0);
+  const bool act_n = kl0 > eps_cov;
+  double eta_n = 0, mu_n = lm;
+  if (act_n) {
+    double lo = 0.0, hi = -1.0;                          // hi < 0: no upper end seen yet
+#pragma unroll 1
+    for (int it = 0; it < 60; ++it) {
+      double t = 0, dt = 0;
+      if (live) {
+        const double w = 1.0 / (eta_n * lm + 1.0);
+        const double m_ = (eta_n + 1.0) * lm * w;
+        t = m_ - 1.0 - log(m_);
+        dt = (1.0 - 1.0 / m_) * lm * (1.0 - lm) * w * w;
+      }
+      const double h = 0.5 * wave_sum_f64(t), dh = 0.5 * wave_sum_f64(dt);
+      if (h > eps_cov) lo = eta_n; else hi = eta_n;
+      if (fabs(h - eps_cov) <= 1e-11 * eps_cov) break;
+      double nxt = eta_n + 2.0 * h * (1.0 - sqrt(h / eps_cov)) / dh;
+      if (!(nxt > lo && (hi < 0.0 || nxt < hi))) nxt = hi < 0.0 ? 2.0 * lo + 1.0 : 0.5 * (lo + hi);
+      const bool done = fabs(nxt - eta_n) <= 1e-11 * fabs(nxt);
+      eta_n = nxt;
+      if (done) break;
+    }
+    mu_n = (eta_n + 1.0) * lm / (eta_n * lm + 1.0);
+  }
+  const double pl = act_n ? so * sqrt(mu_n) : sig;
+  if (live) {
+    L_new_w[kk] = (float)sig;
+    L_proj_w[kk] = (float)pl;
+    Li_proj_w[kk] = 1.f / (float)pl;
+    gL_tr_w[kk] = include_cov ? (float)((double)tr_coeff * (sig / (pl * pl) - 1.0 / sig)) : 0.f;
+    dctx_w[tid] = lm;
+    dctx_w[K + tid] = mu_n;
+  }
+  const double r0 = sig / so, r1 = sig / pl, r2 = pl / so;
+  const double f0 = wave_sum_f64(live ? r0 * r0 : 0.0), l0 = wave_sum_f64(live ? log(r0) : 0.0);
+  const double f1 = wave_sum_f64(live ? r1 * r1 : 0.0), l1 = wave_sum_f64(live ? log(r1) : 0.0);
+  const double f2 = wave_sum_f64(live ? r2 * r2 : 0.0), l2 = wave_sum_f64(live ? log(r2) : 0.0);
+  const double lpld = wave_sum_f64(live ? log(pl) : 0.0);
+  if (tid == 0) {
+    const double f[3] = {f0, f1, f2}, l[3] = {l0, l1, l2};
+    for (int q = 0; q < 3; ++q) {
+      const double shape = 0.5 * (f[q] - (double)K), volume = -l[q];
+      out16[4 * q + 0] = 0.f;
+      out16[4 * q + 1] = (float)(shape + volume);
+      out16[4 * q + 2] = (float)shape;
+      out16[4 * q + 3] = (float)volume;
+    }
+    out16[12] = (float)(0.5 * (double)K * (1.0 + 1.8378770664093453) + lpld);
+    out16[13] = 0.f;
+    out16[14] = 0.f;
+    out16[15] = 0.f;
+    dctx_w[2 * K] = eta_n;
+    dctx_w[2 * K + 1] = act_n ? 1.0 : 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Skinny linear layer on rows: y [N][dout] = x [N][din] A (+ b), A = W^T for a
 // torch Linear weight W [dout][din] (forward of an output layer) or A = W for
@@ -1715,6 +2025,10 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
   return 0;
 }
 
+// (tests: the general finish kernel for diagonal factors too)
+static int g_bb_finish_general = 0;
+void tce_bb_finish_general(int on) { g_bb_finish_general = on; }
+
 int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* actions,
                              const float* logp_old, const float* adv, const float* mean_old,
                              const float* L_old, int64_t N, int din, int H, int K, int act,
@@ -1806,6 +2120,22 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
       TCE_LAUNCH_CHECK();
       rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
       if (rc) return rc;
+    }
+    if (diag && do_adam && P <= SBT * FD_NPT && !g_bb_finish_general) {
+      const int npt = (P + SBT - 1) / SBT;
+#define FD_LAUNCH(NN)                                                                             \
+  hipLaunchKernelGGL(bb_diag_finish_kernel<NN>, dim3(1), dim3(SBT), 0, st, g_pL, gL_tr, L_proj,   \
+                     L_old, proj_ctx, dsum, N, K, P, tr_coeff, tr_include_cov, ent_coef, param,   \
+                     grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,       \
+                     grad_scale, out16, rec + 7 * e, chained && !lastep ? 1 : 0, min_std, eps_cov, \
+                     L_new, L_proj, Li_proj, gL_tr, proj_ctx)
+      if (npt <= 4) FD_LAUNCH(4);
+      else if (npt <= 8) FD_LAUNCH(8);
+      else if (npt <= 12) FD_LAUNCH(12);
+      else FD_LAUNCH(16);
+#undef FD_LAUNCH
+      TCE_LAUNCH_CHECK();
+      continue;
     }
     hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 1, diag, g_pL, gL_tr,
                        gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff, tr_include_cov,

@@ -134,14 +134,24 @@ def test_critic_epochs_are_deterministic():
     assert torch.equal(*outs)
 
 
+@pytest.fixture
+def general_finish():
+    """tce_bb_finish_general(1) for the test, the default back afterwards."""
+    from tce_rl_amd import _lib
+    lib = _lib.load()
+    lib.tce_bb_finish_general(1)
+    yield
+    lib.tce_bb_finish_general(0)
+
+
 @pytest.mark.parametrize("std_only,K,H,din,N,ent,set_var", [
     (True, 20, 32, 39, 300, 0.0, True), (False, 12, 32, 39, 130, 0.01, False),
     (False, 12, 64, 16, 64, 0.0, False), (True, 6, 32, 9, 4096, 0.0, False),
     (False, 33, 32, 39, 77, 0.0, False)])
-@pytest.mark.parametrize("diag_kernels", [True, False])
+@pytest.mark.parametrize("diag_kernels", [True, False, "general_finish"])
 def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
                                                set_var, diag_kernels,
-                                               monkeypatch):
+                                               monkeypatch, request):
     """E policy epochs on the row kernels == E epochs built from the CPU
     oracle's pieces (oracle/kl_oracle.py project / trust_region_loss,
     oracle/tce_oracle.py mvn_log_prob / surrogate_loss) with torch autograd
@@ -153,6 +163,11 @@ def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
     from tce_rl_amd.rl.policy import BlackBoxPolicy
     from tce_rl_amd.rl import projection_factory
     E, act = 3, "relu"
+    if diag_kernels == "general_finish":
+        # the diagonal row kernels with the general finish kernel behind them
+        if not std_only:
+            pytest.skip("full factors always take the general finish kernel")
+        request.getfixturevalue("general_finish")
     if not diag_kernels:
         if not std_only:
             pytest.skip("full factors always take the K x K kernels")
