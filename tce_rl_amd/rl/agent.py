@@ -13,6 +13,7 @@ optimizer step and divided by the world size (local losses are means over the
 local shard, shards are equal, so this equals the reference's global mean);
 advantage statistics are merged over ranks before normalisation.
 """
+import os
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -316,7 +317,8 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.critic_arith = kwargs.get("critic_arith", "f32")
         if self.critic_arith not in ("f32", "f16x2"):
             raise NotImplementedError("critic_arith %r" % (self.critic_arith,))
-        self.critic_workgroups = int(kwargs.get("critic_workgroups", 224))
+        self.critic_workgroups = int(kwargs.get(
+            "critic_workgroups", os.environ.get("TCE_CRITIC_WORKGROUPS", 224)))
         self.critic_cus_per_xcd = kwargs.get("critic_cus_per_xcd", None)
         self.adaptive_critic_split = kwargs.get("adaptive_critic_split", True)
         # step() returns its metrics as util.LazyMetrics (filled on first
@@ -324,7 +326,6 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # host prepares the next rollout meanwhile (overlapped updates, one
         # process; otherwise the metrics are read before step() returns)
         # (TCE_LAZY_METRICS=0: the default of this option, for A / B runs)
-        import os
         self.lazy_metrics = kwargs.get(
             "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
         self._lazy_done = []            # end-of-step events of the last steps
@@ -682,7 +683,6 @@ class TemporalCorrelatedAgent(AbstractAgent):
         stream and the streams of two RCCL communicators, and streams that
         share a hardware queue wait for each other's kernels (measured: the
         K x K kernels queued behind 2 ms critic launches, 2.7 ms per epoch)."""
-        import os
         from .._lib import call
         n = int(os.environ.get("TCE_OBJECTIVE_STREAMS", "0")) or \
             (1 if self.dist.active else 2)
@@ -693,7 +693,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         the chip: tell the library so (tce_set_cu_budget), its kernels then
         prefer few full waves over many short ones."""
         from .._lib import call
-        call("tce_set_cu_budget", 256 - min(self.critic_workgroups, 224))
+        call("tce_set_cu_budget", max(256 - self.critic_workgroups, 16))
         try:
             return self.update_policy(dataset)
         finally:
@@ -1100,7 +1100,6 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # one launch per critic epoch, six per policy epoch, no autograd, no
         # library GEMM, no graph.  Off: the op-by-op / graph paths below.
         self.small_net_kernels = kwargs.get("small_net_kernels", True)
-        import os
         self.lazy_metrics = kwargs.get(
             "lazy_metrics", os.environ.get("TCE_LAZY_METRICS", "1") != "0")
         self._epoch_graphs = {}
