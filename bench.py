@@ -522,6 +522,12 @@ def _run_config(name, spec, steps, warmup):
             if hs[0] == 256 else None,
             "traffic_source": wide_traffic(spec["dtype"], rows)[1]
             if hs[0] == 256 else None,
+            "mfma_busy": None if hs[0] != 256 else {
+                "chain": mfma_busy("mlpw_chain_kernel<" + (
+                    "double" if f64 else "float"))[0],
+                "grad": mfma_busy("mlpw_grad_kernel<" + (
+                    "double" if f64 else "float"))[0],
+                "source": mfma_busy("mlpw_chain_kernel<float")[1]},
             "measured": "HIP events around the %d critic epochs of every "
                         "timed step, policy epochs on a second stream" % E}
     else:
