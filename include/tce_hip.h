@@ -193,6 +193,11 @@ int tce_pair_env_static(int on);
  * written for them, bb_diag_finish_kernel in csrc/smlp.hip).  For A / B runs
  * and tests; results agree to rounding. */
 void tce_bb_finish_general(int on);
+/* on = 0: tce_policy_epoch2_* ends an epoch with the five separate launches
+ * (join add, tce_chol_build_bwd, tce_adam_flat's two kernels, tce_policy_record)
+ * instead of policy_tail_kernel (csrc/objective.hip; default 1, bit-identical
+ * results).  For A / B runs and tests. */
+void tce_policy_tail_fused(int on);
 /* out[j] = sum_n x[n, j]: gradient of a matrix shared by all envs.
  * ws: real [tce_sum_dim0_slices(N, M), M] workspace. */
 int64_t tce_sum_dim0_slices(int64_t N, int64_t M);

@@ -716,6 +716,116 @@ __global__ __launch_bounds__(64) void policy_record_kernel(const real* __restric
 // parameter-gradient norm is stored (bal2), their sum (+ the entropy term's) is
 // the epoch's gradient.
 // ---------------------------------------------------------------------------
+// The tail of a policy epoch in ONE launch (it was five: the join's add of the
+// two halves of d / d L, the Cholesky head's backward, the two kernels of the
+// flat Adam step, the record row -- 42 us of kernels and five launch boundaries
+// of a 470 us epoch at C2, every one a dependent launch of a few workgroups).
+// As tce_adam_once_*: every workgroup forms the head's gradient (<= K (K + 1) / 2
+// values, LDS) and |g|^2 over the WHOLE flat gradient in the order of
+// adam_prep_kernel (so the step is bit-identical to the five-launch tail), then
+// applies its own slice.  The step count stays on the device (graph replays):
+// every workgroup reads state[0] at its start, the LAST one to finish (ticket)
+// writes the state vector and the record row -- a workgroup that starts late
+// must not see the new count.  gL_p == nullptr: g_L is complete (balance epochs).
+constexpr int PT_BT = 1024, PT_MAX_BLOCKS = 32;
+template <typename real>
+__global__ __launch_bounds__(PT_BT) void policy_tail_kernel(
+    real* __restrict__ param, real* __restrict__ grad, real* __restrict__ m, real* __restrict__ v,
+    int64_t PN, int nvec, int K, const real* __restrict__ g_L, const real* __restrict__ gL_p,
+    real* __restrict__ state, unsigned* __restrict__ ticket, const real* __restrict__ sur2,
+    const real* __restrict__ out16, real ent_coef, real* __restrict__ row19, real lr, real b1,
+    real b2, real eps, real wd, real clip, real gscale) {
+  extern __shared__ __attribute__((aligned(16))) char pt_smem[];
+  real* gv = reinterpret_cast<real*>(pt_smem);               // [nvec] the head's gradient
+  __shared__ real red[16];
+  __shared__ int last_s;
+  const int tid = threadIdx.x;
+  const real* var = param + PN;
+  const real step = state[0] + real(1);
+  // ---- Cholesky head backward (chol_build_bwd_kernel) of g_L (+ gL_p)
+  for (int i = tid; i < nvec; i += PT_BT) {
+    int idx;
+    real sig = 1;
+    if (i < K) {
+      idx = i * K + i;
+      const real x = var[i];
+      sig = x > real(20) ? real(1) : real(1) / (real(1) + exp(-x));
+    } else {
+      const int t = i - K;
+      int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+      while (r * (r - 1) / 2 > t) --r;
+      while ((r + 1) * r / 2 <= t) ++r;
+      idx = r * K + (t - r * (r - 1) / 2);
+    }
+    real g = g_L[idx];
+    if (gL_p) g += gL_p[idx];
+    gv[i] = i < K ? g * sig : g;
+  }
+  __syncthreads();
+  // ---- |g|^2 over the flat gradient (adam_prep_kernel's order)
+  const int64_t n = PN + nvec;
+  real sq = 0;
+  for (int64_t i = tid; i < n; i += PT_BT) {
+    const real g = i < PN ? grad[i] : gv[i - PN];
+    sq += g * g;
+  }
+  sq = block_sum(sq, red);
+  const real before = sqrt(sq) * gscale;
+  real coef = 1;
+  if (clip > real(0)) coef = tmin(clip / (before + real(1e-6)), real(1));
+  const real cg = coef * gscale;
+  // ---- this workgroup's slice of the Adam step (adam_apply_kernel)
+  const real bc1 = real(1) - pow(b1, step), bc2s = sqrt(real(1) - pow(b2, step));
+  const real step_size = lr / bc1;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = blockIdx.x * per, i1 = tmin<int64_t>(n, i0 + per);
+  for (int64_t i = i0 + tid; i < i1; i += PT_BT) {
+    real g0;
+    if (i < PN) g0 = grad[i];
+    else { g0 = gv[i - PN]; grad[i] = g0; }                  // (the flat buffer keeps the head's part)
+    real g = g0 * cg;
+    const real w = param[i];
+    if (wd != real(0)) g += wd * w;
+    const real mi = b1 * m[i] + (real(1) - b1) * g;
+    const real vi = b2 * v[i] + (real(1) - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    param[i] = w - step_size * mi / (sqrt(vi) / bc2s + eps);
+  }
+  // ---- the last workgroup to get here: state vector, record row
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(ticket, 1u);
+    last_s = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  if (tid == 0) {
+    state[0] = step;
+    state[1] = before;
+    state[2] = before * coef;
+    state[3] = cg;
+    *ticket = 0u;
+  }
+  if (tid < 19) {
+    const int i = tid;
+    const real entl = ent_coef == real(0) ? real(0) : -ent_coef * out16[12];
+    real r;
+    if (i == 0) r = sur2[0];
+    else if (i == 1) r = entl;
+    else if (i == 2) r = out16[13];
+    else if (i == 3) r = ent_coef == real(0) ? sur2[0] + out16[13] : sur2[0] + out16[13] + entl;
+    else if (i == 4) r = out16[12];
+    else if (i == 5) r = before;
+    else if (i == 6) r = before * coef;
+    else r = out16[i - 7];
+    row19[i] = r;
+  }
+}
+// (A / B runs and tests: the five-launch tail)
+static int g_policy_tail_fused = 1;
+
 template <typename real> struct EpApi;
 template <> struct EpApi<float> {
   static constexpr auto begin = tce_policy_objective_begin_f32;
@@ -738,7 +848,7 @@ template <> struct EpApi<double> {
 
 inline int64_t epoch2_ws_len(int64_t N, int K, int H, int64_t nparam) {
   return 2 * obj_up4(N * (int64_t)H) + 2 * obj_up4(N * (int64_t)K) +
-         3 * obj_up4((int64_t)K * K) + 32 + obj_up4(nparam);
+         3 * obj_up4((int64_t)K * K) + 36 + obj_up4(nparam);
 }
 
 // the fused 128 x 2 float32 kernels (net_kind 0) exist in float32 only
@@ -824,7 +934,8 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
   real* sur2 = g_L + 2 * obj_up4((int64_t)K * K);
   real* out16 = sur2 + 4;
   real* stats = out16 + 16;
-  real* gtmp = stats + 12;                         // balance: the surrogate's parameter gradient
+  unsigned* ticket = reinterpret_cast<unsigned*>(stats + 12);   // policy_tail_kernel (zero between launches)
+  real* gtmp = stats + 16;                         // balance: the surrogate's parameter gradient
   hipStream_t st = (hipStream_t)stream;
   // net: forward / backward of a gradient w.r.t. the mean
   auto net_fwd = [&]() -> int {
@@ -851,10 +962,21 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
                        pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx, tr_coeff,
                        tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16, N,
                        T, P, dof, K, 1, balance ? 3 : 1, stream));
+  const bool fused_tail = do_adam && g_policy_tail_fused && n <= (1 << 17);
+  const real* gL_join = nullptr;                   // fused tail: the half of d / d L still to add
   if (!balance) {
     // ---- backward into the flat gradient
     OBJ_TRY(net_bwd(g_mean));
-    OBJ_TRY(policy_objective_end<real>(g_L, obj_ws, N, K, P, st));
+    if (fused_tail) {
+      // the join without its add (policy_objective_end): the tail kernel adds
+      const bool single = g_obj_streams < 2;
+      ObjSide* S = single ? nullptr : obj_side();
+      TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+      OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+      gL_join = obj_proj_L(obj_ws, N, K, P) + 2 * obj_up4((int64_t)K * K);
+    } else {
+      OBJ_TRY(policy_objective_end<real>(g_L, obj_ws, N, K, P, st));
+    }
   } else {
     const bool single = g_obj_streams < 2;
     ObjSide* S = single ? nullptr : obj_side();
@@ -884,6 +1006,16 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
                        ent_coef != real(0) ? (const real*)gL_e : (const real*)nullptr,
                        (int64_t)K * K);
     TCE_LAUNCH_CHECK();
+  }
+  if (fused_tail) {
+    const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 4 * PT_BT), PT_MAX_BLOCKS);
+    hipLaunchKernelGGL(policy_tail_kernel<real>, dim3(grid), dim3(PT_BT),
+                       sizeof(real) * (size_t)nvec, st, param, grad, m, v, PN, nvec, K,
+                       (const real*)g_L, gL_join, opt_state, ticket, (const real*)sur2,
+                       (const real*)out16, ent_coef, rec_row19, lr, beta1, beta2, eps,
+                       weight_decay, clip_grad, grad_scale);
+    TCE_LAUNCH_CHECK();
+    return 0;
   }
   OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
   if (!do_adam) return 0;                         // the caller all-reduces, steps and records
@@ -1064,6 +1196,8 @@ int tce_policy_epoch_f32(
       sur_ws, kl_ws, obj_ws, ws, partials, ol_ws, T, P, dof, K, m, v, opt_state, lr, beta1, beta2,
       eps, weight_decay, clip_grad, grad_scale, do_adam, 0, rec_row19, nullptr, stream);
 }
+
+void tce_policy_tail_fused(int on) { g_policy_tail_fused = on; }
 
 int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
   return epoch2_ws_len(N, K, hidden, nparam);

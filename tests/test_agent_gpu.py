@@ -885,6 +885,41 @@ def test_objective_on_one_stream_equals_two_streams(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("env,nb,dtype,balance", [
+    ("metaworld", 5, "float32", None), ("box_push", 8, "float64", None),
+    ("table_tennis", 3, "float32", None), ("metaworld", 5, "float32", 2)])
+def test_fused_epoch_tail_is_bit_identical(env, nb, dtype, balance):
+    """policy_tail_kernel (join add + Cholesky head backward + clip + Adam +
+    record in one launch) == the five launches it replaces
+    (tce_policy_tail_fused(0)): parameters, both moments, the optimizer's state
+    vector and the record rows after two iterations, bit for bit -- on the
+    128 x 2 float32 kernels, both pmlp families and a balance-check iteration."""
+    from tce_rl_amd import _lib
+    lib = _lib.load()
+    out = []
+    try:
+        for on in (1, 0):
+            lib.tce_policy_tail_fused(on)
+            torch.manual_seed(31)
+            agent, _ = build(96, 4, True, env=env, num_basis=nb, dtype=dtype,
+                             adaptive_critic_split=False,
+                             balance_check=balance)
+            torch.manual_seed(32)
+            res = [dict(agent.step()) for _ in range(2)]
+            opt = agent.policy_optimizer
+            out.append(([t.clone() for t in (opt.flat_param, opt.m, opt.v,
+                                             opt.dev_state)], res))
+    finally:
+        lib.tce_policy_tail_fused(1)
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    for ra, rb in zip(out[0][1], out[1][1]):
+        for k in ("surrogate_loss_mean", "trust_region_loss_mean",
+                  "policy_grad_norm_mean", "entropy_mean"):
+            if k in ra:
+                assert ra[k] == rb[k], k
+
+
 def test_deferred_join_does_not_depend_on_side_stream_timing(monkeypatch):
     """The trust-region gradient w.r.t. the mean is written by a kernel on the
     library's second stream and added to on the caller's stream in the
