@@ -638,7 +638,9 @@ __global__ __launch_bounds__(256) void out_layer_grad_kernel(const real* __restr
   }
 }
 
-// dst[e] = sum_b part[b][e] (fixed order, 8 loads in flight); e < KH -> dW, else db
+// dst[e] = sum_b part[b][e] (fixed order, 32 loads in flight -- with 8 the 128
+// slabs of a C2 epoch were 16 dependent round trips, 28 us beside the critic);
+// e < KH -> dW, else db
 template <typename real>
 __global__ __launch_bounds__(256) void out_layer_reduce_kernel(const real* __restrict__ part,
                                                                int nb, int64_t KH, int K,
@@ -647,16 +649,22 @@ __global__ __launch_bounds__(256) void out_layer_reduce_kernel(const real* __res
   const int64_t e = blockIdx.x * 256ll + threadIdx.x;
   const int64_t M = KH + K;
   if (e >= M) return;
-  real a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int b = 0;
-  for (; b + 8 <= nb; b += 8) {
+  constexpr int U = 32;
+  real a[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a8[u] += part[(int64_t)(b + u) * M + e];
+  for (int u = 0; u < U; ++u) a[u] = 0;
+  int b = 0;
+  for (; b + U <= nb; b += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] += part[(int64_t)(b + u) * M + e];
   }
-  for (; b < nb; ++b) a8[0] += part[(int64_t)b * M + e];
-  const real sum = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-  if (e < KH) dW[e] = sum;
-  else db[e - KH] = sum;
+  for (; b < nb; ++b) a[0] += part[(int64_t)b * M + e];
+#pragma unroll
+  for (int w = U / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) a[u] += a[u + w];
+  if (e < KH) dW[e] = a[0];
+  else db[e - KH] = a[0];
 }
 
 template <typename real>
