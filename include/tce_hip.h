@@ -255,9 +255,9 @@ int64_t tce_kl_cov_proj_ctx_len(int K);
 /* Implementation of tce_kl_cov_proj_fwd/bwd: 1 = without an
  * eigen-decomposition (csrc/klproj2.h: Newton on the dual variable with one
  * block Gauss-Jordan inversion per evaluation, products on the float64 matrix
- * instruction, implicit-function gradient in matrix form; 64 x 64 images for
- * every K); 0 = one-sided Jacobi (rounds 1 - 3); 2 (default) = form 1 for
- * K > 32, form 0 otherwise.  Same results to ~1e-9; a context (ctx) written by
+ * instruction, implicit-function gradient in matrix form; 32 x 32 images for
+ * K <= 32, 64 x 64 above); 0 = one-sided Jacobi (rounds 1 - 3); 2 (default) =
+ * form 1 for K >= 20, form 0 otherwise.  Same results to ~1e-9; a context (ctx) written by
  * one form must be read by the same form; with warm_start != 0 the context must
  * come from a call with the SAME L_old. */
 int tce_kl_proj_impl(int impl);

@@ -22,7 +22,7 @@ namespace {
 
 constexpr double LOG_2PI = 1.8378770664093453;
 int g_klp_impl = 2;                 // tce_kl_proj_impl: 0 Jacobi, 1 Newton, 2 by size
-inline bool klp_newton(int K) { return g_klp_impl == 1 || (g_klp_impl == 2 && K > 32); }
+inline bool klp_newton(int K) { return g_klp_impl == 1 || (g_klp_impl == 2 && K >= 20); }
 
 // ---------------------------------------------------------------------------
 // Cholesky head: vec [B, K (+ K(K-1)/2)] -> L [B, K, K]
@@ -608,8 +608,10 @@ extern "C" {
 int64_t tce_kl_cov_proj_ctx_len(int K) { return klp_ctx_len(K); }
 
 // 2 (default): by size -- the eigen-decomposition-free kernels of klproj2.h for
-// K > 32 (their images are 64 x 64 whatever K is: at K 24 the Jacobi kernels
-// are still faster, 40 / 16 us against 54 / 24), the Jacobi kernels above
+// K >= 20 (padded to 32 x 32 on two waves for K <= 32, to 64 x 64 on four
+// above: at K 24, forward / backward per call incl. a synchronisation, 48 - 55 /
+// 35 us against 97 - 112 / 51 us for the warm-started Jacobi kernels; at K 63
+// 0.15 / 0.16 ms against 0.41 / 0.31 in the C3 step), the Jacobi kernels above
 // otherwise; 1 / 0: force one form.  A context written by one form must not be
 // read by the other (forward and backward of one evaluation, and a warm start,
 // use one form).
@@ -684,6 +686,15 @@ int tce_kl_proj_impl(int impl) {
                                 void* stream) {                                   \
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && B > 0 && K > 0 && K <= 64,       \
                   "kl_cov_proj: bad arguments (K <= 64)");                        \
+    if (klp_newton(K) && K <= 32) {                                               \
+      set_lds(klp2s::fwd_kernel<REAL>, klp2s::LDS_BYTES);                         \
+      hipLaunchKernelGGL(klp2s::fwd_kernel<REAL>, dim3((unsigned)B),              \
+                         dim3(klp2s::BT), klp2s::LDS_BYTES, (hipStream_t)stream,  \
+                         L, L_old, L_old_stride, eps_cov, beta, entropy_eq,       \
+                         proj_L, ctx, K, warm_start);                             \
+      TCE_LAUNCH_CHECK();                                                         \
+      return 0;                                                                   \
+    }                                                                             \
     if (klp_newton(K)) {                                                          \
       set_lds(klp2::fwd_kernel<REAL>, klp2::LDS_BYTES);                           \
       hipLaunchKernelGGL(klp2::fwd_kernel<REAL>, dim3((unsigned)B),               \
@@ -709,6 +720,15 @@ int tce_kl_proj_impl(int impl) {
     TCE_CHECK_ARG(L && L_old && proj_L && ctx && grad_proj && grad_L && B > 0 &&  \
                       K > 0 && K <= 64,                                           \
                   "kl_cov_proj_bwd: bad arguments (K <= 64)");                    \
+    if (klp_newton(K) && K <= 32) {                                               \
+      set_lds(klp2s::bwd_kernel<REAL>, klp2s::LDS_BYTES);                         \
+      hipLaunchKernelGGL(klp2s::bwd_kernel<REAL>, dim3((unsigned)B),              \
+                         dim3(klp2s::BT), klp2s::LDS_BYTES, (hipStream_t)stream,  \
+                         L, L_old, L_old_stride, proj_L, ctx, grad_proj, grad_L,  \
+                         K);                                                      \
+      TCE_LAUNCH_CHECK();                                                         \
+      return 0;                                                                   \
+    }                                                                             \
     if (klp_newton(K)) {                                                          \
       set_lds(klp2::bwd_kernel<REAL>, klp2::LDS_BYTES);                           \
       hipLaunchKernelGGL(klp2::bwd_kernel<REAL>, dim3((unsigned)B),               \

@@ -1806,20 +1806,41 @@ __global__ __launch_bounds__(SBT) void lin_rows_kernel(const float* __restrict__
   float* Bs = As + dinp * DP;                              // [DP]
   float* Xs = Bs + DP;                                     // [64][xp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < dinp * DP; e += SBT) {
-    const int i = e / DP, o = e - i * DP;
-    float v = 0.f;
-    if (i < din && o < dout) v = transposed ? W[(int64_t)o * din + i] : W[(int64_t)i * dout + o];
-    As[e] = v;
+  // A and the first x tile by LDS-DMA (s_dma64: one round trip instead of two
+  // dependent load / store loops).  Pad
+  // outputs (o >= dout) hold copies of the last output's weights -- their
+  // accumulators are never stored --, pad inputs (rows din .. dinp - 1 of A)
+  // are zeroed behind the wait, pad columns / rows past N of x hold copies.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ulane = (unsigned)lane, udin = (unsigned)din, udout = (unsigned)dout;
+  for (int t = wave_u; t < dinp * DP / 64; t += SNW) {       // (dinp DP: a multiple of 64)
+    const unsigned a = 64u * t + ulane, i = a / DP, o = a % DP;
+    const unsigned ic = i < udin ? i : udin - 1u, oc = o < udout ? o : udout - 1u;
+    s_dma64(W + (transposed ? oc * udin + ic : ic * udout + oc), As + 64 * t);
   }
-  for (int e = tid; e < DP; e += SBT) Bs[e] = (bias && e < dout) ? bias[e] : 0.f;
-  for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < N; r0 += (int64_t)gridDim.x * SR) {
-    __syncthreads();
-    for (int e = tid; e < SR * dinp; e += SBT) {
-      const int r = e / dinp, c = e - r * dinp;
-      const int64_t row = r0 + r;
-      Xs[r * xp + c] = (c < din && row < N) ? x[row * x_stride + c] : 0.f;
+  auto x_tile = [&](int64_t r0) {
+    const unsigned last = (unsigned)(N - r0 < SR ? N - r0 : SR) - 1u;
+    const float* __restrict__ xb = x + r0 * x_stride;
+    const unsigned stride = (unsigned)x_stride, uxp = (unsigned)xp, cl = udin - 1u;
+    // (xp up to 260: a / xp by a 32-bit reciprocal, exact while a xp < 2^32)
+    const unsigned mx = (unsigned)(((1ull << 32) + uxp - 1u) / uxp);
+    for (int t = wave_u; t < xp; t += SNW) {
+      const unsigned a = 64u * t + ulane, r = __umulhi(a, mx), c = a - r * uxp;
+      s_dma64(xb + (r < last ? r : last) * stride + (c < cl ? c : cl), Xs + 64 * t);
     }
+  };
+  x_tile((int64_t)blockIdx.x * SR);
+  for (int e = tid; e < DP; e += SBT) Bs[e] = (bias && e < dout) ? bias[e] : 0.f;
+  s_dma_wait();
+  for (int e = din * DP + tid; e < dinp * DP; e += SBT) As[e] = 0.f;
+  bool first = true;
+  for (int64_t r0 = (int64_t)blockIdx.x * SR; r0 < N; r0 += (int64_t)gridDim.x * SR) {
+    if (!first) {
+      __syncthreads();
+      x_tile(r0);
+      s_dma_wait();
+    }
+    first = false;
     __syncthreads();
     float acc[OPW];
 #pragma unroll
@@ -2151,8 +2172,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
 int tce_lin_rows_f32(const float* x, int64_t x_stride, int64_t N, int din, int dout,
                      const float* W, int transposed, const float* bias, float* y, void* stream) {
   TCE_CHECK_ARG(x && W && y && N > 0 && din >= 1 && din <= 256 && dout >= 1 && dout <= 128 &&
-                    x_stride >= din,
-                "lin_rows: bad arguments (D_in <= 256, D_out <= 128)");
+                    x_stride >= din && x_stride < (1 << 24),
+                "lin_rows: bad arguments (D_in <= 256, D_out <= 128, row stride in [D_in, 2^24))");
   hipStream_t st = (hipStream_t)stream;
   if (dout <= 16) return lin_rows_launch<4>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
   if (dout <= 32) return lin_rows_launch<8>(x, x_stride, N, din, dout, W, transposed, bias, y, st);
