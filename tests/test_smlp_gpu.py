@@ -147,7 +147,10 @@ def general_finish():
 @pytest.mark.parametrize("std_only,K,H,din,N,ent,set_var", [
     (True, 20, 32, 39, 300, 0.0, True), (False, 12, 32, 39, 130, 0.01, False),
     (False, 12, 64, 16, 64, 0.0, False), (True, 6, 32, 9, 4096, 0.0, False),
-    (False, 33, 32, 39, 77, 0.0, False)])
+    (False, 33, 32, 39, 77, 0.0, False),
+    # more than 1024 tiles: workgroups walk several tiles (tile DMA inside the
+    # loop, slabs accumulated)
+    (True, 6, 32, 9, 66000, 0.0, True)])
 @pytest.mark.parametrize("diag_kernels", [True, False, "general_finish"])
 def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
                                                set_var, diag_kernels,
@@ -249,7 +252,7 @@ def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
 @pytest.mark.parametrize("N,din,dout,transposed", [
     (4096, 128, 24, True), (4096, 24, 128, False), (70, 128, 63, True),
     (1000, 63, 128, False), (129, 256, 36, True), (5, 7, 3, True),
-    (300, 20, 100, False)])
+    (300, 20, 100, False), (70000, 40, 24, True)])
 def test_lin_rows(N, din, dout, transposed):
     """tce_lin_rows_f32 (the output layer of the policy mean net and its input
     gradient) against torch in float64."""
