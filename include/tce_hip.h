@@ -245,6 +245,17 @@ int tce_vec_env_f32(int mode, int bwd, const float* x, const float* y, const flo
 int tce_vec_env_f64(int mode, int bwd, const double* x, const double* y, const double* L,
                     int64_t L_stride, double eps, const double* grad_out, double* out,
                     double* grad_x, double* grad_L, int64_t N, int K, void* stream);
+/* The backward of mode 1 (mean projection) that ADDS its result to grad_x
+ * instead of storing it: the policy objective's two halves of d / d mean_new
+ * (trust region loss, written on its second stream; surrogate through the
+ * projection) without a separate add kernel.  The caller has waited for
+ * whatever wrote grad_x. */
+int tce_mean_proj_bwd_acc_f32(const float* x, const float* y, const float* L,
+                              int64_t L_stride, float eps, const float* grad_out,
+                              float* grad_x, int64_t N, int K, void* stream);
+int tce_mean_proj_bwd_acc_f64(const double* x, const double* y, const double* L,
+                              int64_t L_stride, double eps, const double* grad_out,
+                              double* grad_x, int64_t N, int K, void* stream);
 int tce_kl_cov_part_f32(int bwd, const float* L, const float* L_old,
                         int64_t L_old_stride, const float* grad_out, float* out,
                         float* grad_L, int64_t B, int K, void* stream);

@@ -95,7 +95,7 @@ template <typename real, int MODE, bool BWD>
 __global__ __launch_bounds__(64) void vec_env_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     int64_t sL, real eps, const real* __restrict__ gout, real* __restrict__ out,
-    real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K) {
+    real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K, int acc) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: d[K][64] | q[K][64] (lane = env: conflict free)
   real* dS = reinterpret_cast<real*>(smem_raw);
@@ -149,9 +149,12 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
       real gd = 0;
       for (int r = 0; r < K; ++r) gd += gout[n * K + r] * (x[n * K + r] - y[n * K + r]);
       const real coef = gd / (real(2) * eps * s * s * s);
-      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r] / s - coef * q[r * 64];
+      for (int r = 0; r < K; ++r) {
+        const real o = gout[n * K + r] / s - coef * q[r * 64];
+        gx[n * K + r] = acc ? gx[n * K + r] + o : o;
+      }
     } else {
-      for (int r = 0; r < K; ++r) gx[n * K + r] = gout[n * K + r];
+      for (int r = 0; r < K; ++r) gx[n * K + r] = acc ? gx[n * K + r] + gout[n * K + r] : gout[n * K + r];
     }
   } else {
     const real g = gout[n];
@@ -175,7 +178,7 @@ template <typename real, int MODE, bool BWD>
 __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     real eps, const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gx,
-    real* __restrict__ gLout, int64_t N, int K) {
+    real* __restrict__ gLout, int64_t N, int K, int acc) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Ls = reinterpret_cast<real*>(smem_raw);               // [K][KP]
   const int KP = sm_pitch(K);
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
           const real coef = gd / (real(2) * eps * sc * sc * sc);
           o = go / sc - coef * q[s];
         }
-        if (in) gx[n[s] * K + lane] = o;
+        // (acc: the mean projection's backward ADDS to what gx holds -- the other
+        // half of d / d mean, written on another stream and waited for by the caller)
+        if (in) gx[n[s] * K + lane] = acc ? gx[n[s] * K + lane] + o : o;
       } else {
         const real g = gout[n[s]];
         if (in) gx[n[s] * K + lane] = g * q[s];               // d logp / d mean
@@ -570,18 +575,18 @@ int set_lds(F kern, size_t lds) {
 template <typename real, int MODE, bool BWD>
 int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, real eps,
                       const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                      hipStream_t st) {
+                      hipStream_t st, int acc) {
   if (sL == 0) {
     const size_t lds = (size_t)K * sm_pitch(K) * sizeof(real);
     set_lds(vec_env_shared_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_shared_kernel<real, MODE, BWD>),
                        dim3((unsigned)ceil_div(N, VS_EPB)), dim3(VS_BT), lds, st, x, y, L, eps,
-                       gout, out, gx, gL, N, K);
+                       gout, out, gx, gL, N, K, acc);
   } else {
     const size_t lds = 2 * (size_t)K * 64 * sizeof(real);
     set_lds(vec_env_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_kernel<real, MODE, BWD>), dim3((unsigned)ceil_div(N, 64)),
-                       dim3(64), lds, st, x, y, L, sL, eps, gout, out, gx, gL, N, K);
+                       dim3(64), lds, st, x, y, L, sL, eps, gout, out, gx, gL, N, K, acc);
   }
   TCE_LAUNCH_CHECK();
   return 0;
@@ -590,10 +595,10 @@ int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, r
 template <typename real>
 int vec_env_launch(int mode, int bwd, const real* x, const real* y, const real* L, int64_t sL,
                    real eps, const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                   hipStream_t st) {
+                   hipStream_t st, int acc = 0) {
 #define VE_CASE(M, B)                                                                       \
   if (mode == M && (bwd != 0) == B)                                                         \
-    return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st);
+    return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st, acc);
   VE_CASE(0, false) VE_CASE(0, true) VE_CASE(1, false) VE_CASE(1, true) VE_CASE(2, false)
   VE_CASE(2, true)
 #undef VE_CASE
@@ -655,6 +660,17 @@ int tce_kl_proj_impl(int impl) {
                   "vec_env: null output");                                        \
     return vec_env_launch<REAL>(mode, bwd, x, y, L, L_stride, eps, grad_out, out,   \
                                 grad_x, grad_L, N, K, (hipStream_t)stream);         \
+  }                                                                               \
+  /* backward of mode 1 (mean projection) that ADDS to grad_x */                  \
+  int tce_mean_proj_bwd_acc_##SFX(const REAL* x, const REAL* y, const REAL* L,    \
+                                  int64_t L_stride, REAL eps,                     \
+                                  const REAL* grad_out, REAL* grad_x, int64_t N,  \
+                                  int K, void* stream) {                          \
+    TCE_CHECK_ARG(x && y && L && grad_out && grad_x && N > 0 && K > 0 &&          \
+                      K <= VE_MAXK,                                               \
+                  "mean_proj_bwd_acc: bad arguments (K <= 64)");                  \
+    return vec_env_launch<REAL>(1, 1, x, y, L, L_stride, eps, grad_out, nullptr,  \
+                                grad_x, nullptr, N, K, (hipStream_t)stream, 1);   \
   }                                                                               \
   int tce_kl_cov_part_##SFX(int bwd, const REAL* L, const REAL* L_old,            \
                             int64_t L_old_stride, const REAL* grad_out,           \

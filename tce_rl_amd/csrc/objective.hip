@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void obj_add3_kernel(real* __restrict__ a,
 template <typename real> struct ObjApi;
 template <> struct ObjApi<float> {
   static constexpr auto vec_env = tce_vec_env_f32;
+  static constexpr auto mean_bwd_acc = tce_mean_proj_bwd_acc_f32;
   static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f32;
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f32;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f32;
@@ -340,6 +341,7 @@ template <> struct ObjApi<float> {
 };
 template <> struct ObjApi<double> {
   static constexpr auto vec_env = tce_vec_env_f64;
+  static constexpr auto mean_bwd_acc = tce_mean_proj_bwd_acc_f64;
   static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f64;
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f64;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f64;
@@ -444,6 +446,14 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
                         K, sd));
   }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
+  const bool split0 = (defer_join & 2) != 0;
+  if ((defer_join & 1) && !split0) {
+    // deferred join: the mean projection's backward adds to grad_mean itself
+    // (what obj_add2_kernel did in a launch of its own, same operands and order);
+    // grad_L lacks the projection's part until tce_policy_objective_end_*
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
+    return A::mean_bwd_acc(mean_new, mean_old, L_old, 0, eps_mean, g_pm, grad_mean, N, K, st);
+  }
   OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
                      nullptr, N, K, st));
   const int64_t n1 = N * K, n2 = (int64_t)K * K;
