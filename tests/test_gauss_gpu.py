@@ -142,6 +142,32 @@ def test_mean_projection_and_maha(ops, shared):
     torch.testing.assert_close(x_g.grad.cpu(), x_c.grad, rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_mean_projection_backward_accumulating_form(ops, shared, dtype):
+    """tce_mean_proj_bwd_acc_* == tce_vec_env_*(mode 1, bwd) + an add, bit for
+    bit (the policy objective's join of the two halves of d / d mean)."""
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    g = torch.Generator().manual_seed(5)
+    N, K = 70, 24
+    L_o = rand_chol(K, 1.0, g, 1 if shared else N).to(dtype)
+    mu_o = torch.randn(N, K, generator=g, dtype=F64)
+    mu = (mu_o + 0.3 * torch.randn(N, K, generator=g, dtype=F64)
+          * torch.rand(N, 1, generator=g, dtype=F64)).to(dtype).cuda()
+    mu_o = mu_o.to(dtype).cuda()
+    go = torch.randn(N, K, generator=g, dtype=F64).to(dtype).cuda()
+    base = torch.randn(N, K, generator=g, dtype=F64).to(dtype).cuda()
+    Lg = L_o[0].cuda().contiguous() if shared else L_o.cuda().contiguous()
+    sL = 0 if shared else K * K
+    gx = torch.empty_like(mu)
+    call("tce_vec_env_" + sfx(dtype), 1, 1, ptr(mu), ptr(mu_o), ptr(Lg), sL, 0.5,
+         ptr(go), None, ptr(gx), None, N, K, stream())
+    acc = base.clone()
+    call("tce_mean_proj_bwd_acc_" + sfx(dtype), ptr(mu), ptr(mu_o), ptr(Lg), sL,
+         0.5, ptr(go), ptr(acc), N, K, stream())
+    assert torch.equal(acc, base + gx)
+
+
 @pytest.mark.parametrize("K", [5, 24, 36, 63])
 def test_kl_cov_part_fwd_bwd(ops, K):
     g = torch.Generator().manual_seed(K)
