@@ -255,10 +255,11 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
 // ---------------------------------------------------------------------------
 struct ObjSide {
   hipStream_t side = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 int g_obj_streams = 2;            // tce_policy_objective_streams: 1 = everything on the caller's stream
+int g_inline_surrogate = 1;       // tce_policy_inline_surrogate (A / B runs, tests)
 
 inline ObjSide* obj_side() {
   static ObjSide s;
@@ -266,7 +267,7 @@ inline ObjSide* obj_side() {
   if (!tried) {
     tried = true;
     ok = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 6; ++i)
+    for (int i = 0; ok && i < 7; ++i)
       ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
   }
   return ok ? &s : nullptr;
@@ -337,6 +338,7 @@ template <> struct ObjApi<float> {
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f32;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f32;
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f32;
+  static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f32;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f32;
 };
 template <> struct ObjApi<double> {
@@ -346,6 +348,7 @@ template <> struct ObjApi<double> {
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f64;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f64;
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f64;
+  static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f64;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f64;
 };
 
@@ -420,14 +423,32 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   OBJ_HIP(hipEventRecord(S->ev[5], sd));
   // ---- main: pair log-prob under the projection, surrogate, and back
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
-  OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
-                    rel_goal, times, flags_fwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
-                    pl_work, N, T, P, dof, st));
-  OBJ_TRY(surrogate<real>(logp, logp_old, adv, N * (int64_t)P, sur2, glp, sur_ws, st));
-  OBJ_TRY(A::pl_bwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
-                    rel_goal, times, flags_bwd, t0, y0, v0, reg, glp, g_pm, g_pL, basis_ws,
-                    flag_ws, pl_work, N, T, P, dof, st));
   const bool split = (defer_join & 2) != 0;
+  // The backward pair kernels recompute the log-prob and can form the surrogate's
+  // gradient themselves (tce_pair_logprob_bwd_sur_*): the forward pass and the
+  // surrogate kernel then only feed the record row and run on the side stream
+  // BEHIND the projection's backward, off the epoch's critical path (C2: 32 + 12
+  // us and two launch boundaries of a 360 us epoch).  Where the shared-factor
+  // fast path is known to run (what the deferred join's caller, the direct
+  // epoch, guarantees with flag bit 3); with one stream the same kernels in
+  // the same roles, one after the other.
+  const bool inline_sur = g_inline_surrogate && (defer_join & 1) && !split &&
+                          (flags_fwd & 1) == 0 && (flags_fwd & 8) != 0 && (flags_bwd & 8) != 0 &&
+                          N >= 256;
+  if (inline_sur) {
+    // (the backward call runs pair_prep: the forward's flags said so)
+    OBJ_TRY(A::pl_bwd_sur(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                          rel_goal, times, flags_fwd, t0, y0, v0, reg, logp_old, adv, g_pm, g_pL,
+                          basis_ws, flag_ws, pl_work, N, T, P, dof, st));
+  } else {
+    OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                      rel_goal, times, flags_fwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
+                      pl_work, N, T, P, dof, st));
+    OBJ_TRY(surrogate<real>(logp, logp_old, adv, N * (int64_t)P, sur2, glp, sur_ws, st));
+    OBJ_TRY(A::pl_bwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                      rel_goal, times, flags_bwd, t0, y0, v0, reg, glp, g_pm, g_pL, basis_ws,
+                      flag_ws, pl_work, N, T, P, dof, st));
+  }
   if (ent_coef != real(0) && !split) {
     hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
                        ent_coef);
@@ -444,6 +465,15 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
     TCE_LAUNCH_CHECK();
     OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p + obj_up4((int64_t)K * K), 1,
                         K, sd));
+  }
+  if (inline_sur) {
+    // the loss value for the record: forward pair kernels + surrogate sums, behind
+    // the projection's backward on the side stream (they read pm / pL / the pair
+    // records, all final; flags_bwd: the records of this L are in the workspace)
+    OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
+                      rel_goal, times, flags_bwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
+                      pl_work, N, T, P, dof, sd));
+    OBJ_TRY(surrogate<real>(logp, logp_old, adv, N * (int64_t)P, sur2, (real*)nullptr, sur_ws, sd));
   }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
   const bool split0 = (defer_join & 2) != 0;
@@ -1216,6 +1246,7 @@ int tce_policy_epoch_f32(
 }
 
 void tce_policy_tail_fused(int on) { g_policy_tail_fused = on; }
+void tce_policy_inline_surrogate(int on) { g_inline_surrogate = on; }
 
 int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
   return epoch2_ws_len(N, K, hidden, nparam);

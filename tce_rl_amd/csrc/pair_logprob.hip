@@ -409,7 +409,7 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
     const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
     real* __restrict__ logp, const real* __restrict__ gout, real* __restrict__ gmean,
     real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, PFShape s,
-    int EB) {
+    int EB, const real* __restrict__ lp_old, const real* __restrict__ adv, real inv_m) {
   if (*nonuniform != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
@@ -478,7 +478,20 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
         if (ok) logp[n * P + p] = real(-0.5) * quad - Li[2 * R * R] -
                                   real(0.5) * (real)R * real(1.8378770664093453);
       } else {
-        g = ok ? gout[n * P + p] : real(0);
+        g = real(0);
+        if (ok) {
+          if (lp_old) {
+            // the surrogate's gradient from the log-prob this kernel has just
+            // recomputed (surrogate_kernel's formula): no launch between the
+            // forward and the backward pass
+            const real lpn = real(-0.5) * quad - Li[2 * R * R] -
+                             real(0.5) * (real)R * real(1.8378770664093453);
+            const real ra = exp(lpn - lp_old[n * P + p]) * adv[n * P + p];
+            g = -ra * inv_m;
+          } else {
+            g = gout[n * P + p];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < PL_MAXR; ++r) {
           if (r < R) {
@@ -551,7 +564,8 @@ __global__ __launch_bounds__(256) void pair_env_static_kernel(
     const int64_t* __restrict__ pairs, const int* __restrict__ nonuniform,
     const real* __restrict__ y0, const real* __restrict__ v0, const real* __restrict__ ws,
     real* __restrict__ logp, const real* __restrict__ gout, real* __restrict__ gmean,
-    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, int P, int EB) {
+    real* __restrict__ spart /* [gridDim.x][P][R*R + 1] */, int64_t N, int T, int P, int EB,
+    const real* __restrict__ lp_old, const real* __restrict__ adv, real inv_m) {
   if (*nonuniform != 0) return;
   constexpr int R = 2 * DOF, K = DOF * NBG, KP = (K + 1) | 1;
   constexpr int wsp = 2 * NBG + 4 + R * K + 2 * R * R + 1;          // pf_ws_pair
@@ -619,7 +633,17 @@ __global__ __launch_bounds__(256) void pair_env_static_kernel(
       if (ok) logp[n * P + p] = real(-0.5) * quad - Li[2 * R * R] -
                                 real(0.5) * (real)R * real(1.8378770664093453);
     } else {
-      const real g = ok ? gout[n * P + p] : real(0);
+      real g = 0;
+      if (ok) {
+        if (lp_old) {
+          const real lpn = real(-0.5) * quad - Li[2 * R * R] -
+                           real(0.5) * (real)R * real(1.8378770664093453);
+          const real ra = exp(lpn - lp_old[n * P + p]) * adv[n * P + p];
+          g = -ra * inv_m;
+        } else {
+          g = gout[n * P + p];
+        }
+      }
       real ga[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -781,14 +805,17 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
               real scaled_dt, real inv_scale_g, int rel_goal, const real* times,
               int times_flags, const real* t0, const real* y0, const real* v0, real reg,
               real* logp, const real* gout, real* gmean, real* gL, real* B, int* flag,
-              real* work, int64_t N, int T, int P, int dof, hipStream_t stream) {
+              real* work, int64_t N, int T, int P, int dof, hipStream_t stream,
+              const real* lp_old = nullptr, const real* adv = nullptr) {
   const int times_general = times_flags & 1;
   const bool basis_ready = (times_flags & 2) != 0;     // B / flag hold this time grid already
   const bool prep_ready = (times_flags & 4) != 0;      // work holds pair_prep of this L already
   const bool uniform_known = (times_flags & 8) != 0;   // the caller checked: all init times equal
   TCE_CHECK_ARG(traj && mean && L && pairs && tab && times && t0 && y0 && v0 && B && flag,
                 "pair_logprob: null buffer");
-  TCE_CHECK_ARG(bwd ? (gout && gmean && gL) : (logp != nullptr), "pair_logprob: null output");
+  TCE_CHECK_ARG(bwd ? ((gout || (lp_old && adv)) && gmean && gL) : (logp != nullptr),
+                "pair_logprob: null output");
+  const real inv_m = real(1) / (real)(N * (int64_t)P);
   TCE_CHECK_ARG(N > 0 && T > 0 && P > 0, "pair_logprob: bad sizes");
   TCE_CHECK_ARG(nbg >= 1 && nbg <= TCE_MAXB && dof >= 1 && 2 * dof <= PL_MAXR,
                 "pair_logprob: num_basis + 1 <= 16 and num_dof <= 8");
@@ -838,6 +865,9 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     sum_ws = gL_env + N * (int64_t)K * K;
   }
   const bool fast = (sL == 0) && !times_general && N >= 256;
+  TCE_CHECK_ARG(!(bwd && lp_old) || (fast && uniform_known),
+                "pair_logprob_bwd_sur: needs the shared-factor fast path known to run (shared L, "
+                "affine time grid, >= 256 envs, times_general bit 3 set)");
   if (fast) {
     real* wsp = work;                                      // [P][pf_ws_pair]
     real* spart = wsp + (int64_t)P * pf_ws_pair(f);        // [nblk][P][R*R+1]
@@ -854,7 +884,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     if (stat) {
       typedef void (*kern_t)(const real*, const real*, const int64_t*, const int*, const real*,
                              const real*, const real*, real*, const real*, real*, real*, int64_t,
-                             int, int, int);
+                             int, int, int, const real*, const real*, real);
       kern_t kern = reinterpret_cast<kern_t>(stat);
       // four waves per block (one per SIMD: a lane holds up to 2 K + 3 R values;
       // __launch_bounds__(256)).  LDS: the per-wave gradient rows [4][EB][KP]
@@ -864,7 +894,8 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
                             (bwd ? NWS * ((size_t)EB * PE_RP + EB) : 0)) * sizeof(real);
       tce_lds_limit(reinterpret_cast<const void*>(kern), lds_s);
       hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NWS), lds_s, stream, traj, mean, pairs, flag,
-                         y0, v0, (const real*)wsp, logp, gout, gmean, spart, N, T, P, EB);
+                         y0, v0, (const real*)wsp, logp, gout, gmean, spart, N, T, P, EB, lp_old,
+                         adv, inv_m);
       TCE_LAUNCH_CHECK();
     }
     if (bwd) {
@@ -873,7 +904,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
         tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, true>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, true>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
-                         f, EB);
+                         f, EB, lp_old, adv, inv_m);
       TCE_LAUNCH_CHECK();
       }
       real* gLp = spart + (int64_t)nblk * P * (f.R * f.R + 1);   // [P][K][K]
@@ -890,13 +921,14 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
         tce_lds_limit(reinterpret_cast<const void*>(pair_env_kernel<real, false>), (size_t)(lds));
       hipLaunchKernelGGL((pair_env_kernel<real, false>), dim3(nblk), dim3(64 * NWV), lds, stream,
                          traj, mean, pairs, flag, y0, v0, wsp, logp, gout, gmean, spart, N, T,
-                         f, EB);
+                         f, EB, (const real*)nullptr, (const real*)nullptr, real(0));
     }
     TCE_LAUNCH_CHECK();
   }
   // the general kernel below (and the sum of its per-env dL) exits at once when
   // the fast path ran; a caller that knows it will run saves those launches
   if (fast && uniform_known) return 0;
+
   PLShape s{K, 2 * dof, P, P, nbg, dof};
   const size_t budget = 60 * 1024;
   while (s.PC > 1 && pl_lds_reals(s, bwd) * sizeof(real) > budget) --s.PC;
@@ -999,6 +1031,26 @@ int64_t tce_pair_logprob_work_len(int64_t N, int P, int dof, int nbg, int64_t L_
                            times_general, init_time, init_pos, init_vel, reg,    \
                            nullptr, grad_logp, grad_mean, grad_L, basis_ws,      \
                            flag_ws, work, N, T, P, dof, (hipStream_t)stream);    \
+  }                                                                              \
+  /* backward with the surrogate's gradient formed inside: grad_logp[n, p] =      \
+     -exp(logp[n, p] - logp_old[n, p]) adv[n, p] / (N P) from the log-prob the    \
+     kernel recomputes */                                                         \
+  int tce_pair_logprob_bwd_sur_##SFX(                                            \
+      const REAL* traj, const REAL* mean, const REAL* L, int64_t L_stride,       \
+      const int64_t* pairs, const REAL* tab, int M, int nbg, REAL tau,           \
+      REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal,                \
+      const REAL* times, int times_general, const REAL* init_time,               \
+      const REAL* init_pos, const REAL* init_vel, REAL reg,                      \
+      const REAL* logp_old, const REAL* adv, REAL* grad_mean, REAL* grad_L,      \
+      REAL* basis_ws, int* flag_ws, REAL* work, int64_t N, int T, int P,         \
+      int dof, void* stream) {                                                   \
+    TCE_CHECK_ARG(logp_old && adv, "pair_logprob_bwd_sur: null buffer");         \
+    return pl_launch<REAL>(true, traj, mean, L, L_stride, pairs, tab, M, nbg,    \
+                           tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
+                           times_general, init_time, init_pos, init_vel, reg,    \
+                           nullptr, nullptr, grad_mean, grad_L, basis_ws,        \
+                           flag_ws, work, N, T, P, dof, (hipStream_t)stream,     \
+                           logp_old, adv);                                       \
   }                                                                              \
   /* ws: REAL [tce_sum_dim0_slices(N, M), M] workspace (may be NULL when the  \
      slice count is 1) */                                                        \
