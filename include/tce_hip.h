@@ -277,6 +277,16 @@ int tce_vec_env_f32(int mode, int bwd, const float* x, const float* y, const flo
 int tce_vec_env_f64(int mode, int bwd, const double* x, const double* y, const double* L,
                     int64_t L_stride, double eps, const double* grad_out, double* out,
                     double* grad_x, double* grad_L, int64_t N, int K, void* stream);
+/* The forward of mode 1 (mean projection) that also stores the squared
+ * Mahalanobis distance it is built on, quad_out[n] = |L^-1 (x_n - y_n)|^2: the
+ * policy objective's KL diagnostics take maha(new, old) and maha(proj, old) =
+ * quad / s^2 from it instead of solving those two systems again. */
+int tce_mean_proj_fwd_q_f32(const float* x, const float* y, const float* L,
+                            int64_t L_stride, float eps, float* out, float* quad_out,
+                            int64_t N, int K, void* stream);
+int tce_mean_proj_fwd_q_f64(const double* x, const double* y, const double* L,
+                            int64_t L_stride, double eps, double* out, double* quad_out,
+                            int64_t N, int K, void* stream);
 /* The backward of mode 1 (mean projection) that ADDS its result to grad_x
  * instead of storing it: the policy objective's two halves of d / d mean_new
  * (trust region loss, written on its second stream; surrogate through the

@@ -95,7 +95,8 @@ template <typename real, int MODE, bool BWD>
 __global__ __launch_bounds__(64) void vec_env_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     int64_t sL, real eps, const real* __restrict__ gout, real* __restrict__ out,
-    real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K, int acc) {
+    real* __restrict__ gx, real* __restrict__ gLout, int64_t N, int K, int acc,
+    real* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: d[K][64] | q[K][64] (lane = env: conflict free)
   real* dS = reinterpret_cast<real*>(smem_raw);
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(64) void vec_env_kernel(
     if (MODE == 0) out[n] = quad;
     if (MODE == 2) out[n] = real(-0.5) * quad - logdet - real(0.5 * LOG_2PI) * (real)K;
     if (MODE == 1) {
+      if (aux) aux[n] = quad;                       // |L^-1 (x - y)|^2 for the KL diagnostics
       const real m = real(0.5) * quad;
       if (m > eps) {
         const real s = sqrt(m / eps);
@@ -178,7 +180,7 @@ template <typename real, int MODE, bool BWD>
 __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     real eps, const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gx,
-    real* __restrict__ gLout, int64_t N, int K, int acc) {
+    real* __restrict__ gLout, int64_t N, int K, int acc, real* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Ls = reinterpret_cast<real*>(smem_raw);               // [K][KP]
   const int KP = sm_pitch(K);
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
         if (MODE == 0 && lane == 0) out[n[s]] = quad[s];
         if (MODE == 2 && lane == 0)
           out[n[s]] = real(-0.5) * quad[s] - logdet - real(0.5 * LOG_2PI) * (real)K;
+        if (MODE == 1 && aux && lane == 0) aux[n[s]] = quad[s];
         if (MODE == 1 && in) {
           const real m = real(0.5) * quad[s];
           real o = xv[s];
@@ -575,18 +578,18 @@ int set_lds(F kern, size_t lds) {
 template <typename real, int MODE, bool BWD>
 int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, real eps,
                       const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                      hipStream_t st, int acc) {
+                      hipStream_t st, int acc, real* aux) {
   if (sL == 0) {
     const size_t lds = (size_t)K * sm_pitch(K) * sizeof(real);
     set_lds(vec_env_shared_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_shared_kernel<real, MODE, BWD>),
                        dim3((unsigned)ceil_div(N, VS_EPB)), dim3(VS_BT), lds, st, x, y, L, eps,
-                       gout, out, gx, gL, N, K, acc);
+                       gout, out, gx, gL, N, K, acc, aux);
   } else {
     const size_t lds = 2 * (size_t)K * 64 * sizeof(real);
     set_lds(vec_env_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_kernel<real, MODE, BWD>), dim3((unsigned)ceil_div(N, 64)),
-                       dim3(64), lds, st, x, y, L, sL, eps, gout, out, gx, gL, N, K, acc);
+                       dim3(64), lds, st, x, y, L, sL, eps, gout, out, gx, gL, N, K, acc, aux);
   }
   TCE_LAUNCH_CHECK();
   return 0;
@@ -595,10 +598,11 @@ int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, r
 template <typename real>
 int vec_env_launch(int mode, int bwd, const real* x, const real* y, const real* L, int64_t sL,
                    real eps, const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                   hipStream_t st, int acc = 0) {
+                   hipStream_t st, int acc = 0, real* aux = nullptr) {
 #define VE_CASE(M, B)                                                                       \
   if (mode == M && (bwd != 0) == B)                                                         \
-    return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st, acc);
+    return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st, acc, \
+                                         aux);
   VE_CASE(0, false) VE_CASE(0, true) VE_CASE(1, false) VE_CASE(1, true) VE_CASE(2, false)
   VE_CASE(2, true)
 #undef VE_CASE
@@ -660,6 +664,17 @@ int tce_kl_proj_impl(int impl) {
                   "vec_env: null output");                                        \
     return vec_env_launch<REAL>(mode, bwd, x, y, L, L_stride, eps, grad_out, out,   \
                                 grad_x, grad_L, N, K, (hipStream_t)stream);         \
+  }                                                                               \
+  /* forward of mode 1 that also stores |L^-1 (x - y)|^2 per env */               \
+  int tce_mean_proj_fwd_q_##SFX(const REAL* x, const REAL* y, const REAL* L,      \
+                                int64_t L_stride, REAL eps, REAL* out,            \
+                                REAL* quad_out, int64_t N, int K, void* stream) { \
+    TCE_CHECK_ARG(x && y && L && out && quad_out && N > 0 && K > 0 &&             \
+                      K <= VE_MAXK,                                               \
+                  "mean_proj_fwd_q: bad arguments (K <= 64)");                    \
+    return vec_env_launch<REAL>(1, 0, x, y, L, L_stride, eps, nullptr, out,       \
+                                nullptr, nullptr, N, K, (hipStream_t)stream, 0,   \
+                                quad_out);                                        \
   }                                                                               \
   /* backward of mode 1 (mean projection) that ADDS to grad_x */                  \
   int tce_mean_proj_bwd_acc_##SFX(const REAL* x, const REAL* y, const REAL* L,    \

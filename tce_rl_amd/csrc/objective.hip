@@ -84,7 +84,8 @@ template <typename real>
 __global__ __launch_bounds__(KE_BT) void kl_shared_env_kernel(
     const real* __restrict__ mn, const real* __restrict__ mo, const real* __restrict__ mp,
     const real* __restrict__ Lo, const real* __restrict__ Lp, int64_t N, int K, real gscale,
-    real* __restrict__ gmean, double* __restrict__ partials) {
+    real* __restrict__ gmean, double* __restrict__ partials, const real* __restrict__ quad,
+    real eps_mean) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Los = reinterpret_cast<real*>(smem_raw);     // [K][KP]
   const int KP = sm_pitch(K);
@@ -106,13 +107,34 @@ __global__ __launch_bounds__(KE_BT) void kl_shared_env_kernel(
     const int64_t n = n0 + i;
     if (n >= N) break;
     real a = 0, b = 0, c = 0;
-    if (in) { a = mn[n * K + lane]; b = mo[n * K + lane]; c = mp[n * K + lane]; }
-    real v[3] = {a - b, c - b, a - c};
-    const real* const Ls[3] = {Los, Los, Lps};
-    const real rd[3] = {rdo, rdo, rdp};
-    lv_solve_lower<real, 3>(v, Ls, rd, K, KP, lane);
-    m1 += (double)v[0] * (double)v[0];
-    m3 += (double)v[1] * (double)v[1];
+    if (in) { a = mn[n * K + lane]; c = mp[n * K + lane]; }
+    real v[3] = {0, 0, a - c};
+    if (quad) {
+      // the mean projection has formed q = |Lo^-1 (new - old)|^2 already
+      // (tce_mean_proj_fwd_q_*), and proj - old = (new - old) / s: maha(new, old)
+      // = q, maha(proj, old) = q / s^2 -- ONE forward substitution instead of three
+      // (the kernel is bound by the instructions its waves issue, not by the
+      // length of the chain: C2 policy updates/s + 3.6 %)
+      const real q = quad[n];
+      const real m = real(0.5) * q;
+      real s2 = 1;
+      if (m > eps_mean) s2 = m / eps_mean;                    // s^2
+      if (lane == 0) { m1 += (double)q; m3 += (double)q / (double)s2; }
+      real w1[1] = {v[2]};
+      const real* const L1[1] = {Lps};
+      const real r1[1] = {rdp};
+      lv_solve_lower<real, 1>(w1, L1, r1, K, KP, lane);
+      v[2] = w1[0];
+    } else {
+      if (in) b = mo[n * K + lane];
+      v[0] = a - b;
+      v[1] = c - b;
+      const real* const Ls[3] = {Los, Los, Lps};
+      const real rd[3] = {rdo, rdo, rdp};
+      lv_solve_lower<real, 3>(v, Ls, rd, K, KP, lane);
+      m1 += (double)v[0] * (double)v[0];
+      m3 += (double)v[1] * (double)v[1];
+    }
     m2 += (double)v[2] * (double)v[2];
     if (gmean) {                                      // w = Lp^-T z
       real w[1] = {v[2]};
@@ -226,7 +248,8 @@ int surrogate(const real* lp_new, const real* lp_old, const real* adv, int64_t M
 template <typename real>
 int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, const real* Lo,
               const real* Lp, int64_t N, int K, real coeff, int include_cov, real* out,
-              real* gmean, real* gL, double* ws, hipStream_t st) {
+              real* gmean, real* gL, double* ws, hipStream_t st, const real* quad = nullptr,
+              real eps_mean = real(0)) {
   TCE_CHECK_ARG(mn && mo && mp && Ln && Lo && Lp && out && ws && N > 0 && K > 0 && K <= 64,
                 "kl_shared: bad arguments (K <= 64)");
   const int nblk = (int)ceil_div(N, KE_EPB);
@@ -234,7 +257,7 @@ int kl_shared(const real* mn, const real* mo, const real* mp, const real* Ln, co
   if (lds_e > 48 * 1024)
     tce_lds_limit(reinterpret_cast<const void*>(kl_shared_env_kernel<real>), (size_t)(lds_e));
   hipLaunchKernelGGL(kl_shared_env_kernel<real>, dim3(nblk), dim3(KE_BT), lds_e, st, mn, mo, mp,
-                     Lo, Lp, N, K, coeff / (real)N, gmean, ws);
+                     Lo, Lp, N, K, coeff / (real)N, gmean, ws, quad, eps_mean);
   TCE_LAUNCH_CHECK();
   const int par = (size_t)6 * K * sm_pitch(K) * sizeof(double) <= 150 * 1024;   // K <= 55
   const size_t lds_m = (size_t)(par ? 6 : 4) * K * sm_pitch(K) * sizeof(double);
@@ -275,7 +298,7 @@ inline ObjSide* obj_side() {
 
 inline int64_t obj_up4(int64_t n) { return (n + 3) / 4 * 4; }
 inline int64_t obj_ws_len(int64_t N, int K, int P) {
-  return 3 * obj_up4(N * K) + 2 * obj_up4(N * P) + 4 * obj_up4((int64_t)K * K);
+  return 3 * obj_up4(N * K) + 2 * obj_up4(N * P) + 4 * obj_up4((int64_t)K * K) + obj_up4(N);
 }
 template <typename real>
 inline real* obj_proj_L(real* ws, int64_t N, int K, int P) {
@@ -334,6 +357,7 @@ template <typename real> struct ObjApi;
 template <> struct ObjApi<float> {
   static constexpr auto vec_env = tce_vec_env_f32;
   static constexpr auto mean_bwd_acc = tce_mean_proj_bwd_acc_f32;
+  static constexpr auto mean_fwd_q = tce_mean_proj_fwd_q_f32;
   static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f32;
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f32;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f32;
@@ -344,6 +368,7 @@ template <> struct ObjApi<float> {
 template <> struct ObjApi<double> {
   static constexpr auto vec_env = tce_vec_env_f64;
   static constexpr auto mean_bwd_acc = tce_mean_proj_bwd_acc_f64;
+  static constexpr auto mean_fwd_q = tce_mean_proj_fwd_q_f64;
   static constexpr auto proj_fwd = tce_kl_cov_proj_fwd_f64;
   static constexpr auto proj_bwd = tce_kl_cov_proj_bwd_f64;
   static constexpr auto pl_fwd = tce_pair_logprob_fwd_f64;
@@ -411,13 +436,13 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
     OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
     OBJ_HIP(hipEventRecord(S->ev[1], sd));
   }
-  OBJ_TRY(A::vec_env(1, 0, mean_new, mean_old, L_old, 0, eps_mean, nullptr, pm, nullptr,
-                     nullptr, N, K, st));
+  real* quad = g_pL + 3 * obj_up4((int64_t)K * K);           // [N] |Lo^-1 (new - old)|^2
+  OBJ_TRY(A::mean_fwd_q(mean_new, mean_old, L_old, 0, eps_mean, pm, quad, N, K, st));
   OBJ_HIP(hipEventRecord(S->ev[2], st));
   // ---- side: KL diagnostics, entropy, trust region loss and its gradients
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
   OBJ_TRY(kl_shared<real>(mean_new, mean_old, pm, L_new, L_old, pL, N, K, tr_coeff,
-                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd));
+                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd, quad, eps_mean));
   // grad_mean (written by kl_shared_env_kernel on the side stream) is complete
   // here: the deferred join adds to it on `st` before ev[4] is waited for
   OBJ_HIP(hipEventRecord(S->ev[5], sd));
