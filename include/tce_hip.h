@@ -280,13 +280,15 @@ int tce_vec_env_f64(int mode, int bwd, const double* x, const double* y, const d
 /* The forward of mode 1 (mean projection) that also stores the squared
  * Mahalanobis distance it is built on, quad_out[n] = |L^-1 (x_n - y_n)|^2: the
  * policy objective's KL diagnostics take maha(new, old) and maha(proj, old) =
- * quad / s^2 from it instead of solving those two systems again. */
+ * quad / s^2 from it instead of solving those two systems again.  z_out
+ * (nullable; shared L only): z = L^-1 (x - y) [N, K] for
+ * tce_mean_proj_bwd_acc_*, whose backward then is one substitution, not two. */
 int tce_mean_proj_fwd_q_f32(const float* x, const float* y, const float* L,
                             int64_t L_stride, float eps, float* out, float* quad_out,
-                            int64_t N, int K, void* stream);
+                            float* z_out, int64_t N, int K, void* stream);
 int tce_mean_proj_fwd_q_f64(const double* x, const double* y, const double* L,
                             int64_t L_stride, double eps, double* out, double* quad_out,
-                            int64_t N, int K, void* stream);
+                            double* z_out, int64_t N, int K, void* stream);
 /* The backward of mode 1 (mean projection) that ADDS its result to grad_x
  * instead of storing it: the policy objective's two halves of d / d mean_new
  * (trust region loss, written on its second stream; surrogate through the
@@ -294,10 +296,12 @@ int tce_mean_proj_fwd_q_f64(const double* x, const double* y, const double* L,
  * whatever wrote grad_x. */
 int tce_mean_proj_bwd_acc_f32(const float* x, const float* y, const float* L,
                               int64_t L_stride, float eps, const float* grad_out,
-                              float* grad_x, int64_t N, int K, void* stream);
+                              const float* z, float* grad_x, int64_t N, int K,
+                              void* stream);
 int tce_mean_proj_bwd_acc_f64(const double* x, const double* y, const double* L,
                               int64_t L_stride, double eps, const double* grad_out,
-                              double* grad_x, int64_t N, int K, void* stream);
+                              const double* z, double* grad_x, int64_t N, int K,
+                              void* stream);
 int tce_kl_cov_part_f32(int bwd, const float* L, const float* L_old,
                         int64_t L_old_stride, const float* grad_out, float* out,
                         float* grad_L, int64_t B, int K, void* stream);

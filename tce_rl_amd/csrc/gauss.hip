@@ -180,7 +180,8 @@ template <typename real, int MODE, bool BWD>
 __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     real eps, const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gx,
-    real* __restrict__ gLout, int64_t N, int K, int acc, real* __restrict__ aux) {
+    real* __restrict__ gLout, int64_t N, int K, int acc, real* __restrict__ aux,
+    real* __restrict__ aux2) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Ls = reinterpret_cast<real*>(smem_raw);               // [K][KP]
   const int KP = sm_pitch(K);
@@ -210,7 +211,14 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
     }
     const real* const Lp[2] = {Ls, Ls};
     const real rd[2] = {rdk, rdk};
-    lv_solve_lower<real, 2>(d, Lp, rd, K, KP, lane);
+    if (MODE == 1 && BWD && aux2) {
+      // z = L^-1 (x - y) as the forward pass left it (tce_mean_proj_fwd_q_*): the
+      // backward is one substitution instead of two
+#pragma unroll
+      for (int s = 0; s < 2; ++s) d[s] = in ? aux2[n[s] * K + lane] : real(0);
+    } else {
+      lv_solve_lower<real, 2>(d, Lp, rd, K, KP, lane);
+    }
     real quad[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) quad[s] = wave_sum(d[s] * d[s]);
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
         if (MODE == 2 && lane == 0)
           out[n[s]] = real(-0.5) * quad[s] - logdet - real(0.5 * LOG_2PI) * (real)K;
         if (MODE == 1 && aux && lane == 0) aux[n[s]] = quad[s];
+        if (MODE == 1 && aux2 && in) aux2[n[s] * K + lane] = d[s];
         if (MODE == 1 && in) {
           const real m = real(0.5) * quad[s];
           real o = xv[s];
@@ -234,9 +243,11 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
       }
       continue;
     }
-    // backward: q = L^-T d
+    // backward: q = L^-T d (mean projection: only rows outside the trust region
+    // use it -- skipped when neither env of the pair is)
     real q[2] = {d[0], d[1]};
-    lv_solve_lower_t<real, 2>(q, Lp, rd, K, KP, lane);
+    if (MODE != 1 || real(0.5) * quad[0] > eps || real(0.5) * quad[1] > eps)
+      lv_solve_lower_t<real, 2>(q, Lp, rd, K, KP, lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (s == 1 && !ok1) break;
@@ -578,13 +589,13 @@ int set_lds(F kern, size_t lds) {
 template <typename real, int MODE, bool BWD>
 int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, real eps,
                       const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                      hipStream_t st, int acc, real* aux) {
+                      hipStream_t st, int acc, real* aux, real* aux2) {
   if (sL == 0) {
     const size_t lds = (size_t)K * sm_pitch(K) * sizeof(real);
     set_lds(vec_env_shared_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_shared_kernel<real, MODE, BWD>),
                        dim3((unsigned)ceil_div(N, VS_EPB)), dim3(VS_BT), lds, st, x, y, L, eps,
-                       gout, out, gx, gL, N, K, acc, aux);
+                       gout, out, gx, gL, N, K, acc, aux, aux2);
   } else {
     const size_t lds = 2 * (size_t)K * 64 * sizeof(real);
     set_lds(vec_env_kernel<real, MODE, BWD>, lds);
@@ -598,11 +609,13 @@ int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, r
 template <typename real>
 int vec_env_launch(int mode, int bwd, const real* x, const real* y, const real* L, int64_t sL,
                    real eps, const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                   hipStream_t st, int acc = 0, real* aux = nullptr) {
+                   hipStream_t st, int acc = 0, real* aux = nullptr, real* aux2 = nullptr) {
+  // (aux2, the stored z of the mean projection: shared factor only)
+  if (sL != 0) aux2 = nullptr;
 #define VE_CASE(M, B)                                                                       \
   if (mode == M && (bwd != 0) == B)                                                         \
     return vec_env_launch_mb<real, M, B>(x, y, L, sL, eps, gout, out, gx, gL, N, K, st, acc, \
-                                         aux);
+                                         aux, aux2);
   VE_CASE(0, false) VE_CASE(0, true) VE_CASE(1, false) VE_CASE(1, true) VE_CASE(2, false)
   VE_CASE(2, true)
 #undef VE_CASE
@@ -668,24 +681,26 @@ int tce_kl_proj_impl(int impl) {
   /* forward of mode 1 that also stores |L^-1 (x - y)|^2 per env */               \
   int tce_mean_proj_fwd_q_##SFX(const REAL* x, const REAL* y, const REAL* L,      \
                                 int64_t L_stride, REAL eps, REAL* out,            \
-                                REAL* quad_out, int64_t N, int K, void* stream) { \
+                                REAL* quad_out, REAL* z_out, int64_t N, int K,    \
+                                void* stream) {                                   \
     TCE_CHECK_ARG(x && y && L && out && quad_out && N > 0 && K > 0 &&             \
-                      K <= VE_MAXK,                                               \
-                  "mean_proj_fwd_q: bad arguments (K <= 64)");                    \
+                      K <= VE_MAXK && (z_out == nullptr || L_stride == 0),        \
+                  "mean_proj_fwd_q: bad arguments (K <= 64; z_out: shared L)");   \
     return vec_env_launch<REAL>(1, 0, x, y, L, L_stride, eps, nullptr, out,       \
                                 nullptr, nullptr, N, K, (hipStream_t)stream, 0,   \
-                                quad_out);                                        \
+                                quad_out, z_out);                                 \
   }                                                                               \
   /* backward of mode 1 (mean projection) that ADDS to grad_x */                  \
   int tce_mean_proj_bwd_acc_##SFX(const REAL* x, const REAL* y, const REAL* L,    \
                                   int64_t L_stride, REAL eps,                     \
-                                  const REAL* grad_out, REAL* grad_x, int64_t N,  \
-                                  int K, void* stream) {                          \
+                                  const REAL* grad_out, const REAL* z,            \
+                                  REAL* grad_x, int64_t N, int K, void* stream) { \
     TCE_CHECK_ARG(x && y && L && grad_out && grad_x && N > 0 && K > 0 &&          \
-                      K <= VE_MAXK,                                               \
-                  "mean_proj_bwd_acc: bad arguments (K <= 64)");                  \
+                      K <= VE_MAXK && (z == nullptr || L_stride == 0),            \
+                  "mean_proj_bwd_acc: bad arguments (K <= 64; z: shared L)");     \
     return vec_env_launch<REAL>(1, 1, x, y, L, L_stride, eps, grad_out, nullptr,  \
-                                grad_x, nullptr, N, K, (hipStream_t)stream, 1);   \
+                                grad_x, nullptr, N, K, (hipStream_t)stream, 1,    \
+                                nullptr, const_cast<REAL*>(z));                   \
   }                                                                               \
   int tce_kl_cov_part_##SFX(int bwd, const REAL* L, const REAL* L_old,            \
                             int64_t L_old_stride, const REAL* grad_out,           \

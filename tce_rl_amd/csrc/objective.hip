@@ -437,7 +437,10 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
     OBJ_HIP(hipEventRecord(S->ev[1], sd));
   }
   real* quad = g_pL + 3 * obj_up4((int64_t)K * K);           // [N] |Lo^-1 (new - old)|^2
-  OBJ_TRY(A::mean_fwd_q(mean_new, mean_old, L_old, 0, eps_mean, pm, quad, N, K, st));
+  // (gm_p: in the deferred join the projection's backward adds into grad_mean, so
+  // that slot is free to carry z = Lo^-1 (new - old) from the forward to it)
+  real* zbuf = ((defer_join & 1) && !(defer_join & 2)) ? gm_p : nullptr;
+  OBJ_TRY(A::mean_fwd_q(mean_new, mean_old, L_old, 0, eps_mean, pm, quad, zbuf, N, K, st));
   OBJ_HIP(hipEventRecord(S->ev[2], st));
   // ---- side: KL diagnostics, entropy, trust region loss and its gradients
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
@@ -507,7 +510,8 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
     // (what obj_add2_kernel did in a launch of its own, same operands and order);
     // grad_L lacks the projection's part until tce_policy_objective_end_*
     OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
-    return A::mean_bwd_acc(mean_new, mean_old, L_old, 0, eps_mean, g_pm, grad_mean, N, K, st);
+    return A::mean_bwd_acc(mean_new, mean_old, L_old, 0, eps_mean, g_pm, zbuf, grad_mean, N, K,
+                           st);
   }
   OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
                      nullptr, N, K, st));

@@ -164,8 +164,24 @@ def test_mean_projection_backward_accumulating_form(ops, shared, dtype):
          ptr(go), None, ptr(gx), None, N, K, stream())
     acc = base.clone()
     call("tce_mean_proj_bwd_acc_" + sfx(dtype), ptr(mu), ptr(mu_o), ptr(Lg), sL,
-         0.5, ptr(go), ptr(acc), N, K, stream())
+         0.5, ptr(go), None, ptr(acc), N, K, stream())
     assert torch.equal(acc, base + gx)
+    # ... and with z = L^-1 (x - y) handed over by the forward pass (shared L),
+    # which also returns |z|^2 per env
+    if shared:
+        pm, quad, z = (torch.empty_like(mu), torch.empty(N, dtype=dtype, device="cuda"),
+                       torch.empty_like(mu))
+        call("tce_mean_proj_fwd_q_" + sfx(dtype), ptr(mu), ptr(mu_o), ptr(Lg), sL,
+             0.5, ptr(pm), ptr(quad), ptr(z), N, K, stream())
+        ref = torch.empty_like(mu)
+        call("tce_vec_env_" + sfx(dtype), 1, 0, ptr(mu), ptr(mu_o), ptr(Lg), sL, 0.5,
+             None, ptr(ref), None, None, N, K, stream())
+        assert torch.equal(pm, ref)
+        torch.testing.assert_close(quad, (z * z).sum(-1), rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=0)
+        acc2 = base.clone()
+        call("tce_mean_proj_bwd_acc_" + sfx(dtype), ptr(mu), ptr(mu_o), ptr(Lg), sL,
+             0.5, ptr(go), ptr(z), ptr(acc2), N, K, stream())
+        assert torch.equal(acc2, acc)
 
 
 @pytest.mark.parametrize("K", [5, 24, 36, 63])
