@@ -182,8 +182,9 @@ int tce_pair_logprob_bwd_f64(
  * grad_logp[n, p] = -exp(logp[n, p] - logp_old[n, p]) adv[n, p] / (N P)
  * (surrogate_loss, mprl/rl/agent/temporal_correlated_agent.py:641-660) from the
  * log-prob the backward kernel recomputes anyway -- neither the forward pass nor
- * tce_surrogate_* has to run before it (the policy epoch moves both, which
- * then only feed the record row, off its critical path).  Only for the shared
+ * tce_surrogate_* has to run before it; logp_out (nullable, [N, P]) receives that
+ * log-prob, so the loss VALUE needs no forward pass either (the policy epoch
+ * runs tce_surrogate_* for the record row on its second stream).  Only for the shared
  * factor's fast path known to run: L_stride 0, an affine time grid, >= 256 envs,
  * times_flags bit 3 (the caller has checked that all segments start together);
  * anything else is refused. */
@@ -193,16 +194,16 @@ int tce_pair_logprob_bwd_sur_f32(
     float scaled_dt, float inv_scale_g, int rel_goal, const float* times,
     int times_flags, const float* init_time, const float* init_pos,
     const float* init_vel, float reg, const float* logp_old, const float* adv,
-    float* grad_mean, float* grad_L, float* basis_ws, int* flag_ws, float* work,
-    int64_t N, int T, int P, int dof, void* stream);
+    float* logp_out, float* grad_mean, float* grad_L, float* basis_ws, int* flag_ws,
+    float* work, int64_t N, int T, int P, int dof, void* stream);
 int tce_pair_logprob_bwd_sur_f64(
     const double* traj, const double* mean, const double* L, int64_t L_stride,
     const int64_t* pairs, const double* tab, int M, int nbg, double tau, double delay,
     double scaled_dt, double inv_scale_g, int rel_goal, const double* times,
     int times_flags, const double* init_time, const double* init_pos,
     const double* init_vel, double reg, const double* logp_old, const double* adv,
-    double* grad_mean, double* grad_L, double* basis_ws, int* flag_ws, double* work,
-    int64_t N, int T, int P, int dof, void* stream);
+    double* logp_out, double* grad_mean, double* grad_L, double* basis_ws, int* flag_ws,
+    double* work, int64_t N, int T, int P, int dof, void* stream);
 /* Scheduling hint, process-wide: the number of compute units the caller expects
  * to be free for the kernels it is about to enqueue (0 = the whole chip, the
  * default).  The pair log-prob fast path trades latency for wave-instructions

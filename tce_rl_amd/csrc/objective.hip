@@ -453,10 +453,10 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
   const bool split = (defer_join & 2) != 0;
   // The backward pair kernels recompute the log-prob and can form the surrogate's
-  // gradient themselves (tce_pair_logprob_bwd_sur_*): the forward pass and the
-  // surrogate kernel then only feed the record row and run on the side stream
-  // BEHIND the projection's backward, off the epoch's critical path (C2: 32 + 12
-  // us and two launch boundaries of a 360 us epoch).  Where the shared-factor
+  // gradient themselves and leave the log-probs behind
+  // (tce_pair_logprob_bwd_sur_*): no forward pass at all (C2: 32 us of all-CU
+  // time per epoch, 83 at K 63), and the surrogate sums, which then only feed the
+  // record row, run on the side stream.  Where the shared-factor
   // fast path is known to run (what the deferred join's caller, the direct
   // epoch, guarantees with flag bit 3); with one stream the same kernels in
   // the same roles, one after the other.
@@ -466,8 +466,8 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
   if (inline_sur) {
     // (the backward call runs pair_prep: the forward's flags said so)
     OBJ_TRY(A::pl_bwd_sur(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
-                          rel_goal, times, flags_fwd, t0, y0, v0, reg, logp_old, adv, g_pm, g_pL,
-                          basis_ws, flag_ws, pl_work, N, T, P, dof, st));
+                          rel_goal, times, flags_fwd, t0, y0, v0, reg, logp_old, adv, logp, g_pm,
+                          g_pL, basis_ws, flag_ws, pl_work, N, T, P, dof, st));
   } else {
     OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
                       rel_goal, times, flags_fwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
@@ -495,12 +495,9 @@ int policy_objective(const real* mean_new, const real* L_new, const real* mean_o
                         K, sd));
   }
   if (inline_sur) {
-    // the loss value for the record: forward pair kernels + surrogate sums, behind
-    // the projection's backward on the side stream (they read pm / pL / the pair
-    // records, all final; flags_bwd: the records of this L are in the workspace)
-    OBJ_TRY(A::pl_fwd(traj, pm, pL, 0, pairs, tab, M, nbg, tau, delay, scaled_dt, inv_scale_g,
-                      rel_goal, times, flags_bwd, t0, y0, v0, reg, logp, basis_ws, flag_ws,
-                      pl_work, N, T, P, dof, sd));
+    // the loss value for the record: the surrogate sums over the log-probs the
+    // backward kernels left behind, on the side stream behind the projection's
+    // backward (which waited for ev[3], i.e. for those kernels)
     OBJ_TRY(surrogate<real>(logp, logp_old, adv, N * (int64_t)P, sur2, (real*)nullptr, sur_ws, sd));
   }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(1024) void pair_env_kernel(
                              real(0.5) * (real)R * real(1.8378770664093453);
             const real ra = exp(lpn - lp_old[n * P + p]) * adv[n * P + p];
             g = -ra * inv_m;
+            if (logp) logp[n * P + p] = lpn;         // for the loss value (record row)
           } else {
             g = gout[n * P + p];
           }
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(256) void pair_env_static_kernel(
                            real(0.5) * (real)R * real(1.8378770664093453);
           const real ra = exp(lpn - lp_old[n * P + p]) * adv[n * P + p];
           g = -ra * inv_m;
+          if (logp) logp[n * P + p] = lpn;
         } else {
           g = gout[n * P + p];
         }
@@ -1041,14 +1043,14 @@ int64_t tce_pair_logprob_work_len(int64_t N, int P, int dof, int nbg, int64_t L_
       REAL delay, REAL scaled_dt, REAL inv_scale_g, int rel_goal,                \
       const REAL* times, int times_general, const REAL* init_time,               \
       const REAL* init_pos, const REAL* init_vel, REAL reg,                      \
-      const REAL* logp_old, const REAL* adv, REAL* grad_mean, REAL* grad_L,      \
-      REAL* basis_ws, int* flag_ws, REAL* work, int64_t N, int T, int P,         \
-      int dof, void* stream) {                                                   \
+      const REAL* logp_old, const REAL* adv, REAL* logp_out, REAL* grad_mean,    \
+      REAL* grad_L, REAL* basis_ws, int* flag_ws, REAL* work, int64_t N, int T,  \
+      int P, int dof, void* stream) {                                            \
     TCE_CHECK_ARG(logp_old && adv, "pair_logprob_bwd_sur: null buffer");         \
     return pl_launch<REAL>(true, traj, mean, L, L_stride, pairs, tab, M, nbg,    \
                            tau, delay, scaled_dt, inv_scale_g, rel_goal, times,  \
                            times_general, init_time, init_pos, init_vel, reg,    \
-                           nullptr, nullptr, grad_mean, grad_L, basis_ws,        \
+                           logp_out, nullptr, grad_mean, grad_L, basis_ws,       \
                            flag_ws, work, N, T, P, dof, (hipStream_t)stream,     \
                            logp_old, adv);                                       \
   }                                                                              \
