@@ -674,6 +674,43 @@ int tce_policy_epoch2_f64(
     double weight_decay, double clip_grad, double grad_scale, int do_adam, int balance,
     double* rec_row19, double* bal2, void* stream);
 
+/* One whole policy epoch of the black-box agent in one call, for the mean nets
+ * the 64-wide row kernels (tce_bb_policy_epochs_f32) do not cover:
+ * mprl/rl/agent/black_box_agent.py:225-339 with the nets of
+ * mprl/config/box_push_random_init/bbrl/entire/shared.yaml:66-67 (128 x 2) and
+ * mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:72-73 (256 x 1).
+ * Replaces per epoch: policy.policy(states), projection(...), policy.log_prob,
+ * surrogate_loss, kl_old_new_proj, entropy_loss, get_trust_region_loss,
+ * zero_grad / backward, grad_norm_clip, optimizer.step -- and, with balance != 0
+ * (:226-284), the two extra passes whose gradient norms go to bal2.
+ * net_kind / hidden / num_hidden / param / grad / partials / ol_ws / ws / rec_row19 /
+ * balance / do_adam: as tce_policy_epoch2_*; obj_ws:
+ * [tce_bb_policy_objective_ws_len(N, K)]; the other objective arguments as
+ * tce_bb_policy_objective_*.  After the call ws holds this epoch's mean_new [N,K]
+ * at 2 up4(N hidden) and L_new [K,K] at 2 up4(N hidden) + 2 up4(N K) (up4: rounded
+ * up to a multiple of 4); proj_mean_out [N,K] / proj_L_out [K,K] (nullable)
+ * receive the projected distribution. */
+int tce_bb_policy_epoch_f32(
+    const float* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+    int net_kind, int act, int nvec, float min_std, float* param, float* grad,
+    const float* mean_old, const float* L_old, const float* actions, const float* logp_old,
+    const float* adv, float eps_mean, double eps_cov, const float* beta, int entropy_eq,
+    double* proj_ctx, float tr_coeff, int tr_include_cov, float ent_coef, double* sur_ws,
+    double* kl_ws, float* obj_ws, float* ws, float* partials, float* ol_ws, int K, float* m,
+    float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
+    float weight_decay, float clip_grad, float grad_scale, int do_adam, int balance,
+    float* rec_row19, float* bal2, float* proj_mean_out, float* proj_L_out, void* stream);
+int tce_bb_policy_epoch_f64(
+    const double* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+    int net_kind, int act, int nvec, double min_std, double* param, double* grad,
+    const double* mean_old, const double* L_old, const double* actions, const double* logp_old,
+    const double* adv, double eps_mean, double eps_cov, const double* beta, int entropy_eq,
+    double* proj_ctx, double tr_coeff, int tr_include_cov, double ent_coef, double* sur_ws,
+    double* kl_ws, double* obj_ws, double* ws, double* partials, double* ol_ws, int K, double* m,
+    double* v, double* opt_state, double lr, double beta1, double beta2, double eps,
+    double weight_decay, double clip_grad, double grad_scale, int do_adam, int balance,
+    double* rec_row19, double* bal2, double* proj_mean_out, double* proj_L_out, void* stream);
+
 /* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
  * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->
  * mprl/util/util_nn.py:225-246) -- on the kernels of the fused critic epoch.
@@ -847,6 +884,33 @@ int tce_pmlp_backward_f64(const double* x, int64_t x_stride, int64_t N, int din,
                           int num_hidden, int dout, int act, const double* param,
                           const double* h1, const double* h2, const double* grad_out,
                           double* partials, double* grad, void* stream);
+
+/* One full-batch epoch of a value function D_in -> H (-> H) -> 1 of the shapes
+ * above (the black-box agent's 256 x 1 critic of
+ * mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:90-91):
+ * mprl/rl/agent/black_box_agent.py:128-146 -- critic(states), value_loss
+ * (:438-466, clip_critic > 0: old_values required), backward, grad_norm_clip,
+ * Adam -- as forward, one loss kernel, backward, one clip + Adam launch.
+ * param / grad / m / v: FLAT in MLP.parameters() order (P <= 2^17); step: the
+ * optimizer's step count INCLUDING this update; ws: [tce_pmlp_critic_ws_len(N,
+ * hidden)] elements, ZEROED once by the caller (the loss kernel re-arms its
+ * ticket); partials: [tce_pmlp_max_slabs()][P]; rec_row3 = {loss, |g|, |g|
+ * clipped}.  do_adam == 0: the caller (env shards) all-reduces `grad` and steps. */
+int64_t tce_pmlp_critic_ws_len(int64_t N, int hidden);
+int tce_pmlp_critic_epoch_f32(const float* x, int64_t x_stride, const float* returns,
+                              const float* old_values, int64_t N, int din, int hidden,
+                              int num_hidden, int act, float clip_critic, float* param,
+                              float* grad, float* m, float* v, float* opt_state, float lr,
+                              float beta1, float beta2, float eps, float weight_decay,
+                              float clip_grad, float grad_scale, int do_adam, float step,
+                              float* ws, float* partials, float* rec_row3, void* stream);
+int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* returns,
+                              const double* old_values, int64_t N, int din, int hidden,
+                              int num_hidden, int act, double clip_critic, double* param,
+                              double* grad, double* m, double* v, double* opt_state, double lr,
+                              double beta1, double beta2, double eps, double weight_decay,
+                              double clip_grad, double grad_scale, int do_adam, double step,
+                              double* ws, double* partials, double* rec_row3, void* stream);
 
 /* ---- small two-hidden-layer networks (black-box agent) ----------------------
  * D_in <= 64 -> H -> H -> D_out (H in {32, 64}, D_out <= 64), fp32, torch

@@ -306,10 +306,15 @@ class OracleBBRL:
     def __init__(self, mp_args, num_env, dim_obs, policy_hidden, critic_hidden,
                  act, std_only, min_std, out_layer_gain, lr, epochs, mean_bound,
                  cov_bound, tr_coeff, set_variance, norm_advantages=True,
-                 clip_advantages=0.0, clip_critic=0.0, dtype=torch.float32):
+                 clip_advantages=0.0, clip_critic=0.0, dtype=torch.float32,
+                 balance=False, weight_decay=0.0):
         mpa = dict(mp_args)
         mpa.pop("dtype", None), mpa.pop("device", None)
         self.mp = ProDMPOracle(dtype=dtype, **mpa)
+        # balance: this step is one with num_iterations % balance_check == 1
+        # (black_box_agent.py:218-284) -- two extra passes per epoch whose
+        # gradient norms are kept in self.balance_norms
+        self.balance, self.balance_norms = balance, []
         self.dof, self.K = self.mp.num_dof, self.mp.num_dof * self.mp.num_basis_g
         self.N, self.dt, self.dtype = num_env, self.mp.dt, dtype
         self.T = {0.0125: 500, 0.02: 100, 0.008: 350}[self.dt]
@@ -324,8 +329,10 @@ class OracleBBRL:
         self.std_only, self.min_std = std_only, float(min_std)
         self.var = torch.nn.Parameter(
             O.initial_variance_vector(self.K, std_only, dtype))
-        self.p_opt = torch.optim.Adam(list(self.pnet) + [self.var], lr=lr)
-        self.c_opt = torch.optim.Adam(list(self.cnet), lr=lr)
+        self.p_opt = torch.optim.Adam(list(self.pnet) + [self.var], lr=lr,
+                                      weight_decay=weight_decay)
+        self.c_opt = torch.optim.Adam(list(self.cnet), lr=lr,
+                                      weight_decay=weight_decay)
         self.epochs = epochs
         self.mean_bound, self.cov_bound = mean_bound, cov_bound
         self.tr_coeff, self.set_variance = tr_coeff, set_variance
@@ -374,7 +381,31 @@ class OracleBBRL:
             self.c_opt.zero_grad(set_to_none=True)
             loss.backward()
             self.c_opt.step()
+        params = list(self.pnet) + [self.var]
+
+        def grad_norm():                 # util.grad_norm_clip(0.0, params)[0]
+            return torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params
+                                  if p.grad is not None)).item()
         for _ in range(self.epochs):
+            if self.balance:             # black_box_agent.py:226-284
+                mean_new, L_new = self._policy(obs)
+                pm, pL = KO.project(mean_new, L_new, mean_old, L_old,
+                                    self.mean_bound, self.cov_bound, no_beta,
+                                    contextual_std=False)
+                s_loss, _ = O.surrogate_loss(
+                    adv, O.mvn_log_prob(action, pm, pL), lp_old)
+                self.p_opt.zero_grad(set_to_none=True)
+                s_loss.backward()
+                sg = grad_norm()
+                mean_new, L_new = self._policy(obs)
+                pm, pL = KO.project(mean_new, L_new, mean_old, L_old,
+                                    self.mean_bound, self.cov_bound, no_beta,
+                                    contextual_std=False)
+                tr = KO.trust_region_loss(mean_new, L_new, pm, pL,
+                                          self.tr_coeff, not self.set_variance)
+                self.p_opt.zero_grad(set_to_none=True)
+                tr.backward()
+                self.balance_norms.append((sg, grad_norm()))
             mean_new, L_new = self._policy(obs)
             pm, pL = KO.project(mean_new, L_new, mean_old, L_old,
                                 self.mean_bound, self.cov_bound, no_beta,

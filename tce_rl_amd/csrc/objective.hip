@@ -573,7 +573,8 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
                         int entropy_eq, double* proj_ctx, real tr_coeff, int tr_include_cov,
                         real ent_coef, double* sur_ws, double* kl_ws, real* ws, real* grad_mean,
                         real* grad_L, real* sur2, real* out16, real* proj_mean_out,
-                        real* proj_L_out, int64_t N, int K, hipStream_t st) {
+                        real* proj_L_out, int64_t N, int K, hipStream_t st, int proj_started = 0,
+                        int split = 0) {
   typedef ObjApi<real> A;
   TCE_CHECK_ARG(mean_new && L_new && mean_old && L_old && actions && logp_old && adv &&
                     proj_ctx && sur_ws && kl_ws && ws && grad_mean && grad_L && sur2 && out16,
@@ -594,10 +595,14 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   real* gL_p = g_pL + obj_up4(KK);
   real* gL_env = gL_p + obj_up4(KK);              // [N,K,K] d logp / d L per env
   real* sum_ws = gL_env + N * KK;
-  OBJ_HIP(hipEventRecord(S->ev[0], st));
-  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
-  OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
-  OBJ_HIP(hipEventRecord(S->ev[1], sd));
+  // (proj_started: bb_policy_epoch has put the Cholesky head and the covariance
+  // projection on the side stream, beside the mean net's forward)
+  if (!proj_started) {
+    OBJ_HIP(hipEventRecord(S->ev[0], st));
+    OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
+    OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
+    OBJ_HIP(hipEventRecord(S->ev[1], sd));
+  }
   OBJ_TRY(A::vec_env(1, 0, mean_new, mean_old, L_old, 0, eps_mean, nullptr, pm, nullptr,
                      nullptr, N, K, st));
   OBJ_HIP(hipEventRecord(S->ev[2], st));
@@ -611,7 +616,7 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   OBJ_TRY(surrogate<real>(logp, logp_old, adv, N, sur2, glp, sur_ws, st));
   OBJ_TRY(A::vec_env(2, 1, actions, pm, pL, 0, real(0), glp, nullptr, g_pm, gL_env, N, K, st));
   OBJ_TRY(ObjSum<real>::sum_dim0(gL_env, g_pL, sum_ws, N, KK, st));
-  if (ent_coef != real(0)) {
+  if (ent_coef != real(0) && !split) {
     hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
                        ent_coef);
     TCE_LAUNCH_CHECK();
@@ -619,10 +624,29 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   OBJ_HIP(hipEventRecord(S->ev[3], st));
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[3], 0));
   OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p, 1, K, sd));
+  if (split && ent_coef != real(0)) {
+    // the entropy term's own way back (gL_p above is the surrogate's alone); the
+    // per-env slab is free again: its sum was taken in front of ev[3]
+    hipLaunchKernelGGL(obj_ent_only_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0,
+                       sd, g_pL, pL, K, ent_coef);
+    TCE_LAUNCH_CHECK();
+    OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_env, 1, K, sd));
+  }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
   OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
                      nullptr, N, K, st));
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+  if (split) {
+    // nothing is added: grad_mean / grad_L hold the trust region loss's gradient,
+    // ws the surrogate's (gm_p, gL_p) and the entropy term's (gL_env [K,K])
+    if (proj_mean_out)
+      OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_mean_out, pm, sizeof(real) * N * K,
+                                    hipMemcpyDeviceToDevice, st));
+    if (proj_L_out)
+      OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_L_out, pL, sizeof(real) * KK, hipMemcpyDeviceToDevice,
+                                    st));
+    return 0;
+  }
   hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(N * K + KK, 256)), dim3(256),
                      0, st, grad_mean, gm_p, N * (int64_t)K, grad_L, gL_p, KK);
   TCE_LAUNCH_CHECK();
@@ -1098,6 +1122,140 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
   return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
 }
 
+
+// ---------------------------------------------------------------------------
+// One whole policy epoch of the black-box agent (black_box_agent.py:225-339)
+// without autograd in ONE call, for the mean nets the row kernels of
+// csrc/smlp.hip do not cover -- box pushing's 128 x 2 and table tennis's 256 x 1
+// (mprl/config/box_push_random_init/bbrl/entire/shared.yaml:66-67,
+// mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:72-73): Cholesky head +
+// covariance projection on the second stream beside the mean net's forward, the
+// black-box objective and its gradient (bb_policy_objective), the mean net's
+// backward into the flat gradient, then policy_epoch2's tail (Cholesky head
+// backward, clip, Adam, record row).  net_kind / balance / do_adam as there; the
+// workspace has policy_epoch2's layout, obj_ws the one of
+// tce_bb_policy_objective_*.  mean / L of this epoch stay in ws (mean at
+// 2 up4(N H), L behind mean and g_mean); proj_*_out (nullable) receive the
+// projected distribution.
+// ---------------------------------------------------------------------------
+template <typename real>
+int bb_policy_epoch(const real* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
+                    int net_kind, int act, int nvec, real min_std, real* param, real* grad,
+                    const real* mean_old, const real* L_old, const real* actions,
+                    const real* logp_old, const real* adv, real eps_mean, double eps_cov,
+                    const real* beta, int entropy_eq, double* proj_ctx, real tr_coeff,
+                    int tr_include_cov, real ent_coef, double* sur_ws, double* kl_ws, real* obj_ws,
+                    real* ws, real* partials, real* ol_ws, int K, real* m, real* v,
+                    real* opt_state, real lr, real beta1, real beta2, real eps, real weight_decay,
+                    real clip_grad, real grad_scale, int do_adam, int balance, real* rec_row19,
+                    real* bal2, real* proj_mean_out, real* proj_L_out, void* stream) {
+  typedef EpApi<real> E;
+  typedef ObjApi<real> A;
+  TCE_CHECK_ARG(x && param && grad && ws && partials && obj_ws && rec_row19 && N > 0 && K > 0 &&
+                    K <= 64 && mean_old && L_old && proj_ctx,
+                "bb_policy_epoch: bad arguments");
+  TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "bb_policy_epoch: optimizer state missing");
+  TCE_CHECK_ARG(!balance || bal2, "bb_policy_epoch: balance needs bal2");
+  const int H = hidden;
+  if (net_kind == 0)
+    TCE_CHECK_ARG(sizeof(real) == 4 && H == 128 && num_hidden == 2 && din >= 1 && din <= 40 &&
+                      ol_ws,
+                  "bb_policy_epoch: net_kind 0 = float32 D_in <= 40 -> 128 -> 128 -> K");
+  else
+    TCE_CHECK_ARG(net_kind == 1 && tce_pmlp_supported(din, H, num_hidden, K, (int)sizeof(real)),
+                  "bb_policy_epoch: net shape not built (tce_pmlp_supported)");
+  const int64_t PN = (int64_t)H * din + H + (num_hidden == 2 ? (int64_t)H * H + H : 0) +
+                     (int64_t)K * H + K;
+  const int64_t n = PN + nvec;
+  const int64_t KK = (int64_t)K * K;
+  real* var = param + PN;
+  real* g_var = grad + PN;
+  real* h2 = ws;
+  real* h1 = h2 + obj_up4(N * (int64_t)H);
+  real* mean = h1 + obj_up4(N * (int64_t)H);
+  real* g_mean = mean + obj_up4(N * (int64_t)K);
+  real* L = g_mean + obj_up4(N * (int64_t)K);
+  real* g_L = L + obj_up4(KK);
+  real* sur2 = g_L + 2 * obj_up4(KK);
+  real* out16 = sur2 + 4;
+  real* stats = out16 + 16;
+  unsigned* ticket = reinterpret_cast<unsigned*>(stats + 12);
+  real* gtmp = stats + 16;
+  hipStream_t st = (hipStream_t)stream;
+  const bool single = g_obj_streams < 2;
+  ObjSide* S = single ? nullptr : obj_side();
+  TCE_CHECK_ARG(single || S != nullptr, "policy_objective: could not create the side stream");
+  hipStream_t sd = single ? st : S->side;
+  // bb_policy_objective's workspace: where the projected factor and the parts of
+  // a split gradient live
+  real* gm_p = obj_ws + 2 * obj_up4(N * (int64_t)K);
+  real* pL = obj_ws + 3 * obj_up4(N * (int64_t)K) + 2 * obj_up4(N);
+  real* gL_p = pL + 2 * obj_up4(KK);
+  real* gL_e = gL_p + obj_up4(KK);
+  auto net_fwd = [&]() -> int {
+    if (net_kind == 0) return fast_fwd(x, x_stride, N, din, act, param, h2, mean, K, stream);
+    return E::pm_fwd(x, x_stride, N, din, H, num_hidden, K, act, param,
+                     num_hidden == 2 ? h1 : h2, num_hidden == 2 ? h2 : nullptr, mean, stream);
+  };
+  auto net_bwd = [&](const real* gm) -> int {
+    if (net_kind == 0)
+      return fast_bwd(x, x_stride, N, din, act, param, h2, gm, h1, partials, ol_ws, stats, grad, K,
+                      stream);
+    return E::pm_bwd(x, x_stride, N, din, H, num_hidden, K, act, param,
+                     num_hidden == 2 ? h1 : h2, num_hidden == 2 ? h2 : nullptr, gm, partials, grad,
+                     stream);
+  };
+  // ---- forward: head + covariance projection beside the mean net
+  OBJ_HIP(hipEventRecord(S->ev[0], st));
+  OBJ_HIP(hipStreamWaitEvent(sd, S->ev[0], 0));
+  OBJ_TRY(A::chol_fwd(var, L, 1, K, nvec, min_std, sd));
+  OBJ_TRY(A::proj_fwd(L, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
+  OBJ_HIP(hipEventRecord(S->ev[1], sd));
+  OBJ_TRY(net_fwd());
+  OBJ_TRY(bb_policy_objective<real>(mean, L, mean_old, L_old, actions, logp_old, adv, eps_mean,
+                                    eps_cov, beta, entropy_eq, proj_ctx, tr_coeff, tr_include_cov,
+                                    ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16,
+                                    proj_mean_out, proj_L_out, N, K, st, 1, balance ? 1 : 0));
+  if (!balance) {
+    OBJ_TRY(net_bwd(g_mean));
+  } else {
+    // surrogate alone
+    OBJ_TRY(net_bwd(gm_p));
+    OBJ_TRY(E::chol_bwd(var, gL_p, g_var, 1, K, nvec, stream));
+    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2);
+    TCE_LAUNCH_CHECK();
+    OBJ_HIP_ALWAYS(hipMemcpyAsync(gtmp, grad, sizeof(real) * PN, hipMemcpyDeviceToDevice, st));
+    // trust region loss alone
+    OBJ_TRY(net_bwd(g_mean));
+    OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
+    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2 + 1);
+    TCE_LAUNCH_CHECK();
+    // the epoch's gradient: their sum (+ the entropy term's way through the factor)
+    hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div(PN, 256)), dim3(256), 0, st,
+                       grad, gtmp, (const real*)nullptr, PN);
+    TCE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0, st,
+                       g_L, gL_p, ent_coef != real(0) ? (const real*)gL_e : (const real*)nullptr,
+                       KK);
+    TCE_LAUNCH_CHECK();
+  }
+  if (do_adam && g_policy_tail_fused && n <= (1 << 17)) {
+    const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 4 * PT_BT), PT_MAX_BLOCKS);
+    hipLaunchKernelGGL(policy_tail_kernel<real>, dim3(grid), dim3(PT_BT),
+                       sizeof(real) * (size_t)nvec, st, param, grad, m, v, PN, nvec, K,
+                       (const real*)g_L, (const real*)nullptr, opt_state, ticket,
+                       (const real*)sur2, (const real*)out16, ent_coef, rec_row19, lr, beta1, beta2,
+                       eps, weight_decay, clip_grad, grad_scale);
+    TCE_LAUNCH_CHECK();
+    return 0;
+  }
+  OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
+  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
+  OBJ_TRY(E::adam(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps, weight_decay,
+                  clip_grad, grad_scale, stream));
+  return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1304,6 +1462,27 @@ int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
   }
 DEFINE_POLICY_EPOCH2(f32, float)
 DEFINE_POLICY_EPOCH2(f64, double)
+
+#define DEFINE_BB_POLICY_EPOCH(SFX, REAL)                                                    \
+  int tce_bb_policy_epoch_##SFX(                                                             \
+      const REAL* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,       \
+      int net_kind, int act, int nvec, REAL min_std, REAL* param, REAL* grad,                \
+      const REAL* mean_old, const REAL* L_old, const REAL* actions, const REAL* logp_old,    \
+      const REAL* adv, REAL eps_mean, double eps_cov, const REAL* beta, int entropy_eq,      \
+      double* proj_ctx, REAL tr_coeff, int tr_include_cov, REAL ent_coef, double* sur_ws,    \
+      double* kl_ws, REAL* obj_ws, REAL* ws, REAL* partials, REAL* ol_ws, int K, REAL* m,    \
+      REAL* v, REAL* opt_state, REAL lr, REAL beta1, REAL beta2, REAL eps,                   \
+      REAL weight_decay, REAL clip_grad, REAL grad_scale, int do_adam, int balance,          \
+      REAL* rec_row19, REAL* bal2, REAL* proj_mean_out, REAL* proj_L_out, void* stream) {    \
+    return bb_policy_epoch<REAL>(                                                            \
+        x, x_stride, N, din, hidden, num_hidden, net_kind, act, nvec, min_std, param, grad,  \
+        mean_old, L_old, actions, logp_old, adv, eps_mean, eps_cov, beta, entropy_eq,        \
+        proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, ws, partials,   \
+        ol_ws, K, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,           \
+        grad_scale, do_adam, balance, rec_row19, bal2, proj_mean_out, proj_L_out, stream);   \
+  }
+DEFINE_BB_POLICY_EPOCH(f32, float)
+DEFINE_BB_POLICY_EPOCH(f64, double)
 
 int tce_policy_record_f32(const float* sur2, const float* out16, const float* norms2,
                           float ent_coef, float* row19, void* stream) {

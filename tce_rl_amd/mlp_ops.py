@@ -63,6 +63,9 @@ def forward(mlp, x):
         from . import pmlp_ops
         if pmlp_ops.supported(mlp):
             return pmlp_ops.forward(mlp, x)       # csrc/pmlp.hip row kernel
+        if critic_ops.supported(mlp):
+            # few rows of a net without a row kernel (256 x 2 value functions)
+            return critic_ops.forward(mlp, x)
     layers = mlp.layers
     if critic_ops.hidden_supported(mlp, x) and not x.requires_grad \
             and mlp.act_func_last_type is None:

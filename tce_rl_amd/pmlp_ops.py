@@ -100,3 +100,70 @@ def backward(mlp, keep, grad_out, grad=None, partials=None, param=None):
          _ACT[mlp.act_func_hidden_type], ptr(param), ptr(keep["h1"]),
          ptr(keep["h2"]), ptr(g), ptr(partials), ptr(grad), stream())
     return grad
+
+
+# ---------------------------------------------------------------------------
+# the black-box agent's value function on these kernels (csrc/vcritic.hip)
+# ---------------------------------------------------------------------------
+def critic_supported(agent):
+    """A value function D_in -> H (-> H) -> 1 of a shape above with its
+    parameters in a FlatAdam, full-batch epochs (table tennis's 256 x 1 BBRL
+    critic, mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:90-91)."""
+    from .smlp_ops import _opt_matches
+    net, opt = agent.critic.net, agent.critic_optimizer
+    return (net.dim_out == 1 and supported(net) and agent.num_minibatchs == 1
+            and _opt_matches(opt, list(net.parameters()))
+            and opt.flat_param.numel() <= (1 << 17)
+            and opt.flat_param.data_ptr() % 16 == 0)
+
+
+def critic_update(agent, states, returns, old_values):
+    """E critic epochs (black_box_agent.py:105-157) -> rec [E, 3] = {loss,
+    |g|, |g| clipped} on the device; one C call per epoch
+    (tce_pmlp_critic_epoch_*), no autograd, no library GEMM."""
+    net, opt = agent.critic.net, agent.critic_optimizer
+    din, H, NL, _ = shape(net)
+    lib = _lib.load()
+    x = _rows(states, din)
+    N, E = x.shape[0], agent.epochs_critic
+    dt, dev = net.dtype, x.device
+    if x.dtype != dt:
+        raise RuntimeError("pmlp critic: states must be %s" % dt)
+    ret = returns.reshape(-1).contiguous()
+    old = old_values.reshape(-1).contiguous() if agent.clip_critic > 0 \
+        else None
+    cache = net.__dict__.setdefault("_tce_pmlp_ws", {})
+    ws = cache.get(("ws", N))
+    if ws is None:
+        # zeroed once: the loss kernel re-arms its ticket itself
+        ws = cache[("ws", N)] = torch.zeros(
+            lib.tce_pmlp_critic_ws_len(N, H), dtype=dt, device=dev)
+    partials = cache.get("partials")
+    if partials is None:
+        P = lib.tce_pmlp_num_params(din, H, NL, 1)
+        partials = cache["partials"] = torch.empty(
+            lib.tce_pmlp_max_slabs() * P, dtype=dt, device=dev)
+    rec = torch.zeros(E, 3, dtype=dt, device=dev)
+    g = opt.param_groups[0]
+    opt.bind_grads()
+    sharded = agent.dist.active
+    for e in range(E):
+        if not sharded:
+            opt.host_step += 1
+            opt._opt_called = True            # for LinearLR's order check
+        call("tce_pmlp_critic_epoch_" + sfx(dt), ptr(x), x.stride(0), ptr(ret),
+             ptr(old), N, din, H, NL, _ACT[net.act_func_hidden_type],
+             float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
+             ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+             float(g["weight_decay"]), float(agent.clip_grad_norm), 1.0,
+             int(not sharded), float(opt.host_step), ptr(ws), ptr(partials),
+             ptr(rec[e]), stream())
+        if sharded:
+            # the loss is the shard's own mean (as on the other sharded paths);
+            # sum of the shards' gradients, then clip + Adam + the two norms
+            agent.dist.allreduce_flat(opt.flat_grad, average=False)
+            opt.step_once(agent.clip_grad_norm,
+                          grad_scale=1.0 / agent.dist.world,
+                          norms_out=rec[e, 1:3])
+    return rec

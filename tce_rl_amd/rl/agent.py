@@ -1211,13 +1211,48 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 "evaluation"))
         return result
 
-    def step(self):
+    def _critic_path(self):
+        """Which hand-written critic update applies: "smlp" (nets up to 64
+        wide, csrc/smlp.hip), "pmlp" (128 x 1 / 128 x 2 / 256 x 1 on the row
+        kernels of csrc/pmlp.hip: table tennis's BBRL critic), "fused" (the
+        matrix-core epochs of the TCE critics: box pushing's 256 x 2), None
+        (op by op / HIP graph)."""
+        from .. import critic_ops, pmlp_ops, smlp_ops
+        if not (self.small_net_kernels and self.num_minibatchs == 1):
+            return None
+        if smlp_ops.critic_supported(self):
+            return "smlp"
+        if self.device.type != "cuda":
+            return None
+        net, opt = self.critic.net, self.critic_optimizer
+        if critic_ops.supported(net) and smlp_ops._opt_matches(
+                opt, list(net.parameters())):
+            return "fused"
+        if pmlp_ops.critic_supported(self):
+            return "pmlp"
+        return None
+
+    def _policy_path(self, dataset):
+        """As _critic_path for the policy update: "smlp", "direct"
+        (objective.BBDirectEpoch: the mean nets of csrc/pmlp.hip / the fused
+        128 x 2 kernels) or None."""
         from .. import smlp_ops
+        L_old = dataset["segment_params_L"]
+        if not (self.small_net_kernels and self.num_minibatchs == 1):
+            return None
+        if smlp_ops.policy_supported(self, L_old):
+            return "smlp"
+        if self.device.type == "cuda" and objective.BBDirectEpoch.supported(
+                self, dataset["segment_state"], L_old):
+            return "direct"
+        return None
+
+    def step(self):
         if self.lazy_metrics and self.overlap_updates and \
                 self.small_net_kernels and self.num_minibatchs == 1 and \
                 not self.dist.active and self.device.type == "cuda" and \
                 self.projection.initial_entropy is not None and \
-                smlp_ops.critic_supported(self) and \
+                self._critic_path() is not None and \
                 getattr(self, "_bb_small_policy", False):
             return self._step_lazy()
         self.num_iterations += 1
@@ -1231,10 +1266,10 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             {k: v for k, v in dataset.items()
              if k not in ("segment_params_L", "segment_state")}, "exploration")
         util.run_time_test(lock=True, key="update")
-        from .. import smlp_ops
-        small = self.small_net_kernels and smlp_ops.critic_supported(self) \
-            and smlp_ops.policy_supported(self, dataset["segment_params_L"])
-        # (the lazy step needs both networks on the row kernels: known from here on)
+        small = self._critic_path() is not None and \
+            self._policy_path(dataset) is not None
+        # (the lazy step needs both updates on the hand-written kernels -- no
+        # graph, no autograd, deferrable reads: known from here on)
         self._bb_small_policy = bool(small)
         if self.overlap_updates and (self.graph_epochs or small) and \
                 self.num_minibatchs == 1 and not self.dist.active:
@@ -1289,12 +1324,23 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             **util.generate_stats(host[0], "critic_loss"),
             **util.generate_stats(host[1], "critic_grad_norm"),
             **util.generate_stats(host[2], "clipped_critic_grad_norm")}
-        from .. import smlp_ops
-        if self.small_net_kernels and smlp_ops.critic_supported(self):
+        from .. import pmlp_ops, smlp_ops
+        path = self._critic_path()
+        if path == "smlp":
             # E launches, each a whole epoch incl. the Adam step (csrc/smlp.hip)
             rec = smlp_ops.critic_update(self, states, returns, old_values)
             fin = lambda: stats(rec.cpu().numpy().T)
             return fin if defer else fin()
+        if path == "pmlp":
+            # one C call per epoch on the row kernels of csrc/pmlp.hip
+            rec = pmlp_ops.critic_update(self, states, returns, old_values)
+            fin = lambda: stats(rec.cpu().numpy().T)
+            return fin if defer else fin()
+        if path == "fused":
+            # the matrix-core epochs of the TCE critics (rows = envs)
+            ce = _CriticEpochs(self, states, returns, old_values)
+            ce.run(E)
+            return ce.finish if defer else ce.finish()
         if self.num_minibatchs == 1:
             eg, st = self._epoch_graph(
                 "critic", E, self.critic_optimizer,
@@ -1359,10 +1405,12 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             ent0 = self.policy.entropy([mean_old, L_old]).mean()
             self.projection.initial_entropy = self.dist.mean_scalar(ent0)
         E = self.epochs_policy
-        from .. import smlp_ops
-        if self.small_net_kernels and smlp_ops.policy_supported(self, L_old):
+        path = self._policy_path(dataset)
+        if path == "smlp":
             return self._update_policy_small(dataset, defer=defer)
-        assert not defer, "deferred reads: row-kernel path only"
+        if path == "direct":
+            return self._update_policy_direct(dataset, defer=defer)
+        assert not defer, "deferred reads: hand-written epochs only"
         eg, st = self._epoch_graph(
             "policy", E, self.policy_optimizer,
             dict(states=states, actions=actions, log_probs_old=log_probs_old,
@@ -1478,8 +1526,44 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         return self._finish_policy_update(rec, last, states, mean_old, L_old,
                                           defer=defer)
 
+    def _update_policy_direct(self, dataset, defer=False):
+        """update_policy for the mean nets of csrc/pmlp.hip / the fused 128 x 2
+        kernels: every epoch ONE C call (objective.BBDirectEpoch), the epochs
+        of a balance-check iteration (black_box_agent.py:218-284) included."""
+        states = dataset["segment_state"]
+        mean_old, L_old = dataset["segment_params_mean"], \
+            dataset["segment_params_L"]
+        sched = self.projection.entropy_schedule_type
+        beta = None if sched in (None, False) else \
+            self.projection.entropy_schedule(
+                self.projection.initial_entropy,
+                self.projection.target_entropy, self.projection.temperature,
+                self.num_iterations)
+        if beta is not None and not torch.is_tensor(beta):
+            beta = torch.as_tensor(float(beta), device=self.device)
+        self._objective_streams()
+        ctx = objective.BBContext(self, mean_old, L_old,
+                                  dataset["segment_action"],
+                                  dataset["segment_log_prob"],
+                                  dataset["segment_advantage"], beta)
+        direct = objective.BBDirectEpoch(self, states, ctx)
+        # (a sharded run has no split epochs: its balance norms are left out)
+        balance = self._balance_iteration() and not self.dist.active
+        self.check_policy_balance = balance
+        E, N = self.epochs_policy, states.shape[0]
+        # per epoch: 7 loss / norm scalars, 12 KL means, the two balance norms
+        rec = torch.zeros(E, 21, dtype=self.dtype, device=self.device)
+        for e in range(E):
+            direct.run(rec[e, :19], balance=balance, bal=rec[e, 19:21],
+                       last=e == E - 1)
+        mean_new, L_new = direct.latest()
+        last = (mean_new, ops.expand_shared(L_new, N), ctx.proj_mean,
+                ops.expand_shared(ctx.proj_L, N))
+        return self._finish_policy_update(rec, last, states, mean_old, L_old,
+                                          defer=defer, balance=balance)
+
     def _finish_policy_update(self, rec, last, states, mean_old, L_old,
-                              defer=False):
+                              defer=False, balance=False):
         """Everything that changes device state is enqueued here; the host
         reads (per-epoch record, projection metrics) happen in the returned
         closure when `defer` (BlackBoxAgent's lazy step), else at once."""
@@ -1513,6 +1597,24 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             mh = mdev.cpu().numpy()
             out.update({"projection_" + k: float(v)
                         for k, v in zip(mkeys, mh)})
+            if host.shape[1] >= 19:
+                # kl_old_new_proj (black_box_agent.py:391-436) per epoch
+                kl_names = [a + "_" + b
+                            for a in ("new_old", "new_proj", "proj_old")
+                            for b in ("mean_diff", "cov_diff", "shape_diff",
+                                      "volume_diff")]
+                for i, n in enumerate(kl_names):
+                    out.update(util.generate_stats(host[:, 7 + i],
+                                                   "projection_" + n))
+            if balance:
+                out.update(util.generate_stats(host[:, 19],
+                                               "surrogate_grad_norm"))
+                out.update(util.generate_stats(host[:, 20],
+                                               "trust_region_grad_norm"))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    out["balance_ratio"] = float(
+                        np.float64(out["surrogate_grad_norm_mean"]) /
+                        np.float64(out["trust_region_grad_norm_mean"]))
             return out
         return read if defer else read()
 

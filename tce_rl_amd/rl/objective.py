@@ -351,3 +351,110 @@ class DirectEpoch:
             call("tce_policy_record_" + self.sfx, ptr(self.sur), ptr(self.out16),
                  ptr(opt.dev_state) + opt.dev_state.element_size(),
                  c.ent_coef, ptr(rec_row), stream())
+
+
+class BBDirectEpoch:
+    """One policy epoch of the black-box agent WITHOUT autograd, ONE C call
+    (tce_bb_policy_epoch_*; black_box_agent.py:225-339), for the mean nets of
+    ``DirectEpoch`` -- the reference's box-pushing (128 x 2) and table-tennis
+    (256 x 1) BBRL policies, which the 64-wide row kernels of csrc/smlp.hip do
+    not cover: Cholesky head + covariance projection beside the mean net's
+    forward, the black-box objective and its gradient, the net's backward into
+    the optimizer's flat gradient buffer, Cholesky head backward + clip + Adam +
+    record row as one launch.  ``balance``: the epoch of a balance-check
+    iteration (:226-284), the two gradient norms from ONE evaluation whose
+    gradient is kept in two parts."""
+
+    @staticmethod
+    def supported(agent, states, L_old):
+        return bb_supported(agent, L_old) and agent.num_minibatchs == 1 and \
+            DirectEpoch.kind(agent, states) is not None
+
+    def __init__(self, agent, states, context):
+        from .. import critic_ops
+        self.agent, self.c = agent, context
+        pol = agent.policy
+        self.net, self.opt = pol.mean_net, agent.policy_optimizer
+        self.net_kind = DirectEpoch.kind(agent, states)
+        self.var = pol.variance_net.variable
+        self.x = states if states.is_contiguous() else states.contiguous()
+        self.N, self.din = self.x.shape
+        self.K, self.min_std = pol.dim_out, float(pol.min_std)
+        self.act = critic_ops._ACT[self.net.act_func_hidden_type]
+        dev, dt, lib = self.x.device, self.x.dtype, _lib.load()
+        self.sfx = sfx(dt)
+        hl = list(self.net.hidden_layers)
+        self.H, self.NL = hl[0], len(hl)
+        self.nvec = self.var.numel()
+        nparam = self.opt.flat_grad.numel()
+        # scratch kept on the net across updates (same shapes every iteration)
+        cache = self.net.__dict__.setdefault("_tce_bb_direct", {})
+        key = (self.N, self.K, self.net_kind, dt)
+        bufs = cache.get(key)
+        if bufs is None:
+            if self.net_kind == 0:
+                P = lib.tce_mlp_critic_num_params(self.din)
+                partials = torch.empty(min(lib.tce_mlp_critic_grid(),
+                                           (self.N + 63) // 64), P + 2,
+                                       dtype=dt, device=dev)
+                ol_ws = torch.empty(
+                    lib.tce_out_layer_grad_ws_len(self.N, self.K, 128),
+                    dtype=dt, device=dev)
+            else:
+                P = lib.tce_pmlp_num_params(self.din, self.H, self.NL, self.K)
+                assert nparam == P + self.nvec
+                partials = torch.empty(lib.tce_pmlp_max_slabs() * P, dtype=dt,
+                                       device=dev)
+                ol_ws = None
+            # (zeroed once: the tail kernel re-arms its ticket)
+            ws = torch.zeros(lib.tce_policy_epoch2_ws_len(
+                self.N, self.K, self.H, nparam), dtype=dt, device=dev)
+            bufs = cache[key] = (partials, ol_ws, ws)
+            for k in [k for k in cache if k != key]:
+                del cache[k]
+        self.partials, self.ol_ws, self.ws = bufs
+        up4 = lambda n: (n + 3) // 4 * 4
+        self._o_mean = 2 * up4(self.N * self.H)
+        self._o_L = self._o_mean + 2 * up4(self.N * self.K)
+        o = self._o_L + 3 * up4(self.K * self.K)
+        self.sur, self.out16 = self.ws[o:o + 2], self.ws[o + 4:o + 20]
+
+    def latest(self):
+        """(mean_new [N,K], L_new [K,K]) of the latest epoch (copies)."""
+        N, K = self.N, self.K
+        return (self.ws[self._o_mean:self._o_mean + N * K].view(N, K).clone(),
+                self.ws[self._o_L:self._o_L + K * K].view(K, K).clone())
+
+    def run(self, rec_row, balance=False, bal=None, last=False):
+        """One epoch; rec_row [19] as DirectEpoch.run; last: the projected
+        distribution is left in the context (proj_mean / proj_L)."""
+        c, ag, opt = self.c, self.agent, self.opt
+        x, N, K = self.x, self.N, self.K
+        opt.bind_grads()
+        assert rec_row.is_contiguous() and rec_row.numel() == 19
+        g = opt.param_groups[0]
+        do_adam = not ag.dist.active
+        assert do_adam or not balance
+        if do_adam:
+            opt.host_step += 1
+            opt._opt_called = True            # for LinearLR's order check
+        call("tce_bb_policy_epoch_" + self.sfx, ptr(x), x.stride(0), N, self.din,
+             self.H, self.NL, self.net_kind, self.act, self.nvec, self.min_std,
+             ptr(opt.flat_param), ptr(opt.flat_grad), ptr(c.mean_old),
+             ptr(c.L_old), ptr(c.actions), ptr(c.lp_old), ptr(c.adv),
+             float(c.eps_mean), float(c.eps_cov), ptr(c.beta), c.entropy_eq,
+             ptr(c.proj_ctx), float(c.tr_coeff), c.tr_include_cov, c.ent_coef,
+             ptr(c.sur_ws), ptr(c.kl_ws), ptr(c.ws), ptr(self.ws),
+             ptr(self.partials), ptr(self.ol_ws), K, ptr(opt.m), ptr(opt.v),
+             ptr(opt.dev_state), float(g["lr"]), float(g["betas"][0]),
+             float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+             float(ag.clip_grad_norm), 1.0, int(do_adam), int(balance),
+             ptr(rec_row), ptr(bal), ptr(c.proj_mean) if last else None,
+             ptr(c.proj_L) if last else None, stream())
+        if not do_adam:
+            ag.dist.allreduce_flat(opt.flat_grad, ag._policy_group,
+                                   average=False)
+            opt.step_once(ag.clip_grad_norm, grad_scale=1.0 / ag.dist.world)
+            call("tce_policy_record_" + self.sfx, ptr(self.sur), ptr(self.out16),
+                 ptr(opt.dev_state) + opt.dev_state.element_size(),
+                 c.ent_coef, ptr(rec_row), stream())

@@ -439,37 +439,43 @@ BB_MP = dict(num_dof=4, num_basis=4, tau=5.0, alpha_phase=3, alpha=10,
              goal_scale=0.1, relative_goal=True)
 
 
-def build_bbrl(num_env, epochs):
+def build_bbrl(num_env, epochs, policy_hidden=(32, 2), critic_hidden=(32, 2),
+               act="relu", std_only=True, dtype="float32", **agent_kw):
+    """policy_hidden / critic_hidden: (neurons, hidden layers)."""
     from tce_rl_amd.rl import (agent_factory, critic_factory, policy_factory,
                                projection_factory, sampler_factory)
-    mp = {"type": "prodmp", "args": dict(BB_MP, dtype="float32", device="cuda")}
+    mp = {"type": "prodmp", "args": dict(BB_MP, dtype=dtype, device="cuda")}
     sampler = sampler_factory("BlackBoxSampler",
                               env_id="metaworld_ProDMP/push-v2",
                               num_env_train=num_env, num_env_test=16,
-                              dtype="float32", device="cuda", seed=0, mp=mp,
+                              dtype=dtype, device="cuda", seed=0, mp=mp,
                               task_specified_metrics=["success"])
     d_in = sampler.observation_shape[-1]
-    common = dict(init_method="orthogonal", act_func_hidden="relu",
-                  act_func_last=None, dtype="float32", device="cuda")
+    common = dict(init_method="orthogonal", act_func_hidden=act,
+                  act_func_last=None, dtype=dtype, device="cuda")
     policy = policy_factory(
         "BlackBoxPolicy", dim_in=d_in, dim_out=20,
-        mean_net_args=dict(avg_neuron=32, num_hidden=2, shape=0.0),
-        variance_net_args=dict(std_only=True, contextual=False),
+        mean_net_args=dict(avg_neuron=policy_hidden[0],
+                           num_hidden=policy_hidden[1], shape=0.0),
+        variance_net_args=dict(std_only=std_only, contextual=False),
         out_layer_gain=0.01, min_std=1e-5, **common)
     critic = critic_factory("ValueFunction", dim_in=d_in, dim_out=1,
-                            hidden=dict(avg_neuron=32, num_hidden=2, shape=0.0),
+                            hidden=dict(avg_neuron=critic_hidden[0],
+                                        num_hidden=critic_hidden[1], shape=0.0),
                             out_layer_gain=1, **common)
     proj = projection_factory(
         "KLProjectionLayer", proj_type="kl", mean_bound=0.005,
         cov_bound=0.0005, trust_region_coeff=1.0, entropy_schedule=False,
-        action_dim=20, total_train_steps=100, dtype="float32", device="cuda")
+        action_dim=20, total_train_steps=100, dtype=dtype, device="cuda")
+    kw = dict(lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0,
+              wd_critic=0.0, discount_factor=1, epochs_policy=epochs,
+              epochs_critic=epochs, num_minibatchs=1, norm_advantages=True,
+              clip_advantages=0.0, set_variance=True, balance_check=25,
+              evaluation_interval=1, dtype=dtype, device="cuda")
+    kw.update(agent_kw)
     agent = agent_factory(
         "BlackBoxAgent", policy=policy, critic=critic, sampler=sampler,
-        projection=proj, lr_policy=3e-4, lr_critic=3e-4, wd_policy=0.0,
-        wd_critic=0.0, discount_factor=1, epochs_policy=epochs,
-        epochs_critic=epochs, num_minibatchs=1, norm_advantages=True,
-        clip_advantages=0.0, set_variance=True, balance_check=25,
-        evaluation_interval=1, dtype="float32", device="cuda")
+        projection=proj, **kw)
     return agent, d_in
 
 
@@ -608,6 +614,149 @@ def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
     _close("variance", agent.policy.variance_net.variable.detach().cpu(),
            oracle.var.detach(), 3e-6)
     assert (calls["c"], calls["p"]) == ((1, 1) if mode == "small" else (0, 0))
+
+
+BBRL_MID = {
+    # mprl/config/box_push_random_init/bbrl/entire/shared.yaml:4,66-67,84-85,31-33
+    "box_push": dict(policy_hidden=(128, 2), critic_hidden=(256, 2),
+                     act="leaky_relu", std_only=False, dtype="float32",
+                     wd=5e-5, clip_critic=0.0),
+    # mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:72-73,90-91,31-33
+    "table_tennis": dict(policy_hidden=(256, 1), critic_hidden=(256, 1),
+                         act="leaky_relu", std_only=False, dtype="float32",
+                         wd=1e-5, clip_critic=0.0),
+    # the same row kernels in float64, a tanh net, a clipped value loss
+    "f64_clip": dict(policy_hidden=(128, 2), critic_hidden=(128, 2),
+                     act="tanh", std_only=False, dtype="float64", wd=0.0,
+                     clip_critic=0.2),
+    "f64_one_layer": dict(policy_hidden=(128, 1), critic_hidden=(128, 1),
+                          act="relu", std_only=True, dtype="float64", wd=0.0,
+                          clip_critic=0.2),
+}
+
+
+@pytest.mark.parametrize("balance", [False, True])
+@pytest.mark.parametrize("shape", sorted(BBRL_MID))
+def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
+    """One BlackBoxAgent.step() with the reference's OTHER black-box nets -- box
+    pushing's 128 x 2 policy / 256 x 2 critic, table tennis's 256 x 1 / 256 x 1
+    (full covariance, leaky relu, weight decay) -- against the CPU oracle: the
+    policy epochs as ONE C call each (objective.BBDirectEpoch), the critic on
+    the matrix-core epochs (256 x 2) or the row kernels of csrc/pmlp.hip; no
+    autograd, no library GEMM.  balance: an iteration with the policy balance
+    check (black_box_agent.py:218-284), its two gradient norms included."""
+    from oracle.agent_oracle import OracleBBRL
+    from tce_rl_amd import mlp_ops, pmlp_ops
+    from tce_rl_amd.rl import objective
+    cfg = BBRL_MID[shape]
+    # (balance: more and larger steps, so that the trust region becomes active
+    # and its loss has a gradient to measure)
+    N, EPOCHS, LR = (24, 6, 3e-3) if balance else (24, 3, 3e-4)
+    dt = getattr(torch, cfg["dtype"])
+    agent, d_in = build_bbrl(
+        N, EPOCHS, cfg["policy_hidden"], cfg["critic_hidden"], cfg["act"],
+        cfg["std_only"], cfg["dtype"], wd_policy=cfg["wd"], wd_critic=cfg["wd"],
+        clip_critic=cfg["clip_critic"], balance_check=25 if balance else False,
+        lr_policy=LR, lr_critic=LR)
+    agent.evaluation_interval = 0
+    assert agent.num_iterations == 0           # the first step is 1 = 1 mod 25
+    # which implementation ran
+    calls = {"direct": 0, "pmlp_critic": 0, "linear": 0}
+    run = objective.BBDirectEpoch.run
+    monkeypatch.setattr(objective.BBDirectEpoch, "run", lambda *a, **k: (
+        calls.__setitem__("direct", calls["direct"] + 1), run(*a, **k))[1])
+    cu = pmlp_ops.critic_update
+    monkeypatch.setattr(pmlp_ops, "critic_update", lambda *a, **k: (
+        calls.__setitem__("pmlp_critic", calls["pmlp_critic"] + 1),
+        cu(*a, **k))[1])
+    lin = mlp_ops._Linear.apply
+    monkeypatch.setattr(mlp_ops._Linear, "apply", lambda *a: (
+        calls.__setitem__("linear", calls["linear"] + 1), lin(*a))[1])
+    hid = lambda h: [h[0]] * h[1]
+    oracle = OracleBBRL(BB_MP, N, d_in, hid(cfg["policy_hidden"]),
+                        hid(cfg["critic_hidden"]), cfg["act"], cfg["std_only"],
+                        1e-5, 0.01, LR, EPOCHS, 0.005, 0.0005, 1.0, True,
+                        clip_critic=cfg["clip_critic"], dtype=dt,
+                        balance=balance, weight_decay=cfg["wd"])
+    with torch.no_grad():
+        for po, pg in zip(oracle.pnet, agent.policy.mean_net.parameters()):
+            po.copy_(pg.cpu())
+        for po, pg in zip(oracle.cnet, agent.critic.net.parameters()):
+            po.copy_(pg.cpu())
+        oracle.var.copy_(agent.policy.variance_net.variable.cpu())
+    g = torch.Generator().manual_seed(3)
+    goal = (torch.rand(N, 4, generator=g) * 2 - 1).to(dt)
+    pos0 = (0.1 * (torch.rand(N, 4, generator=g) * 2 - 1)).to(dt)
+    eps = torch.randn(N, 20, generator=g).to(dt)
+    env = agent.sampler.train_envs
+
+    def reset():
+        env.goal = goal.cuda()
+        z = torch.zeros(N, 4, device="cuda", dtype=dt)
+        return env._obs(torch.zeros(N, device="cuda", dtype=dt), pos0.cuda(), z)
+    env.reset = reset
+    sample = agent.policy.sample
+    agent.policy.sample = lambda **kw: sample(**kw, eps=eps.cuda())
+    oracle.forced_reset, oracle.forced_eps = (goal, pos0), eps
+    captured = {}
+    pd = agent.process_dataset
+
+    def grab(ds):
+        out = pd(ds)
+        captured.update({k: v.detach().cpu() for k, v in out.items()
+                         if torch.is_tensor(v) and k != "segment_params_L"})
+        return out
+    agent.process_dataset = grab
+    res = dict(agent.step())
+    oracle.step()
+    ref = oracle.last
+    f64 = dt == torch.float64
+    # float32: rounding of 128- / 256-term sums; float64: the basis table and the
+    # projection's Newton iteration stop at 1e-10 .. 1e-12, Adam's first steps
+    # (lr * g / (|g| + 1e-8)) amplify that in parameters with tiny gradients
+    t = (lambda a, b: b) if f64 else (lambda a, b: a)
+    _close("segment_action", captured["segment_action"], ref["segment_action"],
+           t(3e-6, 1e-11))
+    _close("segment_log_prob", captured["segment_log_prob"],
+           ref["segment_log_prob"], t(4e-6, 1e-10))
+    _close("segment_value", captured["segment_value"], ref["segment_value"],
+           t(4e-6, 1e-11))
+    _close("segment_reward", captured["segment_reward"], ref["segment_reward"],
+           t(2e-6, 1e-10))
+    _close("segment_advantage", captured["segment_advantage"],
+           ref["segment_advantage"], t(1e-5, 1e-9))
+    for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
+        _close("critic", pg.detach().cpu(), po.detach(), t(5e-6, 1e-8))
+    for pg, po in zip(agent.policy.mean_net.parameters(), oracle.pnet):
+        # (balance: 10 x the step size, twice the steps -- Adam's step is
+        # lr * m / (sqrt(v) + eps), deviations scale with lr)
+        _close("policy", pg.detach().cpu(), po.detach(),
+               t(5e-5 if balance else 1e-5, 1e-7))
+    _close("variance", agent.policy.variance_net.variable.detach().cpu(),
+           oracle.var.detach(), t(5e-5 if balance else 1e-5, 1e-7))
+    assert calls["direct"] == EPOCHS and calls["linear"] == 0
+    # two hidden layers: the matrix-core epochs (csrc/mlpw_*.hip), one: pmlp
+    rows = cfg["critic_hidden"][1] == 1
+    assert calls["pmlp_critic"] == int(rows)
+    assert agent._critic_path() == ("pmlp" if rows else "fused")
+    # the reference's metric keys of the policy update (black_box_agent.py:359-375)
+    for k in ("projection_new_old_mean_diff_mean",
+              "projection_proj_old_cov_diff_max", "projection_kl",
+              "surrogate_loss_mean", "policy_grad_norm_mean"):
+        assert np.isfinite(res[k]), k
+    if balance:
+        want = np.array(oracle.balance_norms)
+        assert want.shape == (EPOCHS, 2)
+        assert res["surrogate_grad_norm_mean"] == pytest.approx(
+            want[:, 0].mean(), rel=t(2e-4, 1e-7))
+        assert res["trust_region_grad_norm_mean"] == pytest.approx(
+            want[:, 1].mean(), rel=t(2e-4, 1e-7), abs=t(1e-7, 1e-12))
+        assert want[:, 1].max() > 0        # the trust region was active
+        if want[:, 1].mean() > 0:
+            assert res["balance_ratio"] == pytest.approx(
+                want[:, 0].mean() / want[:, 1].mean(), rel=t(5e-4, 1e-6))
+    else:
+        assert "balance_ratio" not in res
 
 
 @pytest.mark.parametrize("ent_coef", [0.0, 0.01])
