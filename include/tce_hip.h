@@ -948,8 +948,10 @@ int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* r
  * grad [P, P + nvec), clip, Adam on all P + nvec entries, record) -- seven
  * launches; diag != 0 (std_only factors, beta == NULL: every shipped BBRL
  * config): the K x K steps collapse into K-vector steps, four launches.  rec
- * [epochs][7] = {surrogate, entropy loss, trust region loss, total, entropy,
- * |g|, |g| clipped}.  mats: float [tce_bb_policy_mats_len(K)], holds after
+ * [epochs][rec_stride], rec_stride 7 = {surrogate, entropy loss, trust region
+ * loss, total, entropy, |g|, |g| clipped}, >= 19: followed by the 12 means of
+ * kl_old_new_proj (black_box_agent.py:391-436) = {mean, cov, shape, volume}
+ * difference of (new || old), (new || proj), (proj || old).  mats: float [tce_bb_policy_mats_len(K)], holds after
  * the call L_new | L_proj | (scratch) in [K,K] blocks of pitch (K*K rounded up
  * to 4); proj_ctx: double [tce_kl_cov_proj_ctx_len(K)], zeroed by the caller
  * once per update; mean_new_out / proj_mean_out (nullable) [N,K]: the last
@@ -983,7 +985,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              float beta2, float eps, float weight_decay, float clip_grad,
                              float grad_scale, int do_adam, int diag, int epochs,
                              double* proj_ctx, float* ws, float* mats, float* rec,
-                             float* mean_new_out, float* proj_mean_out, void* stream);
+                             int rec_stride, float* mean_new_out, float* proj_mean_out,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -315,6 +315,9 @@ class OracleBBRL:
         # (black_box_agent.py:218-284) -- two extra passes per epoch whose
         # gradient norms are kept in self.balance_norms
         self.balance, self.balance_norms = balance, []
+        # per policy epoch the 12 means of kl_old_new_proj: {mean, cov, shape,
+        # volume} x {(new, old), (new, proj), (proj, old)}
+        self.kl_rows = []
         self.dof, self.K = self.mp.num_dof, self.mp.num_dof * self.mp.num_basis_g
         self.N, self.dt, self.dtype = num_env, self.mp.dt, dtype
         self.T = {0.0125: 500, 0.02: 100, 0.008: 350}[self.dt]
@@ -412,6 +415,13 @@ class OracleBBRL:
                                 contextual_std=False)
             lp = O.mvn_log_prob(action, pm, pL)
             s_loss, _ = O.surrogate_loss(adv, lp, lp_old)
+            with torch.no_grad():        # kl_old_new_proj, black_box_agent.py:391-436
+                self.kl_rows.append([
+                    d.mean().item()
+                    for p, q in (((mean_new, L_new), (mean_old, L_old)),
+                                 ((mean_new, L_new), (pm, pL)),
+                                 ((pm, pL), (mean_old, L_old)))
+                    for d in KO.gaussian_kl_details(p[0], p[1], q[0], q[1])])
             tr = KO.trust_region_loss(mean_new, L_new, pm, pL, self.tr_coeff,
                                       not self.set_variance)
             total = s_loss + tr

@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
     int include_cov, float ent_coef, float* __restrict__ param, float* __restrict__ grad,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ state, float lr, float b1,
     float b2, float eps, float wd, float clip_grad, float gscale, int do_adam,
-    float* __restrict__ out16, float* __restrict__ rec,
+    float* __restrict__ out16, float* __restrict__ rec, int rec_kl,
     // next_fwd (diagonal factors, behind the Adam step): bb_diag_fwd_body of the NEXT epoch
     int next_fwd, float min_std, double eps_cov, float* __restrict__ L_new_w,
     float* __restrict__ L_proj_w, float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w,
@@ -1529,6 +1529,11 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
     rec[4] = out16[12];
     rec[5] = before;
     rec[6] = before * coef;
+    // kl_old_new_proj (black_box_agent.py:391-436): {mean, cov, shape, volume}
+    // of (new || old), (new || proj), (proj || old) -- this epoch's K x K parts
+    // are in out16 since the launch that built the factors
+    if (rec_kl)
+      for (int i = 0; i < 12; ++i) rec[7 + i] = out16[i];
   }
   __syncthreads();
   if (!do_adam) return;
@@ -1584,8 +1589,8 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     float tr_coeff, int include_cov, float ent_coef, float* __restrict__ param,
     float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ state, float lr, float b1, float b2, float eps, float wd, float clip_grad,
-    float gscale, float* __restrict__ out16, float* __restrict__ rec, int next_fwd, float min_std,
-    double eps_cov, float* __restrict__ L_new_w, float* __restrict__ L_proj_w,
+    float gscale, float* __restrict__ out16, float* __restrict__ rec, int rec_kl, int next_fwd,
+    float min_std, double eps_cov, float* __restrict__ L_new_w, float* __restrict__ L_proj_w,
     float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w, double* __restrict__ dctx_w) {
   __shared__ float red[SNW];
   __shared__ float coef_s;
@@ -1625,6 +1630,9 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     o5 = out16[5];
     o12 = out16[12];
   }
+  // (this epoch's K x K KL parts, before next_fwd overwrites them)
+  float okl = 0.f;
+  if (rec_kl && tid < 12) okl = out16[tid];
   __builtin_amdgcn_sched_barrier(0);
   const double invN = 1.0 / (double)N;
   // ---- wave 0: d / d L_proj on the diagonal, projection backward, Cholesky head backward
@@ -1688,6 +1696,12 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     rec[4] = o12;
     rec[5] = before;
     rec[6] = before * cf;
+  }
+  if (rec_kl && tid < 12) {
+    // kl_old_new_proj of this epoch: the mean parts from the row sums
+    const int q = tid >> 2;
+    const double dq = q == 0 ? ds2 : (q == 1 ? ds3 : ds4);
+    rec[7 + tid] = (tid & 3) ? okl : (float)(0.5 * dq * invN);
   }
   // ---- Adam on the registers
   const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
@@ -2060,7 +2074,11 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              float beta2, float eps, float weight_decay, float clip_grad,
                              float grad_scale, int do_adam, int diag, int epochs,
                              double* proj_ctx, float* ws, float* mats, float* rec,
-                             float* mean_new_out, float* proj_mean_out, void* stream) {
+                             int rec_stride, float* mean_new_out, float* proj_mean_out,
+                             void* stream) {
+  TCE_CHECK_ARG(rec_stride == 7 || rec_stride >= 19,
+                "bb_policy_epochs: rec_stride is 7 (losses / norms) or >= 19 (+ 12 KL means)");
+  const int rec_kl = rec_stride >= 19;
   TCE_CHECK_ARG(x && actions && logp_old && adv && mean_old && L_old && param && grad &&
                     proj_ctx && ws && mats && rec && N > 0 && epochs > 0,
                 "bb_policy_epochs: null buffer / empty batch");
@@ -2136,8 +2154,9 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
       hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 0, 0, g_pL, gL_tr,
                          gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff,
                          tr_include_cov, ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2,
-                         eps, weight_decay, clip_grad, grad_scale, do_adam, out16, rec + 7 * e, 0,
-                         0.f, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr);
+                         eps, weight_decay, clip_grad, grad_scale, do_adam, out16,
+                         rec + (int64_t)rec_stride * e, 0, 0, 0.f, 0.0, nullptr, nullptr, nullptr,
+                         nullptr, nullptr);
       TCE_LAUNCH_CHECK();
       rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
       if (rc) return rc;
@@ -2148,8 +2167,9 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   hipLaunchKernelGGL(bb_diag_finish_kernel<NN>, dim3(1), dim3(SBT), 0, st, g_pL, gL_tr, L_proj,   \
                      L_old, proj_ctx, dsum, N, K, P, tr_coeff, tr_include_cov, ent_coef, param,   \
                      grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,       \
-                     grad_scale, out16, rec + 7 * e, chained && !lastep ? 1 : 0, min_std, eps_cov, \
-                     L_new, L_proj, Li_proj, gL_tr, proj_ctx)
+                     grad_scale, out16, rec + (int64_t)rec_stride * e, rec_kl,                    \
+                     chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr, \
+                     proj_ctx)
       if (npt <= 4) FD_LAUNCH(4);
       else if (npt <= 8) FD_LAUNCH(8);
       else if (npt <= 12) FD_LAUNCH(12);
@@ -2161,7 +2181,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
     hipLaunchKernelGGL(bb_policy_finish_kernel, dim3(1), dim3(SBT), 0, st, 1, diag, g_pL, gL_tr,
                        gL_p, L_proj, L_old, proj_ctx, dsum, N, K, nvec, P, tr_coeff, tr_include_cov,
                        ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,
-                       clip_grad, grad_scale, do_adam, out16, rec + 7 * e,
+                       clip_grad, grad_scale, do_adam, out16, rec + (int64_t)rec_stride * e, rec_kl,
                        chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr,
                        proj_ctx);
     TCE_LAUNCH_CHECK();

@@ -1411,14 +1411,15 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         if path == "direct":
             return self._update_policy_direct(dataset, defer=defer)
         assert not defer, "deferred reads: hand-written epochs only"
+        # per epoch: 7 loss / norm scalars + the 12 means of kl_old_new_proj
         eg, st = self._epoch_graph(
             "policy", E, self.policy_optimizer,
             dict(states=states, actions=actions, log_probs_old=log_probs_old,
-                 mean_old=mean_old, L_old=L_old, seg_adv=seg_adv), 7)
+                 mean_old=mean_old, L_old=L_old, seg_adv=seg_adv), 19)
         states, actions, log_probs_old = st["states"], st["actions"], \
             st["log_probs_old"]
         mean_old, L_old, seg_adv = st["mean_old"], st["L_old"], st["seg_adv"]
-        rec = eg.rec if eg else torch.zeros(E, 7, dtype=self.dtype,
+        rec = eg.rec if eg else torch.zeros(E, 19, dtype=self.dtype,
                                             device=self.device)
         idx = eg.idx if eg else torch.zeros(1, dtype=torch.int64,
                                             device=self.device)
@@ -1452,7 +1453,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                          self.policy_net_params,
                                          self.clip_grad_norm)
             rec.index_copy_(0, idx, torch.cat(
-                [rec17[:5], torch.stack([g, gc]).to(rec17.dtype)])[None])
+                [rec17[:5], torch.stack([g, gc]).to(rec17.dtype),
+                 rec17[5:17]])[None])
             idx.add_(1)
             last["t"] = (mean_new.detach(), ops.detach_L(L_new),
                          fused_ctx.proj_mean,
@@ -1469,6 +1471,9 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                                 params_L=proj_L)
             surrogate_loss, _ = self.surrogate_loss(seg_adv, log_prob_new,
                                                     log_probs_old)
+            with torch.no_grad():           # black_box_agent.py:308-310
+                kl_row = self.kl_old_new_proj(
+                    mean_new, L_new, mean_old, L_old, proj_mean, proj_L)
             entropy = self.policy.entropy([proj_mean, proj_L]).mean()
             entropy_loss = -self.entropy_penalty_coef * entropy
             trust_region_loss = self.projection.get_trust_region_loss(
@@ -1480,10 +1485,10 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             g, gc = self._optimizer_step(self.policy_optimizer,
                                          self.policy_net_params,
                                          self.clip_grad_norm)
-            rec.index_copy_(0, idx, torch.stack([
+            rec.index_copy_(0, idx, torch.cat([torch.stack([
                 surrogate_loss.detach(), entropy_loss.detach(),
                 trust_region_loss.detach(), policy_loss.detach(),
-                entropy.detach(), g, gc])[None])
+                entropy.detach(), g, gc]), kl_row.to(self.dtype)])[None])
             idx.add_(1)
             # the last epoch's distributions (fixed graph buffers when replayed)
             last["t"] = (mean_new.detach(), ops.detach_L(L_new),
@@ -1516,15 +1521,18 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 self.num_iterations)
         if beta is not None and not torch.is_tensor(beta):
             beta = torch.as_tensor(float(beta), device=self.device)
+        # (a sharded run has no split epochs: its balance norms are left out)
+        balance = self._balance_iteration() and not self.dist.active
+        self.check_policy_balance = balance
         rec, mean_new, L_new, proj_mean, proj_L = smlp_ops.policy_update(
             self, states, dataset["segment_action"],
             dataset["segment_log_prob"], dataset["segment_advantage"],
-            mean_old, L_old, beta)
+            mean_old, L_old, beta, balance=balance)
         N = states.shape[0]
         last = (mean_new, ops.expand_shared(L_new, N), proj_mean,
                 ops.expand_shared(proj_L, N))
         return self._finish_policy_update(rec, last, states, mean_old, L_old,
-                                          defer=defer)
+                                          defer=defer, balance=balance)
 
     def _update_policy_direct(self, dataset, defer=False):
         """update_policy for the mean nets of csrc/pmlp.hip / the fused 128 x 2

@@ -144,9 +144,10 @@ def policy_supported(agent, L_old):
 
 
 def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
-                  beta):
-    """E policy epochs -> (rec [E, 7], mean_new, L_new [K,K], proj_mean,
-    proj_L [K,K]) with the last epoch's distributions."""
+                  beta, balance=False):
+    """E policy epochs -> (rec [E, 19] = 7 loss / norm scalars + 12 KL means,
+    mean_new, L_new [K,K], proj_mean, proj_L [K,K]) with the last epoch's
+    distributions."""
     from . import ops
     pol, proj, opt = agent.policy, agent.projection, agent.policy_optimizer
     net, lib = pol.mean_net, _lib.load()
@@ -163,7 +164,8 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     mats = _workspace(net, ("mats", K), lib.tce_bb_policy_mats_len(K))
     ctx = torch.zeros(lib.tce_kl_cov_proj_ctx_len(K), dtype=torch.float64,
                       device=dev)
-    rec = torch.zeros(E, 7, dtype=torch.float32, device=dev)
+    # per epoch: 7 loss / norm scalars + the 12 KL means of kl_old_new_proj
+    rec = torch.zeros(E, 19, dtype=torch.float32, device=dev)
     mean_new = torch.empty(N, K, dtype=torch.float32, device=dev)
     proj_mean = torch.empty(N, K, dtype=torch.float32, device=dev)
     beta_t = None if beta is None else \
@@ -177,21 +179,39 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     g = opt.param_groups[0]
     opt.bind_grads()
 
-    def launch(epochs, do_adam, rec_rows):
+    def launch(epochs, do_adam, rec_rows, adv=adv, tr_coeff=None,
+               ent_coef=None):
         call("tce_bb_policy_epochs_f32", ptr(x), x.stride(0), ptr(actions),
              ptr(logp_old), ptr(adv), ptr(mean_old), ptr(L_old), N,
              net.dim_in, H, K, _ACT[net.act_func_hidden_type], var.numel(),
              float(pol.min_std), float(proj.mean_bound), float(proj.cov_bound),
              ptr(beta_t), int(bool(proj.entropy_eq)),
-             float(proj.trust_region_coeff), include_cov,
-             float(agent.entropy_penalty_coef), ptr(opt.flat_param),
+             float(proj.trust_region_coeff if tr_coeff is None else tr_coeff),
+             include_cov,
+             float(agent.entropy_penalty_coef if ent_coef is None
+                   else ent_coef), ptr(opt.flat_param),
              ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v), ptr(opt.dev_state),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
              float(g["eps"]), float(g["weight_decay"]),
              float(agent.clip_grad_norm), 1.0, int(do_adam), diag, epochs,
-             ptr(ctx), ptr(ws), ptr(mats), ptr(rec_rows), ptr(mean_new),
+             ptr(ctx), ptr(ws), ptr(mats), ptr(rec_rows), 19, ptr(mean_new),
              ptr(proj_mean), stream())
-    if not agent.dist.active:
+    if balance and not agent.dist.active:
+        # an iteration with the policy balance check (black_box_agent.py:
+        # 218-284): before every epoch the parameter-gradient norms of the
+        # surrogate loss alone (no trust region / entropy term) and of the trust
+        # region loss alone (zero advantages) -- the same kernels without the
+        # optimizer step; the finish kernel leaves |g| in its record row
+        zero_adv = torch.zeros_like(adv)
+        bal = torch.zeros(2, E, 19, dtype=torch.float32, device=dev)
+        for e in range(E):
+            launch(1, False, bal[0, e], tr_coeff=0.0, ent_coef=0.0)
+            launch(1, False, bal[1, e], adv=zero_adv, ent_coef=0.0)
+            launch(1, True, rec[e])
+        opt.host_step += E
+        opt._opt_called = True
+        rec = torch.cat([rec, bal[0, :, 5:6], bal[1, :, 5:6]], dim=1)
+    elif not agent.dist.active:
         launch(E, True, rec)
         opt.host_step += E
         opt._opt_called = True

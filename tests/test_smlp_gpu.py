@@ -231,11 +231,22 @@ def test_policy_epochs_match_the_oracle_pieces(std_only, K, H, din, N, ent,
         total.backward()
         gn = torch.sqrt(sum((p.grad ** 2).sum() for p in ref)).item()
         ropt.step()
+        with torch.no_grad():      # kl_old_new_proj, black_box_agent.py:391-436
+            Lo = d(L_old).expand(N, -1, -1)
+            kl = [t.mean().item()
+                  for p, q in (((mean, L), (d(mean_old), Lo)), ((mean, L), (pm, pLr)),
+                               ((pm, pLr), (d(mean_old), Lo)))
+                  for t in KO.gaussian_kl_details(p[0], p[1], q[0], q[1])]
         rows.append([s_loss.item(), e_loss.item(), tr.item(), total.item(),
-                     entropy.item(), gn, gn])
+                     entropy.item(), gn, gn] + kl)
         last = (mean.detach(), L[0].detach(), pm.detach(), pLr[0].detach())
-    np.testing.assert_allclose(rec.cpu().numpy(), np.array(rows), rtol=2e-3,
+    got = rec.cpu().numpy()
+    assert got.shape == (E, 19)
+    np.testing.assert_allclose(got[:, :7], np.array(rows)[:, :7], rtol=2e-3,
                                atol=2e-5)
+    # the 12 KL means: float32 differences of O(K) terms against a float64 reference
+    np.testing.assert_allclose(got[:, 7:], np.array(rows)[:, 7:], rtol=2e-3,
+                               atol=3e-5)
     for p, q in zip(params, ref):
         torch.testing.assert_close(p.detach().cpu().double(), q.detach(),
                                    rtol=0, atol=5e-5)
