@@ -484,7 +484,9 @@ def _run_config(name, spec, steps, warmup):
         samp += res.get("sampling_time", 0.0)
     E = spec["epochs"]
     bal_ms = None
-    if spec["kind"] == "tce" and isinstance(agent.balance_check, int):
+    # (black-box agent: black_box_agent.py:218-284, two extra launches per
+    # policy epoch without the optimizer step)
+    if isinstance(agent.balance_check, int):
         bal_ms = time_balance_iteration(agent, torch.cuda.synchronize)
     out = {"workload": spec["workload"], "num_env": N, "num_times": T,
            "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],
