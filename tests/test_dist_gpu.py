@@ -163,8 +163,18 @@ def _build_for_equivalence(kind, n_env, overlap):
         exp.initialize(cfg, 0, None)
         return exp.agent, 4, 24
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from test_agent_gpu import build_bbrl
-    agent, _ = build_bbrl(n_env, 3)
+    from test_agent_gpu import BBRL_MID, build_bbrl
+    if kind == "bbrl":
+        agent, _ = build_bbrl(n_env, 3)
+    else:
+        # the reference's box-pushing / table-tennis black-box nets:
+        # objective.BBDirectEpoch + the matrix-core / pmlp critic epochs
+        c = BBRL_MID[kind[len("bbrl_"):]]
+        agent, _ = build_bbrl(n_env, 3, c["policy_hidden"], c["critic_hidden"],
+                              c["act"], c["std_only"], c["dtype"],
+                              wd_policy=c["wd"], wd_critic=c["wd"])
+        assert agent._critic_path() == (
+            "pmlp" if c["critic_hidden"][1] == 1 else "fused")
     agent.evaluation_interval = 0
     return agent, 4, 20
 
@@ -218,7 +228,9 @@ def _equiv_worker(rank, world, port, kind, overlap, q):
 
 @pytest.mark.parametrize("kind,overlap", [("tce", True), ("tce", False),
                                           ("tce_accrew", True),
-                                          ("bbrl", False)])
+                                          ("bbrl", False),
+                                          ("bbrl_box_push", False),
+                                          ("bbrl_table_tennis", False)])
 def test_sharded_equals_single_process(kind, overlap):
     """2 ranks x 32 envs == 1 process x the same 64 envs: parameters after two
     iterations (3 + 3 epochs each), observation statistics and the normalised
@@ -231,7 +243,8 @@ def test_sharded_equals_single_process(kind, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29300 + (os.getpid() % 200) + (37 if overlap else 0) + \
-        {"tce": 0, "tce_accrew": 53, "bbrl": 71}[kind]
+        {"tce": 0, "tce_accrew": 53, "bbrl": 71, "bbrl_box_push": 83,
+         "bbrl_table_tennis": 97}[kind]
     procs = [ctx.Process(target=_equiv_worker,
                          args=(r, 2, port, kind, overlap, q))
              for r in range(2)]
