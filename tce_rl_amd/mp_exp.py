@@ -121,6 +121,13 @@ class MPExperiment:
             return result
         return self.agent.evaluate(render=False)[0]
 
+    def finalize(self, surrender=None, crash=False):
+        """mp_exp.py:105-108 (cw2's end-of-repetition hook: nothing to do)."""
+
+    # mp_exp.py:110-162 keeps these two as static methods of the experiment
+    get_dim_in = staticmethod(get_dim_in)
+    dim_policy_out = staticmethod(dim_policy_out)
+
     def save_state(self, cw_config, rep, n):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() \

@@ -88,6 +88,34 @@ class RunningMeanStd:
             self.count = self.count + float(sum(float(c) for c in
                                                 allr[:, -1].tolist()))
 
+    def copy(self):
+        """util_numerical.py:296-305."""
+        new = RunningMeanStd(name=self.name, shape=tuple(self.mean.shape),
+                             dtype=self.dtype, device=self.device)
+        new.mean, new.var = self.mean.clone(), self.var.clone()
+        new.count = float(self.count)
+        return new
+
+    def combine(self, other):
+        """util_numerical.py:307-313."""
+        self.update_from_moments(other.mean, other.var, other.count)
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        """util_numerical.py:322-337 (the parallel-variance merge; a few
+        D-element device ops -- the per-rollout update takes the fused kernels
+        above)."""
+        batch_mean = torch.as_tensor(batch_mean, dtype=self.dtype,
+                                     device=self.device)
+        batch_var = torch.as_tensor(batch_var, dtype=self.dtype,
+                                    device=self.device)
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        m2 = self.var * self.count + batch_var * batch_count + \
+            torch.square(delta) * self.count * batch_count / tot
+        self.mean = self.mean + delta * batch_count / tot
+        self.var = m2 / tot
+        self.count = tot
+
     def save(self, log_dir, epoch):
         path = util.get_training_state_save_path(log_dir, self.name, epoch)
         with open(path, "wb") as f:
