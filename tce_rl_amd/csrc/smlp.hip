@@ -1309,7 +1309,8 @@ __device__ inline void bb_diag_fwd_body(
     const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
     double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
     float* __restrict__ L_proj, float* __restrict__ Li_proj, float* __restrict__ gL_tr,
-    float* __restrict__ out16, double* __restrict__ dctx, float (*dg)[64]) {
+    float* __restrict__ out16, double* __restrict__ dctx, float (*dg)[64],
+    float* __restrict__ kl_rec = nullptr) {
   if (threadIdx.x >= 64) {
     __syncthreads();                                     // (the barrier below)
     return;
@@ -1388,6 +1389,11 @@ __device__ inline void bb_diag_fwd_body(
       out16[4 * q + 1] = (float)(shape + volume);
       out16[4 * q + 2] = (float)shape;
       out16[4 * q + 3] = (float)volume;
+      if (kl_rec) {                                      // the epoch's record row (KL means)
+        kl_rec[4 * q + 1] = (float)(shape + volume);
+        kl_rec[4 * q + 2] = (float)shape;
+        kl_rec[4 * q + 3] = (float)volume;
+      }
     }
     out16[12] = (float)(0.5 * (double)K * (1.0 + 1.8378770664093453) + lpld);
     out16[13] = 0.f;
@@ -1402,10 +1408,10 @@ __global__ __launch_bounds__(64) void bb_diag_fwd_kernel(
     const float* __restrict__ var, float min_std, const float* __restrict__ L_old, int K,
     double eps_cov, float tr_coeff, int include_cov, float* __restrict__ L_new,
     float* __restrict__ L_proj, float* __restrict__ Li_proj, float* __restrict__ gL_tr,
-    float* __restrict__ out16, double* __restrict__ dctx) {
+    float* __restrict__ out16, double* __restrict__ dctx, float* __restrict__ kl_rec) {
   __shared__ float dg[3][64];
   bb_diag_fwd_body(var, min_std, L_old, K, eps_cov, tr_coeff, include_cov, L_new, L_proj, Li_proj,
-                   gL_tr, out16, dctx, dg);
+                   gL_tr, out16, dctx, dg, kl_rec);
 }
 
 // finish of a black-box policy epoch (one workgroup): the mean parts of the KL
@@ -1580,6 +1586,9 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
 // (NPT: parameters per thread.  The loads are unconditional with clamped
 // addresses and the values selected afterwards: element assignments under a
 // branch make the compiler copy the whole register array at every step.)
+// rec_kl: 0, or the record's row stride when the rows carry the 12 KL means at
+// [7, 19) (the mean parts are written here, the K-vector parts of the NEXT
+// epoch by the next_fwd section into the next row).
 constexpr int FD_NPT = 16;
 template <int NPT>
 __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
@@ -1630,9 +1639,6 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     o5 = out16[5];
     o12 = out16[12];
   }
-  // (this epoch's K x K KL parts, before next_fwd overwrites them)
-  float okl = 0.f;
-  if (rec_kl && tid < 12) okl = out16[tid];
   __builtin_amdgcn_sched_barrier(0);
   const double invN = 1.0 / (double)N;
   // ---- wave 0: d / d L_proj on the diagonal, projection backward, Cholesky head backward
@@ -1696,12 +1702,13 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     rec[4] = o12;
     rec[5] = before;
     rec[6] = before * cf;
-  }
-  if (rec_kl && tid < 12) {
-    // kl_old_new_proj of this epoch: the mean parts from the row sums
-    const int q = tid >> 2;
-    const double dq = q == 0 ? ds2 : (q == 1 ? ds3 : ds4);
-    rec[7 + tid] = (tid & 3) ? okl : (float)(0.5 * dq * invN);
+    if (rec_kl > 0) {
+      // kl_old_new_proj of this epoch: the mean parts from the row sums (the
+      // cov / shape / volume parts were put into this row by the kernel that
+      // built the epoch's factors: bb_diag_fwd_kernel / the previous finish)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rec[7 + 4 * q] = (float)(0.5 * dsq[q] * invN);
+    }
   }
   // ---- Adam on the registers
   const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
@@ -1787,6 +1794,12 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
       out16[4 * q + 1] = (float)(shape + volume);
       out16[4 * q + 2] = (float)shape;
       out16[4 * q + 3] = (float)volume;
+      if (rec_kl > 0) {                                  // the NEXT epoch's record row
+        float* nx = rec + rec_kl + 7;
+        nx[4 * q + 1] = (float)(shape + volume);
+        nx[4 * q + 2] = (float)shape;
+        nx[4 * q + 3] = (float)volume;
+      }
     }
     out16[12] = (float)(0.5 * (double)K * (1.0 + 1.8378770664093453) + lpld);
     out16[13] = 0.f;
@@ -2122,7 +2135,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
       if (e == 0 || !chained) {
         hipLaunchKernelGGL(bb_diag_fwd_kernel, dim3(1), dim3(64), 0, st, param + P, min_std, L_old,
                            K, eps_cov, tr_coeff, tr_include_cov, L_new, L_proj, Li_proj, gL_tr,
-                           out16, proj_ctx);
+                           out16, proj_ctx,
+                           rec_kl ? rec + (int64_t)rec_stride * e + 7 : (float*)nullptr);
         TCE_LAUNCH_CHECK();
       }
     } else {
@@ -2167,7 +2181,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   hipLaunchKernelGGL(bb_diag_finish_kernel<NN>, dim3(1), dim3(SBT), 0, st, g_pL, gL_tr, L_proj,   \
                      L_old, proj_ctx, dsum, N, K, P, tr_coeff, tr_include_cov, ent_coef, param,   \
                      grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,       \
-                     grad_scale, out16, rec + (int64_t)rec_stride * e, rec_kl,                    \
+                     grad_scale, out16, rec + (int64_t)rec_stride * e, rec_kl ? rec_stride : 0,   \
                      chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr, \
                      proj_ctx)
       if (npt <= 4) FD_LAUNCH(4);
