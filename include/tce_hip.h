@@ -290,6 +290,18 @@ int tce_mean_proj_fwd_q_f32(const float* x, const float* y, const float* L,
 int tce_mean_proj_fwd_q_f64(const double* x, const double* y, const double* L,
                             int64_t L_stride, double eps, double* out, double* quad_out,
                             double* z_out, int64_t N, int K, void* stream);
+/* Backward of vec_env mode 2 (log N(x; y, L L^T), black_box_policy.py:95-128) for a
+ * factor SHARED by all envs: grad_mean [N,K] = grad_out[n] L^-T z_n and z_out
+ * [N,K] = z_n = L^-1 (x_n - y_n).  The gradient w.r.t. the shared factor is then
+ * ONE product, sum_n d logp_n / d L = tril((grad_mean)^T z) - (sum_n grad_out[n])
+ * diag(1 / L_ii), instead of N outer products [N,K,K] and their sum (what autograd
+ * builds for log_prob under an expanded factor). */
+int tce_mvn_logprob_bwd_z_f32(const float* x, const float* y, const float* L,
+                              const float* grad_out, float* grad_mean, float* z_out,
+                              int64_t N, int K, void* stream);
+int tce_mvn_logprob_bwd_z_f64(const double* x, const double* y, const double* L,
+                              const double* grad_out, double* grad_mean, double* z_out,
+                              int64_t N, int K, void* stream);
 /* The backward of mode 1 (mean projection) that ADDS its result to grad_x
  * instead of storing it: the policy objective's two halves of d / d mean_new
  * (trust region loss, written on its second stream; surrogate through the

@@ -269,6 +269,9 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
       } else {
         const real g = gout[n[s]];
         if (in) gx[n[s] * K + lane] = g * q[s];               // d logp / d mean
+        // (z = L^-1 (x - y) for a caller that sums d logp / d L over the envs as
+        // ONE product (g q)^T z instead of N outer products: tce_mvn_logprob_bwd_z_*)
+        if (aux2 && in) aux2[n[s] * K + lane] = d[s];
         if (gLout) {
           real* gl = gLout + n[s] * (int64_t)K * K;
           for (int r = 0; r < K; ++r) {
@@ -689,6 +692,18 @@ int tce_kl_proj_impl(int impl) {
     return vec_env_launch<REAL>(1, 0, x, y, L, L_stride, eps, nullptr, out,       \
                                 nullptr, nullptr, N, K, (hipStream_t)stream, 0,   \
                                 quad_out, z_out);                                 \
+  }                                                                               \
+  /* backward of mode 2 (log-prob) for a SHARED factor that leaves z = L^-1 (x -  \
+     y) behind instead of the per-env d / d L */                                  \
+  int tce_mvn_logprob_bwd_z_##SFX(const REAL* x, const REAL* y, const REAL* L,    \
+                                  const REAL* grad_out, REAL* grad_mean,          \
+                                  REAL* z_out, int64_t N, int K, void* stream) {  \
+    TCE_CHECK_ARG(x && y && L && grad_out && grad_mean && z_out && N > 0 &&       \
+                      K > 0 && K <= VE_MAXK,                                      \
+                  "mvn_logprob_bwd_z: bad arguments (K <= 64)");                  \
+    return vec_env_launch<REAL>(2, 1, x, y, L, 0, REAL(0), grad_out, nullptr,     \
+                                grad_mean, nullptr, N, K, (hipStream_t)stream, 0, \
+                                nullptr, z_out);                                  \
   }                                                                               \
   /* backward of mode 1 (mean projection) that ADDS to grad_x */                  \
   int tce_mean_proj_bwd_acc_##SFX(const REAL* x, const REAL* y, const REAL* L,    \

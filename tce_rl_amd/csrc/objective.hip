@@ -364,6 +364,7 @@ template <> struct ObjApi<float> {
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f32;
   static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f32;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f32;
+  static constexpr auto logp_bwd_z = tce_mvn_logprob_bwd_z_f32;
 };
 template <> struct ObjApi<double> {
   static constexpr auto vec_env = tce_vec_env_f64;
@@ -375,6 +376,7 @@ template <> struct ObjApi<double> {
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f64;
   static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f64;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f64;
+  static constexpr auto logp_bwd_z = tce_mvn_logprob_bwd_z_f64;
 };
 
 #define OBJ_TRY(call)          \
@@ -556,14 +558,34 @@ int policy_objective_end(real* grad_L, real* ws, int64_t N, int K, int P, hipStr
 // log-prob is the one of the sampled parameter vectors under the projected
 // Gaussian (tce_vec_env mode 2) instead of the pair-wise trajectory log-prob.
 // ---------------------------------------------------------------------------
-template <typename real> struct ObjSum;
-template <> struct ObjSum<float> { static constexpr auto sum_dim0 = tce_sum_dim0_f32; };
-template <> struct ObjSum<double> { static constexpr auto sum_dim0 = tce_sum_dim0_f64; };
 
+// pm | g_pm | gm_p [N,K] | logp | glp [N] | pL | g_pL | gL_p | gL_e [K,K] | z [N,K] |
+// slabs of the factor's gradient [ceil(N / 32)][K K + K] | column sums [K]
+constexpr int BB_OL_ROWS = 32;                    // = OL_ROWS (out_layer_grad's rows per slab)
 inline int64_t bb_obj_ws_len(int64_t N, int K) {
   const int64_t KK = (int64_t)K * K;
-  return 3 * obj_up4(N * K) + 2 * obj_up4(N) + 3 * obj_up4(KK) + N * KK +
-         tce_sum_dim0_slices(N, KK) * KK;
+  return 3 * obj_up4(N * K) + 2 * obj_up4(N) + 4 * obj_up4(KK) + obj_up4(N * K) +
+         obj_up4(ceil_div(N, BB_OL_ROWS) * (KK + K)) + obj_up4(K);
+}
+
+template <typename real>
+int out_layer_grad(const real* g, const real* h, real* dW, real* db, real* ws, int64_t N, int K,
+                   int H, hipStream_t st);
+
+// g_pL <- tril(g_pL) - (sum_g[0] + ent) diag(1 / L_ii): the shared factor's gradient
+// from the product (g q)^T z (tce_mvn_logprob_bwd_z_*), sum_g[0] = sum_n d loss / d
+// logp_n (= the surrogate loss itself), ent = the entropy bonus' coefficient
+template <typename real>
+__global__ __launch_bounds__(256) void bb_gpl_fix_kernel(real* __restrict__ g,
+                                                         const real* __restrict__ L,
+                                                         const real* __restrict__ sum_g, int K,
+                                                         real ent) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= K * K) return;
+  const int i = e / K, j = e - i * K;
+  real v = j <= i ? g[e] : real(0);
+  if (i == j) v -= (sum_g[0] + ent) / L[e];
+  g[e] = v;
 }
 
 template <typename real>
@@ -593,8 +615,10 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   real* pL = glp + obj_up4(N);
   real* g_pL = pL + obj_up4(KK);
   real* gL_p = g_pL + obj_up4(KK);
-  real* gL_env = gL_p + obj_up4(KK);              // [N,K,K] d logp / d L per env
-  real* sum_ws = gL_env + N * KK;
+  real* gL_e = gL_p + obj_up4(KK);                // split: the entropy term's d / d L_new
+  real* zbuf = gL_e + obj_up4(KK);                // [N,K] L_proj^-1 (actions - proj mean)
+  real* ol_ws = zbuf + obj_up4(N * K);            // slabs of (g q)^T z
+  real* dbs = ol_ws + obj_up4(ceil_div(N, BB_OL_ROWS) * (KK + K));
   // (proj_started: bb_policy_epoch has put the Cholesky head and the covariance
   // projection on the side stream, beside the mean net's forward)
   if (!proj_started) {
@@ -614,23 +638,25 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   OBJ_TRY(A::vec_env(2, 0, actions, pm, pL, 0, real(0), nullptr, logp, nullptr, nullptr, N, K,
                      st));
   OBJ_TRY(surrogate<real>(logp, logp_old, adv, N, sur2, glp, sur_ws, st));
-  OBJ_TRY(A::vec_env(2, 1, actions, pm, pL, 0, real(0), glp, nullptr, g_pm, gL_env, N, K, st));
-  OBJ_TRY(ObjSum<real>::sum_dim0(gL_env, g_pL, sum_ws, N, KK, st));
-  if (ent_coef != real(0) && !split) {
-    hipLaunchKernelGGL(obj_ent_diag_kernel<real>, dim3(1), dim3(64), 0, st, g_pL, pL, K,
-                       ent_coef);
-    TCE_LAUNCH_CHECK();
-  }
+  // d / d proj mean per env and d / d L_proj summed over the envs: the shared factor
+  // makes the sum ONE [K x N] . [N x K] product (g q)^T z (as the mean net's output
+  // layer: 32-row slabs, fixed-order reduction) instead of N outer products
+  // written to and re-read from HBM ([N,K,K]: 65 MB at 4096 envs and K 63, whose
+  // sum alone took 209 us of a 0.8 ms epoch)
+  OBJ_TRY(A::logp_bwd_z(actions, pm, pL, glp, g_pm, zbuf, N, K, st));
+  OBJ_TRY(out_layer_grad<real>(g_pm, zbuf, g_pL, dbs, ol_ws, N, K, K, st));
+  hipLaunchKernelGGL(bb_gpl_fix_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0, st,
+                     g_pL, pL, (const real*)sur2, K, split ? real(0) : ent_coef);
+  TCE_LAUNCH_CHECK();
   OBJ_HIP(hipEventRecord(S->ev[3], st));
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[3], 0));
   OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_p, 1, K, sd));
   if (split && ent_coef != real(0)) {
-    // the entropy term's own way back (gL_p above is the surrogate's alone); the
-    // per-env slab is free again: its sum was taken in front of ev[3]
+    // the entropy term's own way back (gL_p above is the surrogate's alone)
     hipLaunchKernelGGL(obj_ent_only_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0,
                        sd, g_pL, pL, K, ent_coef);
     TCE_LAUNCH_CHECK();
-    OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_env, 1, K, sd));
+    OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_e, 1, K, sd));
   }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
   OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
@@ -638,7 +664,7 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
   if (split) {
     // nothing is added: grad_mean / grad_L hold the trust region loss's gradient,
-    // ws the surrogate's (gm_p, gL_p) and the entropy term's (gL_env [K,K])
+    // ws the surrogate's (gm_p, gL_p) and the entropy term's (gL_e [K,K])
     if (proj_mean_out)
       OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_mean_out, pm, sizeof(real) * N * K,
                                     hipMemcpyDeviceToDevice, st));
@@ -688,6 +714,7 @@ int policy_objective_begin(const real* var_vec, int nvec, real min_std, const re
 // 26 us.)  Blocks of OL_ROWS rows -> partial [K H + K] slabs -> one reduction.
 // ---------------------------------------------------------------------------
 constexpr int OL_ROWS = 32, OL_MAXK = 64;
+static_assert(OL_ROWS == BB_OL_ROWS, "bb_obj_ws_len sizes the slabs of out_layer_grad");
 
 template <typename real>
 __global__ __launch_bounds__(256) void out_layer_grad_kernel(const real* __restrict__ g,
