@@ -4,7 +4,7 @@ documents (tests/golden/resolved/*_bbrl.json: 128 x 2 + 256 x 2 and 256 x 1 +
 hand-written epochs (objective.BBDirectEpoch, pmlp / matrix-core critic) against
 the HIP-graph + library-GEMM path they replace (small_net_kernels=False).
 
-    python scripts/time_bbrl_docs.py [ENVS] [hand|graph|both] [STEPS]
+    python scripts/time_bbrl_docs.py [ENVS] [hand|graph|both] [STEPS] [box|table]
 """
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ ENVS = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 MODES = {"hand": (True,), "graph": (False,), "both": (True, False)}[
     sys.argv[2] if len(sys.argv) > 2 else "both"]
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+ONLY = sys.argv[4] if len(sys.argv) > 4 else ""
 
 
 def build(doc, hand):
@@ -45,6 +46,8 @@ def build(doc, hand):
 
 
 for doc in ("box_push_random_init_bbrl", "table_tennis_4d_bbrl"):
+    if ONLY and not doc.startswith(ONLY):
+        continue
     for hand in MODES:
         agent = build(doc, hand)
         ts = []

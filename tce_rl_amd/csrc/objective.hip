@@ -560,12 +560,13 @@ int policy_objective_end(real* grad_L, real* ws, int64_t N, int K, int P, hipStr
 // ---------------------------------------------------------------------------
 
 // pm | g_pm | gm_p [N,K] | logp | glp [N] | pL | g_pL | gL_p | gL_e [K,K] | z [N,K] |
-// slabs of the factor's gradient [ceil(N / 32)][K K + K] | column sums [K]
+// slabs of the factor's gradient [ceil(N / 32)][K K + K] | column sums [K] |
+// |L_old^-1 (new - old)|^2 [N] | L_old^-1 (new - old) [N,K]
 constexpr int BB_OL_ROWS = 32;                    // = OL_ROWS (out_layer_grad's rows per slab)
 inline int64_t bb_obj_ws_len(int64_t N, int K) {
   const int64_t KK = (int64_t)K * K;
   return 3 * obj_up4(N * K) + 2 * obj_up4(N) + 4 * obj_up4(KK) + obj_up4(N * K) +
-         obj_up4(ceil_div(N, BB_OL_ROWS) * (KK + K)) + obj_up4(K);
+         obj_up4(ceil_div(N, BB_OL_ROWS) * (KK + K)) + obj_up4(K) + obj_up4(N) + obj_up4(N * K);
 }
 
 template <typename real>
@@ -619,6 +620,8 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   real* zbuf = gL_e + obj_up4(KK);                // [N,K] L_proj^-1 (actions - proj mean)
   real* ol_ws = zbuf + obj_up4(N * K);            // slabs of (g q)^T z
   real* dbs = ol_ws + obj_up4(ceil_div(N, BB_OL_ROWS) * (KK + K));
+  real* quad = dbs + obj_up4(K);                  // [N] |L_old^-1 (new - old)|^2
+  real* zmean = quad + obj_up4(N);                // [N,K] L_old^-1 (new - old)
   // (proj_started: bb_policy_epoch has put the Cholesky head and the covariance
   // projection on the side stream, beside the mean net's forward)
   if (!proj_started) {
@@ -627,12 +630,18 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
     OBJ_TRY(A::proj_fwd(L_new, L_old, 0, eps_cov, beta, entropy_eq, pL, proj_ctx, 1, K, 1, sd));
     OBJ_HIP(hipEventRecord(S->ev[1], sd));
   }
-  OBJ_TRY(A::vec_env(1, 0, mean_new, mean_old, L_old, 0, eps_mean, nullptr, pm, nullptr,
-                     nullptr, N, K, st));
+  // (as the TCE objective: the mean projection leaves q = |L_old^-1 (new - old)|^2
+  // and z = L_old^-1 (new - old) per env -- the KL diagnostics take maha(new, old)
+  // = q and maha(proj, old) = q / s^2 from it, one substitution per env instead of
+  // three, and the projection's backward starts from z)
+  OBJ_TRY(A::mean_fwd_q(mean_new, mean_old, L_old, 0, eps_mean, pm, quad, zmean, N, K, st));
   OBJ_HIP(hipEventRecord(S->ev[2], st));
   OBJ_HIP(hipStreamWaitEvent(sd, S->ev[2], 0));
   OBJ_TRY(kl_shared<real>(mean_new, mean_old, pm, L_new, L_old, pL, N, K, tr_coeff,
-                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd));
+                          tr_include_cov, out16, grad_mean, grad_L, kl_ws, sd, quad, eps_mean));
+  // grad_mean (the trust region loss's part, written on the side stream) is
+  // complete here: the mean projection's backward adds to it
+  OBJ_HIP(hipEventRecord(S->ev[5], sd));
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
   // log N(actions; pm, pL pL^T), surrogate, and back
   OBJ_TRY(A::vec_env(2, 0, actions, pm, pL, 0, real(0), nullptr, logp, nullptr, nullptr, N, K,
@@ -659,12 +668,16 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
     OBJ_TRY(A::proj_bwd(L_new, L_old, 0, pL, proj_ctx, g_pL, gL_e, 1, K, sd));
   }
   OBJ_HIP(hipEventRecord(S->ev[4], sd));
-  OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
-                     nullptr, N, K, st));
-  OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
-  if (split) {
-    // nothing is added: grad_mean / grad_L hold the trust region loss's gradient,
-    // ws the surrogate's (gm_p, gL_p) and the entropy term's (gL_e [K,K])
+  if (!split) {
+    // the surrogate's half of d / d mean_new added to the trust region's by the
+    // mean projection's backward itself, then the two halves of d / d L_new
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[5], 0));
+    OBJ_TRY(A::mean_bwd_acc(mean_new, mean_old, L_old, 0, eps_mean, g_pm, zmean, grad_mean, N, K,
+                            st));
+    OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
+    hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0, st,
+                       grad_L, gL_p, KK, grad_L, gL_p, (int64_t)0);
+    TCE_LAUNCH_CHECK();
     if (proj_mean_out)
       OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_mean_out, pm, sizeof(real) * N * K,
                                     hipMemcpyDeviceToDevice, st));
@@ -673,9 +686,11 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
                                     st));
     return 0;
   }
-  hipLaunchKernelGGL(obj_add2_kernel<real>, dim3((unsigned)ceil_div(N * K + KK, 256)), dim3(256),
-                     0, st, grad_mean, gm_p, N * (int64_t)K, grad_L, gL_p, KK);
-  TCE_LAUNCH_CHECK();
+  // split: nothing is added -- grad_mean / grad_L hold the trust region loss's
+  // gradient, ws the surrogate's (gm_p, gL_p) and the entropy term's (gL_e [K,K])
+  OBJ_TRY(A::vec_env(1, 1, mean_new, mean_old, L_old, 0, eps_mean, g_pm, nullptr, gm_p,
+                     nullptr, N, K, st));
+  OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
   if (proj_mean_out)
     OBJ_HIP_ALWAYS(hipMemcpyAsync(proj_mean_out, pm, sizeof(real) * N * K,
                                   hipMemcpyDeviceToDevice, st));
