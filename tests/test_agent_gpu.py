@@ -829,6 +829,44 @@ def test_training_improves_reward_within_the_trust_region():
     assert rewards[-1] > rewards[0]
 
 
+@pytest.mark.parametrize("shape", ["box_push", "table_tennis"])
+def test_bbrl_midsize_training_improves_reward_within_the_trust_region(shape):
+    """A short training run of the black-box agent with the reference's
+    box-pushing / table-tennis nets (full covariance) on the hand-written
+    epochs, lazy steps included: the exploration reward rises while every
+    update stays inside the KL bounds, and iteration 26 -- the second one with
+    the balance check -- reports its ratio."""
+    c = BBRL_MID[shape]
+    torch.manual_seed(0)
+    agent, _ = build_bbrl(256, 20, c["policy_hidden"], c["critic_hidden"],
+                          c["act"], c["std_only"], c["dtype"],
+                          wd_policy=c["wd"], wd_critic=c["wd"],
+                          lr_policy=1e-3, lr_critic=1e-3)
+    agent.evaluation_interval = 0
+    assert agent._critic_path() in ("fused", "pmlp")
+    rewards, covs, means, ratios = [], [], [], {}
+    for i in range(26):
+        res = agent.step()
+        rewards.append(res["exploration_segment_reward_mean"]
+                       if "exploration_segment_reward_mean" in res
+                       else res["exploration_episode_reward_mean"])
+        covs.append(res["projection_proj_old_cov_diff_max"])
+        means.append(res["projection_proj_old_mean_diff_max"])
+        assert np.isfinite(res["policy_loss_mean"])
+        if "balance_ratio" in res:
+            ratios[i + 1] = res["balance_ratio"]
+    assert agent._policy_path({"segment_params_L": agent.policy.policy(
+        torch.zeros(2, agent.policy.mean_net.dim_in, device="cuda"))[1],
+        "segment_state": torch.zeros(256, agent.policy.mean_net.dim_in,
+                                     device="cuda")}) == "direct"
+    assert sorted(ratios) == [1, 26]
+    assert np.isfinite(ratios[26]) and ratios[26] > 0
+    # the projection holds both bounds (build_bbrl: 0.005 / 0.0005)
+    assert max(covs) <= 0.0005 * 1.02
+    assert max(means) <= 0.005 * 1.02
+    assert np.mean(rewards[-5:]) > np.mean(rewards[:5])          # rewards are < 0
+
+
 OPTION_CASES = [
     dict(num_minibatchs=4),
     dict(clip_critic=0.5, clip_advantages=2.0, clip_grad_norm=0.5),
