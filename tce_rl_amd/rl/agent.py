@@ -545,6 +545,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # stays for the next look.  Iterations with the policy balance check
         # (1 in `balance_check`) have a longer policy phase and their own split.
         bal = self._balance_iteration()
+        if lazy and self._early_split_exchange():
+            # (sharded runs, first iterations: see _adopt_split)
+            torch.cuda.synchronize()
         waiting = []
         for probe in self._split_probes:
             pev, pn1, pE, pbal = probe
@@ -652,6 +655,22 @@ class TemporalCorrelatedAgent(AbstractAgent):
             return
         import torch.distributed as dist
         from ..dist import all_reduce
+        if self._early_split_exchange():
+            # The first iterations of a sharded run exchange the estimate at once
+            # (the caller has waited for the device, so the previous step's
+            # events have given it): the pipelined exchange below hands the
+            # first measured split to iteration 6 -- until then every critic
+            # epoch would run on 224 workgroups (+ 10 % per step), and a short
+            # warm-up would time exactly those steps.
+            t = torch.tensor(self._local_split, dtype=torch.int32,
+                             device=self.device)
+            all_reduce(t, op=dist.ReduceOp.MAX, group=self.dist.group)
+            a, b = (int(v) for v in t.tolist())
+            if a:
+                self._critic_split = a
+            if b:
+                self._critic_split_bal = b
+            return
         q = self._split_exchanges
         if len(q) >= 2:
             ev, host = q.pop(0)
@@ -669,6 +688,12 @@ class TemporalCorrelatedAgent(AbstractAgent):
         ev = torch.cuda.Event()
         ev.record()
         q.append((ev, host))
+
+    def _early_split_exchange(self):
+        """Sharded lazy steps 2 .. 6: the split is agreed with a blocking
+        exchange (same decision on every rank: the iteration count)."""
+        return self.dist.active and self.adaptive_critic_split and \
+            self.num_iterations <= 6
 
     def _balance_iteration(self):
         """Is the current iteration one with the policy balance check
