@@ -958,8 +958,10 @@ int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* r
  * Gaussian, surrogate, trust region loss, their gradients, mean net backward),
  * slab reduction, tce_kl_cov_proj_bwd, finish (Cholesky head backward into
  * grad [P, P + nvec), clip, Adam on all P + nvec entries, record) -- seven
- * launches; diag != 0 (std_only factors, beta == NULL: every shipped BBRL
- * config): the K x K steps collapse into K-vector steps, four launches.  rec
+ * launches; diag & 1 (std_only factors, beta == NULL: every shipped BBRL
+ * config): the K x K steps collapse into K-vector steps, four launches; diag & 2:
+ * `mats` still holds L_old^-1 from an earlier call with the same L_old (the
+ * per-epoch calls of a balance-check iteration skip its recomputation).  rec
  * [epochs][rec_stride], rec_stride 7 = {surrogate, entropy loss, trust region
  * loss, total, entropy, |g|, |g| clipped}, >= 19: followed by the 12 means of
  * kl_old_new_proj (black_box_agent.py:391-436) = {mean, cov, shape, volume}

@@ -2098,7 +2098,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "bb_policy_epochs: optimizer state missing");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, K, HEAD_BB_POLICY), "bb_policy_epochs: unsupported shape");
   TCE_CHECK_ARG(nvec == K || nvec == K + K * (K - 1) / 2, "bb_policy_epochs: bad variance vector");
-  TCE_CHECK_ARG(!diag || (nvec == K && beta == nullptr),
+  TCE_CHECK_ARG(!(diag & 1) || (nvec == K && beta == nullptr),
                 "bb_policy_epochs: the diagonal path needs std_only and no entropy bound");
   TCE_CHECK_ARG(x_stride >= din && x_stride < (1 << 24), "bb_policy_epochs: row stride outside [din, 2^24)");
   TCE_CHECK_ARG(do_adam || epochs == 1, "bb_policy_epochs: epochs > 1 needs the Adam step");
@@ -2114,7 +2114,11 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
   float* Li_old = gL_p + KK;
   float* Li_proj = Li_old + KK;
   float* out16 = Li_proj + KK;
-  {
+  // (diag bit 1: `mats` still holds L_old^-1 from an earlier call of this update --
+  // the per-epoch calls of a balance-check iteration)
+  const bool have_Li_old = (diag & 2) != 0;
+  diag &= 1;
+  if (!have_Li_old) {
     const int rc0 = s_tri_inverse(L_old, Li_old, K, st);     // once per update
     if (rc0) return rc0;
   }

@@ -180,7 +180,7 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     opt.bind_grads()
 
     def launch(epochs, do_adam, rec_rows, adv=adv, tr_coeff=None,
-               ent_coef=None):
+               ent_coef=None, again=False):
         call("tce_bb_policy_epochs_f32", ptr(x), x.stride(0), ptr(actions),
              ptr(logp_old), ptr(adv), ptr(mean_old), ptr(L_old), N,
              net.dim_in, H, K, _ACT[net.act_func_hidden_type], var.numel(),
@@ -193,7 +193,8 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
              ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v), ptr(opt.dev_state),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
              float(g["eps"]), float(g["weight_decay"]),
-             float(agent.clip_grad_norm), 1.0, int(do_adam), diag, epochs,
+             float(agent.clip_grad_norm), 1.0, int(do_adam),
+             diag | (2 if again else 0), epochs,
              ptr(ctx), ptr(ws), ptr(mats), ptr(rec_rows), 19, ptr(mean_new),
              ptr(proj_mean), stream())
     if balance and not agent.dist.active:
@@ -205,9 +206,10 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
         zero_adv = torch.zeros_like(adv)
         bal = torch.zeros(2, E, 19, dtype=torch.float32, device=dev)
         for e in range(E):
-            launch(1, False, bal[0, e], tr_coeff=0.0, ent_coef=0.0)
-            launch(1, False, bal[1, e], adv=zero_adv, ent_coef=0.0)
-            launch(1, True, rec[e])
+            # (again: L_old^-1 stays in `mats` from the update's first call)
+            launch(1, False, bal[0, e], tr_coeff=0.0, ent_coef=0.0, again=e > 0)
+            launch(1, False, bal[1, e], adv=zero_adv, ent_coef=0.0, again=True)
+            launch(1, True, rec[e], again=True)
         opt.host_step += E
         opt._opt_called = True
         rec = torch.cat([rec, bal[0, :, 5:6], bal[1, :, 5:6]], dim=1)
