@@ -302,6 +302,19 @@ int tce_mvn_logprob_bwd_z_f32(const float* x, const float* y, const float* L,
 int tce_mvn_logprob_bwd_z_f64(const double* x, const double* y, const double* L,
                               const double* grad_out, double* grad_mean, double* z_out,
                               int64_t N, int K, void* stream);
+/* The same with the surrogate's gradient (black_box_agent.py:468-489) formed
+ * inside -- grad_out[n] = -exp(logp_n - logp_old[n]) adv[n] / N needs no sum
+ * over the envs -- and the log-probs left in logp_out [N] for the loss value
+ * (tce_surrogate_* with grad == NULL): policy.log_prob's forward pass and the
+ * surrogate's gradient kernel drop out of the epoch. */
+int tce_mvn_logprob_bwd_z_sur_f32(const float* x, const float* y, const float* L,
+                                  const float* logp_old, const float* adv,
+                                  float* grad_mean, float* z_out, float* logp_out,
+                                  int64_t N, int K, void* stream);
+int tce_mvn_logprob_bwd_z_sur_f64(const double* x, const double* y, const double* L,
+                                  const double* logp_old, const double* adv,
+                                  double* grad_mean, double* z_out, double* logp_out,
+                                  int64_t N, int K, void* stream);
 /* The backward of mode 1 (mean projection) that ADDS its result to grad_x
  * instead of storing it: the policy objective's two halves of d / d mean_new
  * (trust region loss, written on its second stream; surrogate through the

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
     const real* __restrict__ x, const real* __restrict__ y, const real* __restrict__ L,
     real eps, const real* __restrict__ gout, real* __restrict__ out, real* __restrict__ gx,
     real* __restrict__ gLout, int64_t N, int K, int acc, real* __restrict__ aux,
-    real* __restrict__ aux2) {
+    real* __restrict__ aux2, const real* __restrict__ lp_old = nullptr,
+    const real* __restrict__ adv = nullptr, real* __restrict__ logp_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* Ls = reinterpret_cast<real*>(smem_raw);               // [K][KP]
   const int KP = sm_pitch(K);
@@ -267,7 +268,18 @@ __global__ __launch_bounds__(VS_BT) void vec_env_shared_kernel(
         // half of d / d mean, written on another stream and waited for by the caller)
         if (in) gx[n[s] * K + lane] = acc ? gx[n[s] * K + lane] + o : o;
       } else {
-        const real g = gout[n[s]];
+        real g;
+        if (lp_old) {
+          // the surrogate's gradient formed here (it needs no sum over the envs):
+          // d (-mean(ratio adv)) / d logp_n = -ratio_n adv_n / N, ratio = exp(logp -
+          // logp_old); the log-prob is left behind for the loss value
+          // (tce_mvn_logprob_bwd_z_sur_*: no forward pass, no gradient kernel)
+          const real lp = real(-0.5) * quad[s] - logdet - real(0.5 * LOG_2PI) * (real)K;
+          g = -(exp(lp - lp_old[n[s]]) * adv[n[s]]) * (real(1) / (real)N);
+          if (lane == 0) logp_out[n[s]] = lp;
+        } else {
+          g = gout[n[s]];
+        }
         if (in) gx[n[s] * K + lane] = g * q[s];               // d logp / d mean
         // (z = L^-1 (x - y) for a caller that sums d logp / d L over the envs as
         // ONE product (g q)^T z instead of N outer products: tce_mvn_logprob_bwd_z_*)
@@ -592,13 +604,15 @@ int set_lds(F kern, size_t lds) {
 template <typename real, int MODE, bool BWD>
 int vec_env_launch_mb(const real* x, const real* y, const real* L, int64_t sL, real eps,
                       const real* gout, real* out, real* gx, real* gL, int64_t N, int K,
-                      hipStream_t st, int acc, real* aux, real* aux2) {
+                      hipStream_t st, int acc, real* aux, real* aux2,
+                      const real* lp_old = nullptr, const real* adv = nullptr,
+                      real* logp_out = nullptr) {
   if (sL == 0) {
     const size_t lds = (size_t)K * sm_pitch(K) * sizeof(real);
     set_lds(vec_env_shared_kernel<real, MODE, BWD>, lds);
     hipLaunchKernelGGL((vec_env_shared_kernel<real, MODE, BWD>),
                        dim3((unsigned)ceil_div(N, VS_EPB)), dim3(VS_BT), lds, st, x, y, L, eps,
-                       gout, out, gx, gL, N, K, acc, aux, aux2);
+                       gout, out, gx, gL, N, K, acc, aux, aux2, lp_old, adv, logp_out);
   } else {
     const size_t lds = 2 * (size_t)K * 64 * sizeof(real);
     set_lds(vec_env_kernel<real, MODE, BWD>, lds);
@@ -704,6 +718,20 @@ int tce_kl_proj_impl(int impl) {
     return vec_env_launch<REAL>(2, 1, x, y, L, 0, REAL(0), grad_out, nullptr,     \
                                 grad_mean, nullptr, N, K, (hipStream_t)stream, 0, \
                                 nullptr, z_out);                                  \
+  }                                                                               \
+  /* the same with the surrogate's gradient formed inside: grad_out[n] =         \
+     -exp(logp_n - logp_old[n]) adv[n] / N; logp_out [N] receives the log-probs   \
+     (no forward pass, no tce_surrogate_* gradient) */                            \
+  int tce_mvn_logprob_bwd_z_sur_##SFX(                                            \
+      const REAL* x, const REAL* y, const REAL* L, const REAL* logp_old,          \
+      const REAL* adv, REAL* grad_mean, REAL* z_out, REAL* logp_out, int64_t N,   \
+      int K, void* stream) {                                                      \
+    TCE_CHECK_ARG(x && y && L && logp_old && adv && grad_mean && z_out &&         \
+                      logp_out && N > 0 && K > 0 && K <= VE_MAXK,                 \
+                  "mvn_logprob_bwd_z_sur: bad arguments (K <= 64)");              \
+    return vec_env_launch_mb<REAL, 2, true>(                                      \
+        x, y, L, 0, REAL(0), nullptr, nullptr, grad_mean, nullptr, N, K,          \
+        (hipStream_t)stream, 0, nullptr, z_out, logp_old, adv, logp_out);         \
   }                                                                               \
   /* backward of mode 1 (mean projection) that ADDS to grad_x */                  \
   int tce_mean_proj_bwd_acc_##SFX(const REAL* x, const REAL* y, const REAL* L,    \

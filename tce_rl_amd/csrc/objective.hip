@@ -364,7 +364,7 @@ template <> struct ObjApi<float> {
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f32;
   static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f32;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f32;
-  static constexpr auto logp_bwd_z = tce_mvn_logprob_bwd_z_f32;
+  static constexpr auto logp_bwd_z_sur = tce_mvn_logprob_bwd_z_sur_f32;
 };
 template <> struct ObjApi<double> {
   static constexpr auto vec_env = tce_vec_env_f64;
@@ -376,7 +376,7 @@ template <> struct ObjApi<double> {
   static constexpr auto pl_bwd = tce_pair_logprob_bwd_f64;
   static constexpr auto pl_bwd_sur = tce_pair_logprob_bwd_sur_f64;
   static constexpr auto chol_fwd = tce_chol_build_fwd_f64;
-  static constexpr auto logp_bwd_z = tce_mvn_logprob_bwd_z_f64;
+  static constexpr auto logp_bwd_z_sur = tce_mvn_logprob_bwd_z_sur_f64;
 };
 
 #define OBJ_TRY(call)          \
@@ -643,16 +643,16 @@ int bb_policy_objective(const real* mean_new, const real* L_new, const real* mea
   // complete here: the mean projection's backward adds to it
   OBJ_HIP(hipEventRecord(S->ev[5], sd));
   OBJ_HIP(hipStreamWaitEvent(st, S->ev[1], 0));
-  // log N(actions; pm, pL pL^T), surrogate, and back
-  OBJ_TRY(A::vec_env(2, 0, actions, pm, pL, 0, real(0), nullptr, logp, nullptr, nullptr, N, K,
-                     st));
-  OBJ_TRY(surrogate<real>(logp, logp_old, adv, N, sur2, glp, sur_ws, st));
+  // log N(actions; pm, pL pL^T), surrogate, and back: ONE per-env kernel (the
+  // backward recomputes z anyway and the surrogate's gradient needs no sum over
+  // the envs), then the loss value from the log-probs it left behind
   // d / d proj mean per env and d / d L_proj summed over the envs: the shared factor
   // makes the sum ONE [K x N] . [N x K] product (g q)^T z (as the mean net's output
   // layer: 32-row slabs, fixed-order reduction) instead of N outer products
   // written to and re-read from HBM ([N,K,K]: 65 MB at 4096 envs and K 63, whose
   // sum alone took 209 us of a 0.8 ms epoch)
-  OBJ_TRY(A::logp_bwd_z(actions, pm, pL, glp, g_pm, zbuf, N, K, st));
+  OBJ_TRY(A::logp_bwd_z_sur(actions, pm, pL, logp_old, adv, g_pm, zbuf, logp, N, K, st));
+  OBJ_TRY(surrogate<real>(logp, logp_old, adv, N, sur2, (real*)nullptr, sur_ws, st));
   OBJ_TRY(out_layer_grad<real>(g_pm, zbuf, g_pL, dbs, ol_ws, N, K, K, st));
   hipLaunchKernelGGL(bb_gpl_fix_kernel<real>, dim3((unsigned)ceil_div(KK, 256)), dim3(256), 0, st,
                      g_pL, pL, (const real*)sur2, K, split ? real(0) : ent_coef);

@@ -158,3 +158,50 @@ def test_objective_entry_points_reject_bad_arguments():
     assert b"null buffer" in lib.tce_last_error()
     # (no [N, K, K] tensor: the shared factor's gradient is one product over the envs)
     assert 4 * 4096 * 20 < lib.tce_bb_policy_objective_ws_len(4096, 20) < 4096 * 400
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("N,K", [(37, 5), (300, 28), (4096, 63)])
+def test_logprob_backward_with_z_matches_autograd(N, K, dtype):
+    """tce_mvn_logprob_bwd_z_* / _sur_* (black_box_policy.py:95-128 under a
+    factor shared by all envs): the per-env gradient w.r.t. the mean, the
+    log-probs, and -- from z -- the factor's gradient as ONE product over the
+    envs, tril((g q)^T z) - (sum g) diag(1 / L_ii), against torch autograd of
+    the surrogate loss in float64."""
+    from tce_rl_amd._lib import call, ptr, sfx, stream
+    g = torch.Generator().manual_seed(N + K)
+    d64 = torch.float64
+    L = torch.tril(torch.randn(K, K, generator=g, dtype=d64)) * 0.2
+    L.diagonal().copy_(torch.rand(K, generator=g, dtype=d64) + 0.5)
+    mean = torch.randn(N, K, generator=g, dtype=d64)
+    x = mean + (torch.randn(N, K, generator=g, dtype=d64) @ L.T)
+    adv = torch.randn(N, generator=g, dtype=d64)
+    m_ref = mean.clone().requires_grad_(True)
+    L_ref = L.clone().requires_grad_(True)
+    dist = torch.distributions.MultivariateNormal(m_ref, scale_tril=L_ref)
+    logp = dist.log_prob(x)
+    lp_old = (logp.detach() + 0.1 * torch.randn(N, generator=g, dtype=d64))
+    loss = -((logp - lp_old).exp() * adv).mean()
+    loss.backward()
+    dev = lambda t: t.to(dtype).cuda().contiguous()
+    xd, md, Ld, lod, ad = dev(x), dev(mean), dev(L), dev(lp_old), dev(adv)
+    gm = torch.empty(N, K, dtype=dtype, device="cuda")
+    z = torch.empty(N, K, dtype=dtype, device="cuda")
+    lp = torch.empty(N, dtype=dtype, device="cuda")
+    call("tce_mvn_logprob_bwd_z_sur_" + sfx(dtype), ptr(xd), ptr(md), ptr(Ld),
+         ptr(lod), ptr(ad), ptr(gm), ptr(z), ptr(lp), N, K, stream())
+    tol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else \
+        dict(rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(lp.cpu().double(), logp.detach(), **tol)
+    torch.testing.assert_close(gm.cpu().double(), m_ref.grad, **tol)
+    glp = -((logp.detach() - lp_old).exp() * adv) / N
+    gL = torch.tril(gm.cpu().double().T @ z.cpu().double()) - \
+        glp.sum() * torch.diag(1.0 / L.diagonal())
+    torch.testing.assert_close(gL, torch.tril(L_ref.grad), **tol)
+    # the variant that takes d loss / d logp from the caller
+    gm2 = torch.empty_like(gm)
+    z2 = torch.empty_like(z)
+    call("tce_mvn_logprob_bwd_z_" + sfx(dtype), ptr(xd), ptr(md), ptr(Ld),
+         ptr(dev(glp)), ptr(gm2), ptr(z2), N, K, stream())
+    torch.testing.assert_close(gm2.cpu().double(), m_ref.grad, **tol)
+    torch.testing.assert_close(z2, z)
