@@ -486,7 +486,9 @@ def _run_config(name, spec, steps, warmup):
     bal_ms = None
     # (black-box agent: black_box_agent.py:218-284, two extra launches per
     # policy epoch without the optimizer step)
-    if isinstance(agent.balance_check, int):
+    # (a sharded black-box run leaves the check's two norms out: rl/agent.py)
+    if isinstance(agent.balance_check, int) and not (
+            spec["kind"] != "tce" and agent.dist.active):
         bal_ms = time_balance_iteration(agent, torch.cuda.synchronize)
     out = {"workload": spec["workload"], "num_env": N, "num_times": T,
            "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],

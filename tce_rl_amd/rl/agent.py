@@ -1273,9 +1273,13 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         return None
 
     def step(self):
+        # (sharded runs too: the two updates issue their gradient all-reduces on
+        # two communicators -- the critic's on the default group from the side
+        # stream, the policy's on the agent's second group from the main stream --
+        # in the same host order on every rank, and nothing waits for the device)
         if self.lazy_metrics and self.overlap_updates and \
                 self.small_net_kernels and self.num_minibatchs == 1 and \
-                not self.dist.active and self.device.type == "cuda" and \
+                self.device.type == "cuda" and \
                 self.projection.initial_entropy is not None and \
                 self._critic_path() is not None and \
                 getattr(self, "_bb_small_policy", False):
@@ -1296,8 +1300,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # (the lazy step needs both updates on the hand-written kernels -- no
         # graph, no autograd, deferrable reads: known from here on)
         self._bb_small_policy = bool(small)
-        if self.overlap_updates and (self.graph_epochs or small) and \
-                self.num_minibatchs == 1 and not self.dist.active:
+        if self.overlap_updates and self.num_minibatchs == 1 and \
+                (small or (self.graph_epochs and not self.dist.active)):
             # the two updates are independent chains of ~100 small launches per
             # epoch, replayed from HIP graphs: side by side on two streams
             main = torch.cuda.current_stream()

@@ -125,8 +125,10 @@ def critic_update(agent, states, returns, old_values):
         for e in range(E):
             launch(1, False, rec[e], 1.0)
             agent.dist.allreduce_flat(opt.flat_grad, average=False)
-            opt.step(agent.clip_grad_norm, grad_scale=1.0 / agent.dist.world)
-            rec[e, 1:3].copy_(opt.dev_state[1:3])
+            # clip + Adam + the record's two norms in ONE launch (tce_adam_once_*)
+            opt.step_once(agent.clip_grad_norm,
+                          grad_scale=1.0 / agent.dist.world,
+                          norms_out=rec[e, 1:3])
     return rec
 
 
@@ -222,8 +224,9 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
             launch(1, False, rec[e])
             agent.dist.allreduce_flat(opt.flat_grad, agent._policy_group,
                                       average=False)
-            opt.step(agent.clip_grad_norm, grad_scale=1.0 / agent.dist.world)
-            rec[e, 5:7].copy_(opt.dev_state[1:3])
+            opt.step_once(agent.clip_grad_norm,
+                          grad_scale=1.0 / agent.dist.world,
+                          norms_out=rec[e, 5:7])
     KK = (K * K + 3) // 4 * 4
     L_new = mats[:K * K].view(K, K).clone()
     proj_L = mats[KK:KK + K * K].view(K, K).clone()
