@@ -77,7 +77,17 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# torch.cuda.current_stream() builds a Stream object through three layers of
+# device-index helpers: 8 us per call, paid by every C call (400 + 200 per step on
+# the sharded black-box path, which is host-bound).  The raw handle of the same
+# stream comes from two C calls.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
