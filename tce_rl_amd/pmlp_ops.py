@@ -135,7 +135,10 @@ def critic_update(agent, states, returns, old_values):
     cache = net.__dict__.setdefault("_tce_pmlp_ws", {})
     ws = cache.get(("ws", N))
     if ws is None:
-        # zeroed once: the loss kernel re-arms its ticket itself
+        # zeroed once: the loss kernel re-arms its ticket itself (one batch
+        # size at a time: a workspace of another N is let go)
+        for k in [k for k in cache if k != "partials"]:
+            del cache[k]
         ws = cache[("ws", N)] = torch.zeros(
             lib.tce_pmlp_critic_ws_len(N, H), dtype=dt, device=dev)
     partials = cache.get("partials")
