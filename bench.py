@@ -812,6 +812,7 @@ def main():
     barrier()
     if rank == 0:
         print("[bench] warmup done", file=sys.stderr, flush=True)
+    agent.dist.check_exchanges()
     tdist.reset_stats()
     t0 = time.perf_counter()
     pol_time = crit_time = 0.0
@@ -826,7 +827,8 @@ def main():
     for res in results:
         pol_time += res["update_policy_time"]
         crit_time += res["update_critic_time"]      # device time (HIP events)
-    coll = dict(tdist.STATS)
+    agent.dist.check_exchanges()        # (a wait that ran into its limit is fatal)
+    coll = tdist.stats()                # torch.distributed + in-library collectives
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
     # one iteration in `balance_check` (25) carries the policy balance check:
     # timed by itself, outside the K steps
@@ -897,6 +899,10 @@ def main():
                                      for t in per_rank],
             # what this rank put on the wire per step (tce_rl_amd/dist.py
             # counters over the timed region; all ranks issue the same)
+            # what carries the gradients: "xgmi-oneshot" = the in-library
+            # exchange inside the finish kernels (csrc/xchg.h), "rccl" =
+            # torch.distributed all-reduces between the C calls
+            "gradient_exchange": agent.dist.exchange_kind(),
             "collectives_per_step": round(coll["collectives"] / args.steps, 1),
             "collective_bytes_per_step": round(coll["bytes"] / args.steps),
             "roofline": roof, "roofline_extra": extra,

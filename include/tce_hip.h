@@ -668,7 +668,12 @@ int tce_policy_epoch_f32(
  * mean net and the Cholesky head alone, bal2[0] / bal2[1] receive the norms of
  * the surrogate's / the trust region loss's parameter gradient, and their sum
  * (plus the entropy term's) is the gradient the optimizer step uses.  Requires
- * do_adam (one process). */
+ * do_adam.
+ * xchg (nullable; needs do_adam): the envs are sharded over the ranks of this
+ * exchange (tce_xchg_create) -- the kernel that ends the epoch adds the peers'
+ * gradients in rank order before Adam (grad_scale = 1 / world), so a sharded
+ * epoch is the same ONE call; the two norms of a balance epoch are those of the
+ * rank-averaged parts (two more collectives).  grad keeps the SUMMED gradient. */
 int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam);
 int tce_policy_epoch2_f32(
     const float* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
@@ -683,7 +688,7 @@ int tce_policy_epoch2_f32(
     float* obj_ws, float* ws, float* partials, float* ol_ws, int T, int P, int dof, int K,
     float* m, float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
     float weight_decay, float clip_grad, float grad_scale, int do_adam, int balance,
-    float* rec_row19, float* bal2, void* stream);
+    float* rec_row19, float* bal2, void* xchg, void* stream);
 int tce_policy_epoch2_f64(
     const double* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
     int net_kind, int act, int nvec, double min_std, double* param, double* grad,
@@ -697,7 +702,7 @@ int tce_policy_epoch2_f64(
     double* obj_ws, double* ws, double* partials, double* ol_ws, int T, int P, int dof, int K,
     double* m, double* v, double* opt_state, double lr, double beta1, double beta2, double eps,
     double weight_decay, double clip_grad, double grad_scale, int do_adam, int balance,
-    double* rec_row19, double* bal2, void* stream);
+    double* rec_row19, double* bal2, void* xchg, void* stream);
 
 /* One whole policy epoch of the black-box agent in one call, for the mean nets
  * the 64-wide row kernels (tce_bb_policy_epochs_f32) do not cover:
@@ -709,7 +714,7 @@ int tce_policy_epoch2_f64(
  * zero_grad / backward, grad_norm_clip, optimizer.step -- and, with balance != 0
  * (:226-284), the two extra passes whose gradient norms go to bal2.
  * net_kind / hidden / num_hidden / param / grad / partials / ol_ws / ws / rec_row19 /
- * balance / do_adam: as tce_policy_epoch2_*; obj_ws:
+ * balance / do_adam / xchg: as tce_policy_epoch2_*; obj_ws:
  * [tce_bb_policy_objective_ws_len(N, K)]; the other objective arguments as
  * tce_bb_policy_objective_*.  After the call ws holds this epoch's mean_new [N,K]
  * at 2 up4(N hidden) and L_new [K,K] at 2 up4(N hidden) + 2 up4(N K) (up4: rounded
@@ -724,7 +729,8 @@ int tce_bb_policy_epoch_f32(
     double* kl_ws, float* obj_ws, float* ws, float* partials, float* ol_ws, int K, float* m,
     float* v, float* opt_state, float lr, float beta1, float beta2, float eps,
     float weight_decay, float clip_grad, float grad_scale, int do_adam, int balance,
-    float* rec_row19, float* bal2, float* proj_mean_out, float* proj_L_out, void* stream);
+    float* rec_row19, float* bal2, float* proj_mean_out, float* proj_L_out, void* xchg,
+    void* stream);
 int tce_bb_policy_epoch_f64(
     const double* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
     int net_kind, int act, int nvec, double min_std, double* param, double* grad,
@@ -734,7 +740,8 @@ int tce_bb_policy_epoch_f64(
     double* kl_ws, double* obj_ws, double* ws, double* partials, double* ol_ws, int K, double* m,
     double* v, double* opt_state, double lr, double beta1, double beta2, double eps,
     double weight_decay, double clip_grad, double grad_scale, int do_adam, int balance,
-    double* rec_row19, double* bal2, double* proj_mean_out, double* proj_L_out, void* stream);
+    double* rec_row19, double* bal2, double* proj_mean_out, double* proj_L_out, void* xchg,
+    void* stream);
 
 /* The two hidden layers D_in -> 128 -> 128 (fp32) of a network with a wider
  * output -- the policy mean net (mprl/rl/policy/abstract_policy.py:58-99 ->
@@ -786,6 +793,57 @@ int tce_adam_once_f64(double* param, const double* grad, double* m, double* v, i
                       double beta2, double eps, double weight_decay, double clip,
                       double grad_scale, void* stream);
 
+/* ---- one-shot gradient exchange between the env shards of one node -------
+ * No reference counterpart: mprl/ is single-device (no collectives anywhere);
+ * the sum over ranks stands for the global-batch `.mean()` of its losses
+ * (mprl/rl/agent/temporal_correlated_agent.py:716,736;
+ * mprl/rl/agent/black_box_agent.py:160-166,330-339) when the envs of one job
+ * are sharded over the GPUs of a node.  Replaces, in the sharded
+ * update, torch.distributed.all_reduce between two C calls: every rank owns
+ * one peer-visible buffer (uncached device memory, mapped by the peers through
+ * HIP IPC over xGMI); the kernels that finish an epoch publish their locally
+ * reduced gradient there, wait for the peers' per-workgroup flags, add the
+ * peers' values in rank order (bit-identical sums on every rank) and apply
+ * Adam -- no separate collective launch, no host round trip (csrc/xchg.h).
+ *   tce_xchg_create: this rank's end; max_bytes = largest message (bytes of
+ *     the largest flat gradient).  world <= 8.  *out receives the handle that
+ *     every `void* xchg` argument below takes (NULL there = no exchange).
+ *   tce_xchg_export / tce_xchg_connect: the 64-byte (tce_xchg_handle_bytes)
+ *     IPC handle of the own buffer; the handles of all ranks in rank order
+ *     (exchanged by the caller over any channel, e.g. an all-gather) map the
+ *     peers.  tce_xchg_connect_local: a peer that lives in the same process.
+ *   tce_xchg_status: 0, or 1 + r once a wait for rank r exceeded the limit
+ *     (TCE_XCHG_TIMEOUT_MS, default 20000; tce_xchg_set_timeout_ms): the
+ *     kernel goes on instead of hanging, the caller must treat it as fatal.
+ *   tce_xchg_counters: collectives issued and payload bytes, per rank.
+ *   tce_xchg_allreduce_*: in-place sum over ranks of buf [n], rank order.
+ *   tce_xchg_adam_*: all-reduce of grad (the sum stays there) + tce_adam_once_*
+ *     in ONE launch (clip == 0; with clipping: all-reduce, then the step).
+ * Every rank must issue the same sequence of collectives on an exchange, from
+ * one stream; two independent chains (critic / policy epochs) take two
+ * exchanges.  A launch that carries a sequence number cannot be replayed from
+ * a HIP graph.
+ */
+int tce_xchg_handle_bytes(void);
+int tce_xchg_create(int rank, int world, int64_t max_bytes, void** out);
+int tce_xchg_export(void* xchg, void* handle_out);
+int tce_xchg_connect(void* xchg, const void* handles);
+int tce_xchg_connect_local(void* xchg, int peer_rank, void* peer_xchg);
+int tce_xchg_destroy(void* xchg);
+int tce_xchg_status(void* xchg);
+int tce_xchg_set_timeout_ms(void* xchg, double ms);
+int tce_xchg_counters(void* xchg, int64_t* collectives, int64_t* bytes);
+int tce_xchg_allreduce_f32(void* xchg, float* buf, int64_t n, void* stream);
+int tce_xchg_allreduce_f64(void* xchg, double* buf, int64_t n, void* stream);
+int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v, int64_t n,
+                      float* state, float* norms_out, float step, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float clip, float grad_scale,
+                      void* stream);
+int tce_xchg_adam_f64(void* xchg, double* param, double* grad, double* m, double* v, int64_t n,
+                      double* state, double* norms_out, double step, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, double clip,
+                      double grad_scale, void* stream);
+
 /* ---- fused critic MLP epoch (exact-fp32 MFMA) ----------------------------
  * Forward (+ value loss + backward when `partials` != NULL) of the value
  * network D_in -> 128 -> 128 -> 1 (ValueFunction.critic ->
@@ -803,6 +861,13 @@ int tce_adam_once_f64(double* param, const double* grad, double* m, double* v, i
  * temporal_correlated_agent.py:361-366) on the flat buffers adam_param / adam_m /
  * adam_v [num_params] is fused into the gradient reduction (no clipping;
  * adam_step = step count including this update, stored to adam_state[0]).
+ * xchg (nullable; needs adam_param): the envs are sharded over the ranks of
+ * this exchange (tce_xchg_*) -- the slab reduction leaves the local gradient and
+ * ONE small launch (tce_xchg_adam_*: few workgroups wait for the peers, not the
+ * reduction's hundreds) adds the peers' gradients in rank order and applies Adam
+ * with grad_scale (1 / world): still one call per epoch.  stats is then float[4]:
+ * [2], [3] receive |g| of the rank-averaged gradient (before / after clipping);
+ * grad keeps the SUMMED gradient; stats[0] / [1] stay the local shard's.
  * max_workgroups (0 = one per CU): persistent workgroups to launch; fewer than
  * the CU count leaves CUs free for kernels of another stream (the policy
  * update runs beside the critic epochs).
@@ -817,7 +882,8 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        float* values, float* partials, float* grad, float* stats,
                        int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                        float* adam_state, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, float adam_step, void* stream);
+                       float weight_decay, float adam_step, float grad_scale, void* xchg,
+                       void* stream);
 
 /* ---- fused critic epoch for wide / double-precision value networks ---------
  * The contract of tce_mlp_critic_f32 for  D_in -> hidden -> hidden -> 1  with
@@ -844,7 +910,8 @@ int tce_mlpw_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, 
                         float* values, float* workspace, float* partials, float* grad,
                         float* stats, int max_workgroups, float* adam_param, float* adam_m,
                         float* adam_v, float* adam_state, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, float adam_step, void* stream);
+                        float eps, float weight_decay, float adam_step, float grad_scale,
+                        void* xchg, void* stream);
 int tce_mlpw_critic_f64(const double* x, int64_t env_stride, int64_t row_stride, int T,
                         int64_t R, int din, int hidden, const double* w1, const double* b1,
                         const double* w2, const double* b2, const double* w3,
@@ -854,7 +921,7 @@ int tce_mlpw_critic_f64(const double* x, int64_t env_stride, int64_t row_stride,
                         int max_workgroups, double* adam_param, double* adam_m,
                         double* adam_v, double* adam_state, double lr, double beta1,
                         double beta2, double eps, double weight_decay, double adam_step,
-                        void* stream);
+                        double grad_scale, void* xchg, void* stream);
 
 /* The backward launch of tce_mlp_critic_f32 (same buffers and contract;
  * partials != NULL required) on the f16 matrix cores with SPLIT operands: every
@@ -871,7 +938,8 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
                          float* values, float* partials, float* grad, float* stats,
                          int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                          float* adam_state, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, float adam_step, void* stream);
+                         float weight_decay, float adam_step, float grad_scale, void* xchg,
+                         void* stream);
 
 /* ---- policy mean net on rows (float32 / float64, one or two hidden layers) ----
  * D_in <= 64 -> hidden (-> hidden) -> D_out <= 64 over N rows, torch Linear
@@ -920,7 +988,9 @@ int tce_pmlp_backward_f64(const double* x, int64_t x_stride, int64_t N, int din,
  * optimizer's step count INCLUDING this update; ws: [tce_pmlp_critic_ws_len(N,
  * hidden)] elements, ZEROED once by the caller (the loss kernel re-arms its
  * ticket); partials: [tce_pmlp_max_slabs()][P]; rec_row3 = {loss, |g|, |g|
- * clipped}.  do_adam == 0: the caller (env shards) all-reduces `grad` and steps. */
+ * clipped}.  do_adam == 0: the caller steps.  xchg (nullable; needs do_adam): env
+ * shards -- the Adam launch adds the peers' gradients first (tce_xchg_adam_*),
+ * grad_scale = 1 / world. */
 int64_t tce_pmlp_critic_ws_len(int64_t N, int hidden);
 int tce_pmlp_critic_epoch_f32(const float* x, int64_t x_stride, const float* returns,
                               const float* old_values, int64_t N, int din, int hidden,
@@ -928,14 +998,16 @@ int tce_pmlp_critic_epoch_f32(const float* x, int64_t x_stride, const float* ret
                               float* grad, float* m, float* v, float* opt_state, float lr,
                               float beta1, float beta2, float eps, float weight_decay,
                               float clip_grad, float grad_scale, int do_adam, float step,
-                              float* ws, float* partials, float* rec_row3, void* stream);
+                              float* ws, float* partials, float* rec_row3, void* xchg,
+                              void* stream);
 int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* returns,
                               const double* old_values, int64_t N, int din, int hidden,
                               int num_hidden, int act, double clip_critic, double* param,
                               double* grad, double* m, double* v, double* opt_state, double lr,
                               double beta1, double beta2, double eps, double weight_decay,
                               double clip_grad, double grad_scale, int do_adam, double step,
-                              double* ws, double* partials, double* rec_row3, void* stream);
+                              double* ws, double* partials, double* rec_row3, void* xchg,
+                              void* stream);
 
 /* ---- small two-hidden-layer networks (black-box agent) ----------------------
  * D_in <= 64 -> H -> H -> D_out (H in {32, 64}, D_out <= 64), fp32, torch
@@ -959,9 +1031,15 @@ int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* r
  * (mprl/rl/agent/abstract_agent.py:62-82) on param / m / v [P] (opt_state[0] =
  * step count; first_step = count INCLUDING the first of these epochs); with
  * clip_grad > 0 (mprl/util/util_numerical.py:244-275) tce_adam_flat follows
- * instead.  do_adam == 0 (env shards: the caller all-reduces `grad` first)
- * requires epochs == 1.  rec [epochs][3], ZEROED by the caller, receives
- * {mean loss, |grad|^2, -}.
+ * instead.  do_adam == 0 (the caller steps itself) requires epochs == 1.
+ * xchg (nullable, both entries; needs do_adam): the envs are sharded over the
+ * ranks of this exchange (tce_xchg_*) -- the launch that applies Adam (critic:
+ * tce_xchg_adam behind the slab reduction; policy: the one-workgroup finish
+ * kernel) adds the peers' gradients in rank order first and takes grad_scale =
+ * 1 / world, so the `epochs` epochs of a sharded update are the same ONE call;
+ * grad keeps the SUMMED gradient, the critic's rec rows are then {mean loss of
+ * the local shard, |g|, |g| clipped} of the rank-averaged gradient.
+ * rec [epochs][3], ZEROED by the caller, receives {mean loss, |grad|^2, -}.
  *
  * tce_bb_policy_epochs: `epochs` policy epochs of BlackBoxAgent.update_policy
  * (black_box_agent.py:159-389) for a shared (non-contextual) covariance:
@@ -1001,7 +1079,8 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
                                float clip_critic, float* param, float* grad, float* m, float* v,
                                float* opt_state, float lr, float beta1, float beta2, float eps,
                                float weight_decay, float clip_grad, float grad_scale, int do_adam,
-                               int first_step, int epochs, float* ws, float* rec, void* stream);
+                               int first_step, int epochs, float* ws, float* rec, void* xchg,
+                               void* stream);
 int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* actions,
                              const float* logp_old, const float* adv, const float* mean_old,
                              const float* L_old, int64_t N, int din, int H, int K, int act,
@@ -1013,7 +1092,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              float grad_scale, int do_adam, int diag, int epochs,
                              double* proj_ctx, float* ws, float* mats, float* rec,
                              int rec_stride, float* mean_new_out, float* proj_mean_out,
-                             void* stream);
+                             void* xchg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,11 +47,11 @@ def run():
         vp = ctypes.c_void_p
         fn = lib.tce_mlp_critic_f16x2
         fn.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [vp] * 6 + \
-            [ctypes.c_int, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp] + [ctypes.c_float] * 6 + [vp]
+            [ctypes.c_int, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp] + [ctypes.c_float] * 7 + [vp, vp]
         def go():
             rc = fn(x.data_ptr(), x.stride(0), x.stride(1), T, N * T, din, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                     b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), 1, ret.data_ptr(), None, 0.0, None, partials.data_ptr(),
-                    flat.data_ptr(), stats.data_ptr(), 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    flat.data_ptr(), stats.data_ptr(), 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None,
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0
         go(); torch.cuda.synchronize()

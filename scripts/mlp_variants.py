@@ -49,12 +49,12 @@ def run():
         vp = ctypes.c_void_p
         fn = lib.tce_mlp_critic_f32
         fn.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [vp] * 6 + \
-            [ctypes.c_int, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp] + [ctypes.c_float] * 6 + [vp]
+            [ctypes.c_int, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp] + [ctypes.c_float] * 7 + [vp, vp]
         def go(bwd=True):
             rc = fn(x.data_ptr(), x.stride(0), x.stride(1), T, N * T, din, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                     b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), 1, ret.data_ptr() if bwd else None, None, 0.0,
                     None if bwd else stats.data_ptr() * 0 + partials.data_ptr(), partials.data_ptr() if bwd else None,
-                    flat.data_ptr() if bwd else None, stats.data_ptr() if bwd else None, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    flat.data_ptr() if bwd else None, stats.data_ptr() if bwd else None, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None,
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.tce_last_error()
         res = []

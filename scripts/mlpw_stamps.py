@@ -33,11 +33,11 @@ fn = lib.tce_mlpw_critic_f64 if f64 else lib.tce_mlpw_critic_f32
 rl = ctypes.c_double if f64 else ctypes.c_float
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int] + \
     [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, rl] + [ctypes.c_void_p] * 5 + [ctypes.c_int] + \
-    [ctypes.c_void_p] * 4 + [rl] * 6 + [ctypes.c_void_p]
+    [ctypes.c_void_p] * 4 + [rl] * 7 + [ctypes.c_void_p] * 2
 p = lambda t: t.data_ptr()
 for it in range(3):
     rc = fn(p(x), 0, din, R, R, din, H, p(w1), p(b), p(w2), p(b), p(w3), p(b), 1, p(ret), None, 0.0, None, p(ws), p(part),
-            p(grad), p(stats), 0, None, None, None, None, 0, 0, 0, 0, 0, 0, None)
+            p(grad), p(stats), 0, None, None, None, None, 0, 0, 0, 0, 0, 0, 1, None, None)
     assert rc == 0
     torch.cuda.synchronize()
 dy1 = ws[2 * H * H + 2 * R * H:]

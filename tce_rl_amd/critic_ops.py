@@ -69,7 +69,7 @@ def forward(mlp, x):
     call("tce_mlp_critic_f32", ptr(xs), es, rs, T, R, mlp.dim_in,
          *_weights(mlp), _ACT[mlp.act_func_hidden_type], None, None, 0.0,
          ptr(out), None, None, None, 0, None, None, None, None, 0.0, 0.0, 0.0,
-         0.0, 0.0, 0.0, stream())
+         0.0, 0.0, 0.0, 1.0, None, stream())
     return out.reshape(*x.shape[:-1], 1)
 
 
@@ -94,7 +94,7 @@ def _wide_forward(mlp, x):
          mlp.dim_in, mlp.hidden_layers[0], *_weights(mlp),
          _ACT[mlp.act_func_hidden_type], None, None, 0.0, ptr(out), ptr(ws),
          None, None, None, 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0,
-         0.0, stream())
+         0.0, 1.0, None, stream())
     return out.reshape(*x.shape[:-1], 1)
 
 
@@ -126,13 +126,13 @@ class WideEpochRunner:
         assert off == self.P
 
     def epoch(self, states, returns, old_values, clip, max_workgroups=0,
-              stats=None, adam=None):
+              stats=None, adam=None, xchg=None, grad_scale=1.0):
         xs, es, rs, T, R = _rows(states)
         ret = returns.reshape(-1)
         ret = ret if ret.is_contiguous() else ret.contiguous()
         old = old_values.reshape(-1).contiguous() if clip > 0 else None
         if stats is None:
-            stats = torch.zeros(2, dtype=self.mlp.dtype,
+            stats = torch.zeros(4, dtype=self.mlp.dtype,
                                 device=self.flat.device)
         if adam is not None:
             g = adam.param_groups[0]
@@ -149,7 +149,8 @@ class WideEpochRunner:
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(ws),
              ptr(self.partials), ptr(self.flat), ptr(stats),
-             int(max_workgroups), *ad, stream())
+             int(max_workgroups), *ad, float(grad_scale),
+             None if xchg is None else xchg.handle, stream())
         for p, v in zip(self.params, self.views):
             p.grad = v
         return stats
@@ -194,12 +195,15 @@ class EpochRunner:
         assert off == self.P
 
     def epoch(self, states, returns, old_values, clip, max_workgroups=0,
-              stats=None, adam=None):
+              stats=None, adam=None, xchg=None, grad_scale=1.0):
         """One full-batch forward + loss + backward; leaves the gradient in
         p.grad (views of the flat buffer) and returns stats = {mean loss,
         |grad|^2} as a device tensor [2] (``stats``: a ZEROED float32[2] to
         fill instead of a fresh one).  adam: a FlatAdam over the same
-        parameters whose step (without clipping) is fused into the launch."""
+        parameters whose step (without clipping) is fused into the launch.
+        xchg (a dist.Exchange; needs adam): the envs are sharded -- the
+        reduction kernel adds the peers' gradients before Adam and applies
+        grad_scale (1 / world) to the sum."""
         xs, es, rs, T, R = _rows(states)
         ret = returns.reshape(-1)
         ret = ret if ret.is_contiguous() else ret.contiguous()
@@ -207,7 +211,7 @@ class EpochRunner:
         if clip > 0:
             old = old_values.reshape(-1).contiguous()
         if stats is None:
-            stats = torch.zeros(2, dtype=torch.float32, device=self.flat.device)
+            stats = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
         if adam is not None:
             g = adam.param_groups[0]
             adam.host_step += 1
@@ -221,7 +225,9 @@ class EpochRunner:
         call(self.entry, ptr(xs), es, rs, T, R, self.mlp.dim_in,
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
-             ptr(self.flat), ptr(stats), int(max_workgroups), *ad, stream())
+             ptr(self.flat), ptr(stats), int(max_workgroups), *ad,
+             float(grad_scale), None if xchg is None else xchg.handle,
+             stream())
         for p, v in zip(self.params, self.views):
             p.grad = v
         return stats

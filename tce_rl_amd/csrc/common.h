@@ -100,3 +100,33 @@ __device__ inline T block_sum(T v, T* scratch) {
   for (int i = 0; i < nw; ++i) s += scratch[i];
   return s;
 }
+
+// ---------------------------------------------------------------------------
+// One element of torch.optim.Adam with L2-in-gradient weight decay
+// (mprl/rl/agent/abstract_agent.py:62-82), written so that EVERY kernel that
+// applies it -- the stand-alone steps of csrc/optim.hip, the finish kernels of
+// the fused epochs, the exchange kernels of csrc/xchg.hip -- produces the same
+// bits from the same inputs: contraction is off and each product-sum is an
+// explicit fma, so neither the vectorizer nor the surrounding code decides how
+// the expression rounds (the fused and the stand-alone paths are compared bit
+// for bit in tests/).  g: the gradient with its clip / shard factor applied.
+template <typename real>
+__device__ __forceinline__ void adam_coef(real lr, real b1, real b2, real step, real& step_size,
+                                          real& bc2s) {
+#pragma clang fp contract(off)
+  const real bc1 = real(1) - pow(b1, step);
+  bc2s = sqrt(real(1) - pow(b2, step));
+  step_size = lr / bc1;
+}
+template <typename real>
+__device__ __forceinline__ void adam_elem(real g, real& w, real& m, real& v, real b1, real b2,
+                                          real eps, real wd, real step_size, real bc2s) {
+#pragma clang fp contract(off)
+  if (wd != real(0)) g = fma(wd, w, g);
+  const real g1 = (real(1) - b1) * g;
+  const real g2 = ((real(1) - b2) * g) * g;
+  m = fma(b1, m, g1);
+  v = fma(b2, v, g2);
+  const real den = sqrt(v) / bc2s + eps;
+  w = w - (step_size * m) / den;
+}

@@ -41,6 +41,11 @@
 // MFMA-bound: 944 MFMAs per SIMD and tile.
 #include "mlp_shared.h"
 
+extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v,
+                                 int64_t n, float* state, float* norms_out, float step, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay,
+                                 float clip, float grad_scale, void* stream);
+
 namespace {
 
 __device__ inline f32x4 mfma(float a, float b, f32x4 c) {
@@ -704,7 +709,8 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        float* values, float* partials, float* grad, float* stats,
                        int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                        float* adam_state, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, float adam_step, void* stream) {
+                       float weight_decay, float adam_step, float grad_scale, void* xchg,
+                       void* stream) {
   TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && R > 0 && T > 0,
                 "mlp_critic: null buffer / bad sizes");
   TCE_CHECK_ARG(din >= 1 && din <= MAX_DIN, "mlp_critic: 1 <= D_in <= 40");
@@ -731,11 +737,18 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_LAUNCH_CHECK();
   if (bwd) {
     const int P = mlp_num_params(din);
-    AdamArgs ad{adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps, weight_decay,
-                adam_step};
+    TCE_CHECK_ARG(!xchg || adam_param, "mlp_critic: an exchange needs the fused Adam step");
+    // env shards: the slab reduction leaves the local gradient, the exchange + Adam
+    // follow as ONE small launch (few waiting workgroups; csrc/mlp_shared.h)
+    AdamArgs ad{xchg ? nullptr : adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps,
+                weight_decay, adam_step};
     hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
                        dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
     TCE_LAUNCH_CHECK();
+    if (xchg)
+      return tce_xchg_adam_f32(xchg, adam_param, grad, adam_m, adam_v, P, adam_state, stats + 2,
+                               adam_step, lr, beta1, beta2, eps, weight_decay, 0.f, grad_scale,
+                               stream);
   }
   return 0;
 }
@@ -783,7 +796,7 @@ int tce_mlp_hidden_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_LAUNCH_CHECK();
   if (bwd) {
     const int P = mlp_num_params(din);
-    AdamArgs ad{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    AdamArgs ad = adam_args_none();
     hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
                        dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
     TCE_LAUNCH_CHECK();

@@ -38,6 +38,11 @@
 // the chains of 16 rows each, waves 4-7 own the weight-gradient accumulators.
 #include "mlp_shared.h"
 
+extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v,
+                                 int64_t n, float* state, float* norms_out, float step, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay,
+                                 float clip, float grad_scale, void* stream);
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -707,7 +712,8 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
                          float* values, float* partials, float* grad, float* stats,
                          int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
                          float* adam_state, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, float adam_step, void* stream) {
+                         float weight_decay, float adam_step, float grad_scale, void* xchg,
+                         void* stream) {
   TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && R > 0 && T > 0,
                 "mlp_critic_f16x2: null buffer / bad sizes");
   TCE_CHECK_ARG(din >= 1 && din <= MAX_DIN, "mlp_critic_f16x2: 1 <= D_in <= 40");
@@ -736,11 +742,18 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
   }
   TCE_LAUNCH_CHECK();
   const int P = mlp_num_params(din);
-  AdamArgs ad{adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps, weight_decay,
-              adam_step};
+  TCE_CHECK_ARG(!xchg || adam_param, "mlp_critic_f16x2: an exchange needs the fused Adam step");
+  // env shards: the slab reduction leaves the local gradient, the exchange + Adam
+  // follow as ONE small launch (few waiting workgroups; csrc/mlp_shared.h)
+  AdamArgs ad{xchg ? nullptr : adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2, eps,
+              weight_decay, adam_step};
   hipLaunchKernelGGL(mlp_finish_kernel, dim3((unsigned)ceil_div(P + 1, 64)),
                      dim3(64 * FIN_GROUPS), 0, st, partials, grid, P, R, grad, stats, ad);
   TCE_LAUNCH_CHECK();
+  if (xchg)
+    return tce_xchg_adam_f32(xchg, adam_param, grad, adam_m, adam_v, P, adam_state, stats + 2,
+                             adam_step, lr, beta1, beta2, eps, weight_decay, 0.f, grad_scale,
+                             stream);
   return 0;
 }
 

@@ -105,12 +105,18 @@ struct AdamArgs {
   float *param, *m, *v, *state;          // param == nullptr: gradient only
   float lr, b1, b2, eps, wd, step;       // step = count INCLUDING this update
 };
+inline AdamArgs adam_args_none() {
+  return AdamArgs{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
 
 // grad[p] = sum over the workgroup slabs (fixed order: FIN_GROUPS interleaved
 // groups of slabs, then the groups); stats[0] = mean loss, stats[1] += |grad|^2 (the caller
 // zeroes stats); with ad.param the Adam update of torch.optim.Adam (L2 weight
 // decay in the gradient, mprl/rl/agent/abstract_agent.py:62-82) is applied in
-// the same pass.
+// the same pass.  (Env shards: gradient only here -- this grid is hundreds of
+// workgroups, and workgroups that WAIT for a peer must be few: they hold their
+// compute units while they wait -- and the exchange + Adam follow as one small
+// launch, tce_xchg_adam_*.)
 constexpr int FIN_GROUPS = 16;          // slab groups summed in parallel per column
 
 __global__ __launch_bounds__(64 * FIN_GROUPS) void mlp_finish_kernel(
@@ -137,14 +143,12 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void mlp_finish_kernel(
       grad[p] = g0;
       sq = g0 * g0;
       if (ad.param) {
-        const float w = ad.param[p];
-        const float g = ad.wd != 0.f ? g0 + ad.wd * w : g0;
-        const float mi = ad.b1 * ad.m[p] + (1.f - ad.b1) * g;
-        const float vi = ad.b2 * ad.v[p] + (1.f - ad.b2) * g * g;
+        float w = ad.param[p], mi = ad.m[p], vi = ad.v[p], step_size, bc2s;
+        adam_coef(ad.lr, ad.b1, ad.b2, ad.step, step_size, bc2s);
+        adam_elem(g0, w, mi, vi, ad.b1, ad.b2, ad.eps, ad.wd, step_size, bc2s);
         ad.m[p] = mi;
         ad.v[p] = vi;
-        const float bc1 = 1.f - powf(ad.b1, ad.step), bc2s = sqrtf(1.f - powf(ad.b2, ad.step));
-        ad.param[p] = w - (ad.lr / bc1) * mi / (sqrtf(vi) / bc2s + ad.eps);
+        ad.param[p] = w;
       }
     } else {
       stats[0] = g0 / (float)R;                                // mean loss

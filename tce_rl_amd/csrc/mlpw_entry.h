@@ -4,6 +4,16 @@
 #pragma once
 #include "mlpw_impl.h"
 
+extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v,
+                                 int64_t n, float* state, float* norms_out, float step, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay,
+                                 float clip, float grad_scale, void* stream);
+extern "C" int tce_xchg_adam_f64(void* xchg, double* param, double* grad, double* m, double* v,
+                                 int64_t n, double* state, double* norms_out, double step,
+                                 double lr, double beta1, double beta2, double eps,
+                                 double weight_decay, double clip, double grad_scale,
+                                 void* stream);
+
 #define MLPW_DEFINE(SFX, REAL)                                                      \
   extern "C" int tce_mlpw_critic_##SFX(                                             \
       const REAL* x, int64_t env_stride, int64_t row_stride, int T, int64_t R,      \
@@ -13,7 +23,7 @@
       REAL* partials, REAL* grad, REAL* stats, int max_workgroups,                  \
       REAL* adam_param, REAL* adam_m, REAL* adam_v, REAL* adam_state, REAL lr,      \
       REAL beta1, REAL beta2, REAL eps, REAL weight_decay, REAL adam_step,          \
-      void* stream) {                                                               \
+      REAL grad_scale, void* xchg, void* stream) {                                  \
     TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && workspace,               \
                   "mlpw_critic: null buffer");                                      \
     TCE_CHECK_ARG(R > 0 && T > 0 && din >= 1 && din <= 40,                          \
@@ -32,9 +42,23 @@
     a.w1 = w1; a.b1 = b1; a.b2 = b2; a.w3 = w3; a.b3 = b3;                          \
     a.ret = returns; a.old_v = old_values; a.clip = clip; a.values = values;        \
     a.partials = partials; a.P = (int)mlpw_num_params(din, hidden);                 \
-    WAdam<REAL> ad = {adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2,     \
-                      eps, weight_decay, adam_step};                                \
+    TCE_CHECK_ARG(!xchg || (partials && adam_param),                                \
+                  "mlpw_critic: an exchange needs the backward pass with the fused " \
+                  "Adam step");                                                     \
+    /* env shards: gradient only in the slab reduction, the exchange + Adam */      \
+    /* follow as ONE small launch (csrc/mlp_shared.h) */                            \
+    WAdam<REAL> ad = {xchg ? nullptr : adam_param, adam_m, adam_v, adam_state, lr,  \
+                      beta1, beta2, eps, weight_decay, adam_step};                  \
     hipStream_t st = (hipStream_t)stream;                                           \
-    MLPW_DISPATCH(REAL)                                                             \
+    const auto go_ = [&]() -> int { MLPW_DISPATCH(REAL) };                          \
+    {                                                                               \
+      const int rc_ = go_();                                                        \
+      if (rc_) return rc_;                                                          \
+    }                                                                               \
+    if (xchg)                                                                       \
+      return tce_xchg_adam_##SFX(xchg, adam_param, grad, adam_m, adam_v, a.P,       \
+                                 adam_state, stats + 2, adam_step, lr, beta1,       \
+                                 beta2, eps, weight_decay, REAL(0), grad_scale,     \
+                                 stream);                                           \
     return 0;                                                                       \
   }

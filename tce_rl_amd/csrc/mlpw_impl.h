@@ -1211,6 +1211,8 @@ struct WAdam {
 
 constexpr int WFIN_GROUPS = 16;
 
+// (env shards: gradient only here, the exchange + Adam follow as one small launch --
+// see mlp_finish_kernel, csrc/mlp_shared.h)
 template <typename real>
 __global__ __launch_bounds__(64 * WFIN_GROUPS) void mlpw_finish_kernel(
     const real* __restrict__ partials, int nparts, int P, int64_t R, real* __restrict__ grad,
@@ -1236,15 +1238,12 @@ __global__ __launch_bounds__(64 * WFIN_GROUPS) void mlpw_finish_kernel(
       grad[p] = g0;
       sq = g0 * g0;
       if (ad.param) {
-        const real w = ad.param[p];
-        const real gg = ad.wd != real(0) ? g0 + ad.wd * w : g0;
-        const real mi = ad.b1 * ad.m[p] + (real(1) - ad.b1) * gg;
-        const real vi = ad.b2 * ad.v[p] + (real(1) - ad.b2) * gg * gg;
+        real w = ad.param[p], mi = ad.m[p], vi = ad.v[p], step_size, bc2s;
+        adam_coef(ad.lr, ad.b1, ad.b2, ad.step, step_size, bc2s);
+        adam_elem(g0, w, mi, vi, ad.b1, ad.b2, ad.eps, ad.wd, step_size, bc2s);
         ad.m[p] = mi;
         ad.v[p] = vi;
-        const real bc1 = real(1) - pow(ad.b1, ad.step);
-        const real bc2s = sqrt(real(1) - pow(ad.b2, ad.step));
-        ad.param[p] = w - (ad.lr / bc1) * mi / (sqrt(vi) / bc2s + ad.eps);
+        ad.param[p] = w;
       }
     } else {
       stats[0] = g0 / (real)R;

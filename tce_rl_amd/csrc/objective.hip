@@ -12,6 +12,7 @@
 // one workgroup for the K x K parts (fp64 in LDS, smallmat.h).
 #include "smallmat.h"
 #include "lanevec.h"
+#include "xchg.h"
 #include "../../include/tce_hip.h"
 
 namespace {
@@ -337,12 +338,12 @@ __global__ __launch_bounds__(256) void obj_ent_only_kernel(real* __restrict__ g,
 // out[0] = |g|_2 over n elements (one workgroup; fixed order)
 template <typename real>
 __global__ __launch_bounds__(1024) void obj_norm_kernel(const real* __restrict__ g, int64_t n,
-                                                        real* __restrict__ out) {
+                                                        real* __restrict__ out, real scale) {
   __shared__ double red[16];
   double sq = 0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) sq += (double)g[i] * (double)g[i];
   sq = block_sum(sq, red);
-  if (threadIdx.x == 0) out[0] = (real)sqrt(sq);
+  if (threadIdx.x == 0) out[0] = (real)sqrt(sq) * scale;
 }
 // a[i] += b[i] (+ c[i])
 template <typename real>
@@ -868,13 +869,25 @@ __global__ __launch_bounds__(64) void policy_record_kernel(const real* __restric
 // writes the state vector and the record row -- a workgroup that starts late
 // must not see the new count.  gL_p == nullptr: g_L is complete (balance epochs).
 constexpr int PT_BT = 1024, PT_MAX_BLOCKS = 32;
+// Who applies what: the mean net's part [0, PN) is split over the workgroups.
+// The head's part [PN, n) -- whose gradient every workgroup forms from the
+// variance PARAMETERS (sigmoid of var) for the norm -- is applied by the LAST
+// workgroup to finish, i.e. after every workgroup has read var: a workgroup
+// that starts late (the grid is spread over 8 XCDs beside the critic's
+// persistent grid) never sees parameters this launch has already written.
+// Sharded run (xchg_on(X); clip == 0, the caller's condition): every workgroup
+// publishes its slice of the local gradient, waits for the peers' same
+// workgroup and adds their values in rank order before Adam (csrc/xchg.h);
+// only workgroup 0 reads var and owns the head's part; |g| of the summed
+// gradient comes from per-workgroup partial sums added in workgroup order by the
+// last one.
 template <typename real>
 __global__ __launch_bounds__(PT_BT) void policy_tail_kernel(
     real* __restrict__ param, real* __restrict__ grad, real* __restrict__ m, real* __restrict__ v,
     int64_t PN, int nvec, int K, const real* __restrict__ g_L, const real* __restrict__ gL_p,
     real* __restrict__ state, unsigned* __restrict__ ticket, const real* __restrict__ sur2,
     const real* __restrict__ out16, real ent_coef, real* __restrict__ row19, real lr, real b1,
-    real b2, real eps, real wd, real clip, real gscale) {
+    real b2, real eps, real wd, real clip, real gscale, XchgView X, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char pt_smem[];
   real* gv = reinterpret_cast<real*>(pt_smem);               // [nvec] the head's gradient
   __shared__ real red[16];
@@ -882,57 +895,88 @@ __global__ __launch_bounds__(PT_BT) void policy_tail_kernel(
   const int tid = threadIdx.x;
   const real* var = param + PN;
   const real step = state[0] + real(1);
+  const bool shard = xchg_on(X);
   // ---- Cholesky head backward (chol_build_bwd_kernel) of g_L (+ gL_p)
-  for (int i = tid; i < nvec; i += PT_BT) {
-    int idx;
-    real sig = 1;
-    if (i < K) {
-      idx = i * K + i;
-      const real x = var[i];
-      sig = x > real(20) ? real(1) : real(1) / (real(1) + exp(-x));
-    } else {
-      const int t = i - K;
-      int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
-      while (r * (r - 1) / 2 > t) --r;
-      while ((r + 1) * r / 2 <= t) ++r;
-      idx = r * K + (t - r * (r - 1) / 2);
+  if (!shard || blockIdx.x == 0) {
+    for (int i = tid; i < nvec; i += PT_BT) {
+      int idx;
+      real sig = 1;
+      if (i < K) {
+        idx = i * K + i;
+        const real x = var[i];
+        sig = x > real(20) ? real(1) : real(1) / (real(1) + exp(-x));
+      } else {
+        const int t = i - K;
+        int r = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+        while (r * (r - 1) / 2 > t) --r;
+        while ((r + 1) * r / 2 <= t) ++r;
+        idx = r * K + (t - r * (r - 1) / 2);
+      }
+      real g = g_L[idx];
+      if (gL_p) g += gL_p[idx];
+      gv[i] = i < K ? g * sig : g;
     }
-    real g = g_L[idx];
-    if (gL_p) g += gL_p[idx];
-    gv[i] = i < K ? g * sig : g;
   }
   __syncthreads();
-  // ---- |g|^2 over the flat gradient (adam_prep_kernel's order)
   const int64_t n = PN + nvec;
-  real sq = 0;
-  for (int64_t i = tid; i < n; i += PT_BT) {
-    const real g = i < PN ? grad[i] : gv[i - PN];
-    sq += g * g;
+  real step_size, bc2s;
+  adam_coef(lr, b1, b2, step, step_size, bc2s);
+  const int64_t per = (PN + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = blockIdx.x * per, i1 = tmin<int64_t>(PN, i0 + per);
+  real before, coef = 1, cg = gscale;
+  if (!shard) {
+    // ---- |g|^2 over the flat gradient (adam_prep_kernel's order)
+    real sq = 0;
+    for (int64_t i = tid; i < n; i += PT_BT) {
+      const real g = i < PN ? grad[i] : gv[i - PN];
+      sq += g * g;
+    }
+    sq = block_sum(sq, red);
+    before = sqrt(sq) * gscale;
+    if (clip > real(0)) coef = tmin(clip / (before + real(1e-6)), real(1));
+    cg = coef * gscale;
+    // ---- this workgroup's slice of the Adam step
+    for (int64_t i = i0 + tid; i < i1; i += PT_BT) {
+      real w = param[i], mi = m[i], vi = v[i];
+      adam_elem(grad[i] * cg, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
+      m[i] = mi;
+      v[i] = vi;
+      param[i] = w;
+    }
+  } else {
+    // ---- publish the local gradient, meet the peers' same workgroup, add
+    for (int64_t i = i0 + tid; i < i1; i += PT_BT) xchg_put<real>(X, i, grad[i]);
+    if (blockIdx.x == 0)
+      for (int i = tid; i < nvec; i += PT_BT) xchg_put<real>(X, PN + i, gv[i]);
+    xchg_sync(X, blockIdx.x);
+    real sq = 0;
+    for (int64_t i = i0 + tid; i < i1; i += PT_BT) {
+      const real g = xchg_get<real>(X, i, grad[i]);
+      grad[i] = g;
+      sq += g * g;
+      real w = param[i], mi = m[i], vi = v[i];
+      adam_elem(g * cg, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
+      m[i] = mi;
+      v[i] = vi;
+      param[i] = w;
+    }
+    if (blockIdx.x == 0)
+      for (int i = tid; i < nvec; i += PT_BT) {
+        const int64_t e = PN + i;
+        const real g = xchg_get<real>(X, e, gv[i]);
+        grad[e] = g;
+        sq += g * g;
+        real w = param[e], mi = m[e], vi = v[e];
+        adam_elem(g * cg, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
+        m[e] = mi;
+        v[e] = vi;
+        param[e] = w;
+      }
+    sq = block_sum(sq, red);
+    if (tid == 0) partial[blockIdx.x] = (double)sq;
+    before = 0;
   }
-  sq = block_sum(sq, red);
-  const real before = sqrt(sq) * gscale;
-  real coef = 1;
-  if (clip > real(0)) coef = tmin(clip / (before + real(1e-6)), real(1));
-  const real cg = coef * gscale;
-  // ---- this workgroup's slice of the Adam step (adam_apply_kernel)
-  const real bc1 = real(1) - pow(b1, step), bc2s = sqrt(real(1) - pow(b2, step));
-  const real step_size = lr / bc1;
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t i0 = blockIdx.x * per, i1 = tmin<int64_t>(n, i0 + per);
-  for (int64_t i = i0 + tid; i < i1; i += PT_BT) {
-    real g0;
-    if (i < PN) g0 = grad[i];
-    else { g0 = gv[i - PN]; grad[i] = g0; }                  // (the flat buffer keeps the head's part)
-    real g = g0 * cg;
-    const real w = param[i];
-    if (wd != real(0)) g += wd * w;
-    const real mi = b1 * m[i] + (real(1) - b1) * g;
-    const real vi = b2 * v[i] + (real(1) - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    param[i] = w - step_size * mi / (sqrt(vi) / bc2s + eps);
-  }
-  // ---- the last workgroup to get here: state vector, record row
+  // ---- the last workgroup to get here: the head's part, state vector, record row
   __syncthreads();
   if (tid == 0) {
     __threadfence();
@@ -941,6 +985,24 @@ __global__ __launch_bounds__(PT_BT) void policy_tail_kernel(
   }
   __syncthreads();
   if (!last_s) return;
+  __threadfence();
+  if (!shard) {
+    for (int i = tid; i < nvec; i += PT_BT) {
+      const int64_t e = PN + i;
+      const real g0 = gv[i];
+      grad[e] = g0;                                            // (the flat buffer keeps the head's part)
+      real w = param[e], mi = m[e], vi = v[e];
+      adam_elem(g0 * cg, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
+      m[e] = mi;
+      v[e] = vi;
+      param[e] = w;
+    }
+  } else {
+    double tot = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b)
+      tot += __hip_atomic_load(partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    before = (real)sqrt(tot) * gscale;
+  }
   if (tid == 0) {
     state[0] = step;
     state[1] = before;
@@ -975,6 +1037,7 @@ template <> struct EpApi<float> {
   static constexpr auto record = tce_policy_record_f32;
   static constexpr auto pm_fwd = tce_pmlp_forward_f32;
   static constexpr auto pm_bwd = tce_pmlp_backward_f32;
+  static constexpr auto xsum = tce_xchg_allreduce_f32;
 };
 template <> struct EpApi<double> {
   static constexpr auto begin = tce_policy_objective_begin_f64;
@@ -984,11 +1047,12 @@ template <> struct EpApi<double> {
   static constexpr auto record = tce_policy_record_f64;
   static constexpr auto pm_fwd = tce_pmlp_forward_f64;
   static constexpr auto pm_bwd = tce_pmlp_backward_f64;
+  static constexpr auto xsum = tce_xchg_allreduce_f64;
 };
 
 inline int64_t epoch2_ws_len(int64_t N, int K, int H, int64_t nparam) {
   return 2 * obj_up4(N * (int64_t)H) + 2 * obj_up4(N * (int64_t)K) +
-         3 * obj_up4((int64_t)K * K) + 36 + obj_up4(nparam);
+         3 * obj_up4((int64_t)K * K) + 36 + 2 * obj_up4(nparam);
 }
 
 // the fused 128 x 2 float32 kernels (net_kind 0) exist in float32 only
@@ -1031,6 +1095,71 @@ inline int fast_bwd(const double*, int64_t, int64_t, int, int, const double*, co
   return 1;
 }
 
+// |g| of one part of a balance epoch's split gradient (grad [n], head part
+// included).  Sharded: the norm of the MEAN over the ranks' gradients -- the
+// part is copied to `scratch` [n], summed over the exchange there (grad keeps
+// the local part) and its norm scaled by grad_scale = 1 / world.
+template <typename real>
+int balance_norm(const real* grad, int64_t n, real* scratch, void* xchg, real grad_scale,
+                 real* out, hipStream_t st) {
+  typedef EpApi<real> E;
+  const real* src = grad;
+  real scale = 1;
+  if (xchg) {
+    OBJ_HIP_ALWAYS(hipMemcpyAsync(scratch, grad, sizeof(real) * n, hipMemcpyDeviceToDevice, st));
+    OBJ_TRY(E::xsum(xchg, scratch, n, (void*)st));
+    src = scratch;
+    scale = grad_scale;
+  }
+  hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, src, n, out, scale);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+// The end of a policy epoch behind the net's backward: Cholesky head backward,
+// (gradient exchange,) clip, Adam, record row -- ONE launch where the fused tail
+// applies (n <= 2^17; sharded: no clipping), else the separate launches.
+// host_step: the step count including this update (the exchange's stand-alone
+// Adam takes it from the host; the fused tail counts on the device).
+template <typename real>
+int policy_epoch_finish(real* param, real* grad, real* m, real* v, int64_t PN, int nvec, int K,
+                        real* g_L, const real* gL_join, real* opt_state, unsigned* ticket,
+                        const real* sur2, const real* out16, real ent_coef, real* rec_row19,
+                        real lr, real beta1, real beta2, real eps, real weight_decay,
+                        real clip_grad, real grad_scale, int do_adam, void* xchg, void* stream) {
+  typedef EpApi<real> E;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = PN + nvec;
+  real* var = param + PN;
+  real* g_var = grad + PN;
+  const bool fused = do_adam && g_policy_tail_fused && n <= (1 << 17) &&
+                     (!xchg || clip_grad <= real(0));
+  if (fused) {
+    const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 4 * PT_BT), PT_MAX_BLOCKS);
+    XchgView X;
+    if (xchg_next(xchg, n * (int64_t)sizeof(real), (int)grid, &X)) return 1;
+    hipLaunchKernelGGL(policy_tail_kernel<real>, dim3(grid), dim3(PT_BT),
+                       sizeof(real) * (size_t)nvec, st, param, grad, m, v, PN, nvec, K,
+                       (const real*)g_L, gL_join, opt_state, ticket, sur2, out16, ent_coef,
+                       rec_row19, lr, beta1, beta2, eps, weight_decay, clip_grad, grad_scale, X,
+                       X.partial);
+    TCE_LAUNCH_CHECK();
+    return 0;
+  }
+  TCE_CHECK_ARG(gL_join == nullptr, "policy_epoch: internal (join pending)");
+  OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
+  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
+  if (xchg) {
+    // (the step count lives on the device in the fused tail; here the exchange's
+    // Adam wants it from the host: not reachable from policy_epoch2's arguments,
+    // so this path counts on the device through tce_adam_flat after a plain sum)
+    OBJ_TRY(E::xsum(xchg, grad, n, stream));
+  }
+  OBJ_TRY(E::adam(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps, weight_decay,
+                  clip_grad, grad_scale, stream));
+  return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+}
+
 template <typename real>
 int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidden, int num_hidden,
                   int net_kind, int act, int nvec, real min_std, real* param, real* grad,
@@ -1045,11 +1174,12 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
                   real* ws, real* partials, real* ol_ws, int T, int P, int dof, int K, real* m,
                   real* v, real* opt_state, real lr, real beta1, real beta2, real eps,
                   real weight_decay, real clip_grad, real grad_scale, int do_adam, int balance,
-                  real* rec_row19, real* bal2, void* stream) {
+                  real* rec_row19, real* bal2, void* xchg, void* stream) {
   typedef EpApi<real> E;
   TCE_CHECK_ARG(x && param && grad && ws && partials && obj_ws && rec_row19 && N > 0 &&
                     K == dof * nbg && K <= 64,
                 "policy_epoch: bad arguments");
+  TCE_CHECK_ARG(!xchg || do_adam, "policy_epoch: an exchange needs do_adam");
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "policy_epoch: optimizer state missing");
   TCE_CHECK_ARG(!balance || bal2, "policy_epoch: balance needs bal2");
   const int H = hidden;
@@ -1076,6 +1206,7 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
   real* stats = out16 + 16;
   unsigned* ticket = reinterpret_cast<unsigned*>(stats + 12);   // policy_tail_kernel (zero between launches)
   real* gtmp = stats + 16;                         // balance: the surrogate's parameter gradient
+  real* gtmp2 = gtmp + obj_up4(n);                 // balance, sharded: a part summed over the ranks
   hipStream_t st = (hipStream_t)stream;
   // net: forward / backward of a gradient w.r.t. the mean
   auto net_fwd = [&]() -> int {
@@ -1102,7 +1233,8 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
                        pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx, tr_coeff,
                        tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, g_mean, g_L, sur2, out16, N,
                        T, P, dof, K, 1, balance ? 3 : 1, stream));
-  const bool fused_tail = do_adam && g_policy_tail_fused && n <= (1 << 17);
+  const bool fused_tail = do_adam && g_policy_tail_fused && n <= (1 << 17) &&
+                          (!xchg || clip_grad <= real(0));
   const real* gL_join = nullptr;                   // fused tail: the half of d / d L still to add
   if (!balance) {
     // ---- backward into the flat gradient
@@ -1129,14 +1261,12 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
     OBJ_TRY(net_bwd(gm_p));
     OBJ_HIP(hipStreamWaitEvent(st, S->ev[4], 0));
     OBJ_TRY(E::chol_bwd(var, gL_p, g_var, 1, K, nvec, stream));
-    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2);
-    TCE_LAUNCH_CHECK();
+    OBJ_TRY(balance_norm<real>(grad, n, gtmp2, xchg, grad_scale, bal2, st));
     OBJ_HIP_ALWAYS(hipMemcpyAsync(gtmp, grad, sizeof(real) * PN, hipMemcpyDeviceToDevice, st));
     // trust region loss alone
     OBJ_TRY(net_bwd(g_mean));
     OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
-    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2 + 1);
-    TCE_LAUNCH_CHECK();
+    OBJ_TRY(balance_norm<real>(grad, n, gtmp2, xchg, grad_scale, bal2 + 1, st));
     // the epoch's gradient: their sum (+ the entropy term's way through the factor)
     hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div(PN, 256)), dim3(256), 0, st,
                        grad, gtmp, (const real*)nullptr, PN);
@@ -1147,21 +1277,9 @@ int policy_epoch2(const real* x, int64_t x_stride, int64_t N, int din, int hidde
                        (int64_t)K * K);
     TCE_LAUNCH_CHECK();
   }
-  if (fused_tail) {
-    const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 4 * PT_BT), PT_MAX_BLOCKS);
-    hipLaunchKernelGGL(policy_tail_kernel<real>, dim3(grid), dim3(PT_BT),
-                       sizeof(real) * (size_t)nvec, st, param, grad, m, v, PN, nvec, K,
-                       (const real*)g_L, gL_join, opt_state, ticket, (const real*)sur2,
-                       (const real*)out16, ent_coef, rec_row19, lr, beta1, beta2, eps,
-                       weight_decay, clip_grad, grad_scale);
-    TCE_LAUNCH_CHECK();
-    return 0;
-  }
-  OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
-  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
-  OBJ_TRY(E::adam(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps, weight_decay,
-                  clip_grad, grad_scale, stream));
-  return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+  return policy_epoch_finish<real>(param, grad, m, v, PN, nvec, K, g_L, gL_join, opt_state, ticket,
+                                   sur2, out16, ent_coef, rec_row19, lr, beta1, beta2, eps,
+                                   weight_decay, clip_grad, grad_scale, do_adam, xchg, stream);
 }
 
 
@@ -1190,9 +1308,10 @@ int bb_policy_epoch(const real* x, int64_t x_stride, int64_t N, int din, int hid
                     real* ws, real* partials, real* ol_ws, int K, real* m, real* v,
                     real* opt_state, real lr, real beta1, real beta2, real eps, real weight_decay,
                     real clip_grad, real grad_scale, int do_adam, int balance, real* rec_row19,
-                    real* bal2, real* proj_mean_out, real* proj_L_out, void* stream) {
+                    real* bal2, real* proj_mean_out, real* proj_L_out, void* xchg, void* stream) {
   typedef EpApi<real> E;
   typedef ObjApi<real> A;
+  TCE_CHECK_ARG(!xchg || do_adam, "bb_policy_epoch: an exchange needs do_adam");
   TCE_CHECK_ARG(x && param && grad && ws && partials && obj_ws && rec_row19 && N > 0 && K > 0 &&
                     K <= 64 && mean_old && L_old && proj_ctx,
                 "bb_policy_epoch: bad arguments");
@@ -1223,6 +1342,7 @@ int bb_policy_epoch(const real* x, int64_t x_stride, int64_t N, int din, int hid
   real* stats = out16 + 16;
   unsigned* ticket = reinterpret_cast<unsigned*>(stats + 12);
   real* gtmp = stats + 16;
+  real* gtmp2 = gtmp + obj_up4(n);
   hipStream_t st = (hipStream_t)stream;
   const bool single = g_obj_streams < 2;
   ObjSide* S = single ? nullptr : obj_side();
@@ -1264,14 +1384,12 @@ int bb_policy_epoch(const real* x, int64_t x_stride, int64_t N, int din, int hid
     // surrogate alone
     OBJ_TRY(net_bwd(gm_p));
     OBJ_TRY(E::chol_bwd(var, gL_p, g_var, 1, K, nvec, stream));
-    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2);
-    TCE_LAUNCH_CHECK();
+    OBJ_TRY(balance_norm<real>(grad, n, gtmp2, xchg, grad_scale, bal2, st));
     OBJ_HIP_ALWAYS(hipMemcpyAsync(gtmp, grad, sizeof(real) * PN, hipMemcpyDeviceToDevice, st));
     // trust region loss alone
     OBJ_TRY(net_bwd(g_mean));
     OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
-    hipLaunchKernelGGL(obj_norm_kernel<real>, dim3(1), dim3(1024), 0, st, grad, n, bal2 + 1);
-    TCE_LAUNCH_CHECK();
+    OBJ_TRY(balance_norm<real>(grad, n, gtmp2, xchg, grad_scale, bal2 + 1, st));
     // the epoch's gradient: their sum (+ the entropy term's way through the factor)
     hipLaunchKernelGGL(obj_add3_kernel<real>, dim3((unsigned)ceil_div(PN, 256)), dim3(256), 0, st,
                        grad, gtmp, (const real*)nullptr, PN);
@@ -1281,21 +1399,10 @@ int bb_policy_epoch(const real* x, int64_t x_stride, int64_t N, int din, int hid
                        KK);
     TCE_LAUNCH_CHECK();
   }
-  if (do_adam && g_policy_tail_fused && n <= (1 << 17)) {
-    const unsigned grid = (unsigned)tmin<int64_t>(ceil_div(n, 4 * PT_BT), PT_MAX_BLOCKS);
-    hipLaunchKernelGGL(policy_tail_kernel<real>, dim3(grid), dim3(PT_BT),
-                       sizeof(real) * (size_t)nvec, st, param, grad, m, v, PN, nvec, K,
-                       (const real*)g_L, (const real*)nullptr, opt_state, ticket,
-                       (const real*)sur2, (const real*)out16, ent_coef, rec_row19, lr, beta1, beta2,
-                       eps, weight_decay, clip_grad, grad_scale);
-    TCE_LAUNCH_CHECK();
-    return 0;
-  }
-  OBJ_TRY(E::chol_bwd(var, g_L, g_var, 1, K, nvec, stream));
-  if (!do_adam) return 0;                         // the caller all-reduces, steps and records
-  OBJ_TRY(E::adam(param, grad, m, v, n, opt_state, nullptr, lr, beta1, beta2, eps, weight_decay,
-                  clip_grad, grad_scale, stream));
-  return E::record(sur2, out16, opt_state + 1, ent_coef, rec_row19, stream);
+  return policy_epoch_finish<real>(param, grad, m, v, PN, nvec, K, g_L, (const real*)nullptr,
+                                   opt_state, ticket, sur2, out16, ent_coef, rec_row19, lr, beta1,
+                                   beta2, eps, weight_decay, clip_grad, grad_scale, do_adam, xchg,
+                                   stream);
 }
 
 }  // namespace
@@ -1468,7 +1575,7 @@ int tce_policy_epoch_f32(
       times_flags_fwd, times_flags_bwd, init_time, init_pos, init_vel, reg, basis_ws, flag_ws,
       pair_work, eps_mean, eps_cov, beta, entropy_eq, proj_ctx, tr_coeff, tr_include_cov, ent_coef,
       sur_ws, kl_ws, obj_ws, ws, partials, ol_ws, T, P, dof, K, m, v, opt_state, lr, beta1, beta2,
-      eps, weight_decay, clip_grad, grad_scale, do_adam, 0, rec_row19, nullptr, stream);
+      eps, weight_decay, clip_grad, grad_scale, do_adam, 0, rec_row19, nullptr, nullptr, stream);
 }
 
 void tce_policy_tail_fused(int on) { g_policy_tail_fused = on; }
@@ -1492,7 +1599,7 @@ int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
       REAL* obj_ws, REAL* ws, REAL* partials, REAL* ol_ws, int T, int P, int dof, int K,     \
       REAL* m, REAL* v, REAL* opt_state, REAL lr, REAL beta1, REAL beta2, REAL eps,          \
       REAL weight_decay, REAL clip_grad, REAL grad_scale, int do_adam, int balance,          \
-      REAL* rec_row19, REAL* bal2, void* stream) {                                           \
+      REAL* rec_row19, REAL* bal2, void* xchg, void* stream) {                               \
     return policy_epoch2<REAL>(                                                              \
         x, x_stride, N, din, hidden, num_hidden, net_kind, act, nvec, min_std, param, grad,  \
         mean_old, L_old, traj, logp_old, adv, pairs, tab, M, nbg, tau, delay, scaled_dt,     \
@@ -1500,7 +1607,7 @@ int64_t tce_policy_epoch2_ws_len(int64_t N, int K, int hidden, int64_t nparam) {
         init_vel, reg, basis_ws, flag_ws, pair_work, eps_mean, eps_cov, beta, entropy_eq,    \
         proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, ws, partials,   \
         ol_ws, T, P, dof, K, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,           \
-        clip_grad, grad_scale, do_adam, balance, rec_row19, bal2, stream);                   \
+        clip_grad, grad_scale, do_adam, balance, rec_row19, bal2, xchg, stream);             \
   }
 DEFINE_POLICY_EPOCH2(f32, float)
 DEFINE_POLICY_EPOCH2(f64, double)
@@ -1515,13 +1622,15 @@ DEFINE_POLICY_EPOCH2(f64, double)
       double* kl_ws, REAL* obj_ws, REAL* ws, REAL* partials, REAL* ol_ws, int K, REAL* m,    \
       REAL* v, REAL* opt_state, REAL lr, REAL beta1, REAL beta2, REAL eps,                   \
       REAL weight_decay, REAL clip_grad, REAL grad_scale, int do_adam, int balance,          \
-      REAL* rec_row19, REAL* bal2, REAL* proj_mean_out, REAL* proj_L_out, void* stream) {    \
+      REAL* rec_row19, REAL* bal2, REAL* proj_mean_out, REAL* proj_L_out, void* xchg,        \
+      void* stream) {                                                                        \
     return bb_policy_epoch<REAL>(                                                            \
         x, x_stride, N, din, hidden, num_hidden, net_kind, act, nvec, min_std, param, grad,  \
         mean_old, L_old, actions, logp_old, adv, eps_mean, eps_cov, beta, entropy_eq,        \
         proj_ctx, tr_coeff, tr_include_cov, ent_coef, sur_ws, kl_ws, obj_ws, ws, partials,   \
         ol_ws, K, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,           \
-        grad_scale, do_adam, balance, rec_row19, bal2, proj_mean_out, proj_L_out, stream);   \
+        grad_scale, do_adam, balance, rec_row19, bal2, proj_mean_out, proj_L_out, xchg,      \
+        stream);                                                                             \
   }
 DEFINE_BB_POLICY_EPOCH(f32, float)
 DEFINE_BB_POLICY_EPOCH(f64, double)

@@ -44,18 +44,15 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(real* __restrict__ p,
                                                          real lr, real b1, real b2, real eps,
                                                          real wd) {
   const real step = state[0], coef = state[3];
-  const real bc1 = real(1) - pow(b1, step), bc2s = sqrt(real(1) - pow(b2, step));
-  const real step_size = lr / bc1;
+  real step_size, bc2s;
+  adam_coef(lr, b1, b2, step, step_size, bc2s);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    real g = grad[i] * coef;
-    const real w = p[i];
-    if (wd != real(0)) g += wd * w;
-    const real mi = b1 * m[i] + (real(1) - b1) * g;
-    const real vi = b2 * v[i] + (real(1) - b2) * g * g;
+    real w = p[i], mi = m[i], vi = v[i];
+    adam_elem(grad[i] * coef, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
     m[i] = mi;
     v[i] = vi;
-    p[i] = w - step_size * mi / (sqrt(vi) / bc2s + eps);
+    p[i] = w;
   }
 }
 
@@ -88,19 +85,16 @@ __global__ __launch_bounds__(ADAM1_BT) void adam_once_kernel(
     if (norms_out) { norms_out[0] = before; norms_out[1] = before * coef; }
   }
   const real cg = coef * gscale;
-  const real bc1 = real(1) - pow(b1, step), bc2s = sqrt(real(1) - pow(b2, step));
-  const real step_size = lr / bc1;
+  real step_size, bc2s;
+  adam_coef(lr, b1, b2, step, step_size, bc2s);
   const int64_t per = (n + gridDim.x - 1) / gridDim.x;
   const int64_t i0 = blockIdx.x * per, i1 = tmin<int64_t>(n, i0 + per);
   for (int64_t i = i0 + threadIdx.x; i < i1; i += ADAM1_BT) {
-    real g = grad[i] * cg;
-    const real w = p[i];
-    if (wd != real(0)) g += wd * w;
-    const real mi = b1 * m[i] + (real(1) - b1) * g;
-    const real vi = b2 * v[i] + (real(1) - b2) * g * g;
+    real w = p[i], mi = m[i], vi = v[i];
+    adam_elem(grad[i] * cg, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
     m[i] = mi;
     v[i] = vi;
-    p[i] = w - step_size * mi / (sqrt(vi) / bc2s + eps);
+    p[i] = w;
   }
 }
 

@@ -45,6 +45,7 @@
 // finish kernel does the projection's backward -- four launches per epoch
 // instead of seven.
 #include "mlp_shared.h"
+#include "xchg.h"
 #include "smallmat.h"
 #include "../../include/tce_hip.h"
 
@@ -1229,15 +1230,12 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void smlp_reduce_kernel(SFinish f)
       f.grad[p] = g0;
       sq = g0 * g0;
       if (f.param) {
-        const float w = f.param[p];
-        float g = g0 * f.gscale;
-        if (f.wd != 0.f) g += f.wd * w;
-        const float mi = f.b1 * f.m[p] + (1.f - f.b1) * g;
-        const float vi = f.b2 * f.v[p] + (1.f - f.b2) * g * g;
+        float w = f.param[p], mi = f.m[p], vi = f.v[p], step_size, bc2s;
+        adam_coef(f.lr, f.b1, f.b2, f.step, step_size, bc2s);
+        adam_elem(g0 * f.gscale, w, mi, vi, f.b1, f.b2, f.eps, f.wd, step_size, bc2s);
         f.m[p] = mi;
         f.v[p] = vi;
-        const float bc1 = 1.f - powf(f.b1, f.step), bc2s = sqrtf(1.f - powf(f.b2, f.step));
-        f.param[p] = w - (f.lr / bc1) * mi / (sqrtf(vi) / bc2s + f.eps);
+        f.param[p] = w;
       }
     } else {
       f.extra[p - f.P] = g0;
@@ -1435,7 +1433,7 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
     // next_fwd (diagonal factors, behind the Adam step): bb_diag_fwd_body of the NEXT epoch
     int next_fwd, float min_std, double eps_cov, float* __restrict__ L_new_w,
     float* __restrict__ L_proj_w, float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w,
-    double* __restrict__ dctx_w) {
+    double* __restrict__ dctx_w, XchgView X) {
   __shared__ float red[SNW];
   __shared__ float coef_s, step_s;
   __shared__ double gsh[64];
@@ -1502,6 +1500,13 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
   }
   __syncthreads();
   const int n = P + nvec;
+  if (xchg_on(X) && do_adam) {
+    // env shards: the peers' gradients in rank order (one workgroup, one flag)
+    for (int p = tid; p < n; p += SBT) xchg_put<float>(X, p, grad[p]);
+    xchg_sync(X, 0);
+    for (int p = tid; p < n; p += SBT) grad[p] = xchg_get<float>(X, p, grad[p]);
+    __syncthreads();
+  }
   float sq = 0.f;
   for (int p = tid; p < n; p += SBT) sq += grad[p] * grad[p];
   sq = block_sum(sq, red);
@@ -1544,17 +1549,14 @@ __global__ __launch_bounds__(SBT) void bb_policy_finish_kernel(
   __syncthreads();
   if (!do_adam) return;
   const float step = step_s, coef = coef_s;
-  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
-  const float step_size = lr / bc1;
+  float step_size, bc2s;
+  adam_coef(lr, b1, b2, step, step_size, bc2s);
   for (int p = tid; p < n; p += SBT) {
-    float gr = grad[p] * coef;
-    const float w = param[p];
-    if (wd != 0.f) gr += wd * w;
-    const float mi = b1 * m[p] + (1.f - b1) * gr;
-    const float vi = b2 * v[p] + (1.f - b2) * gr * gr;
+    float w = param[p], mi = m[p], vi = v[p];
+    adam_elem(grad[p] * coef, w, mi, vi, b1, b2, eps, wd, step_size, bc2s);
     m[p] = mi;
     v[p] = vi;
-    param[p] = w - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    param[p] = w;
   }
   if (next_fwd) {
     // the next epoch's head / projection from the parameters just written (same
@@ -1600,7 +1602,8 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     float* __restrict__ state, float lr, float b1, float b2, float eps, float wd, float clip_grad,
     float gscale, float* __restrict__ out16, float* __restrict__ rec, int rec_kl, int next_fwd,
     float min_std, double eps_cov, float* __restrict__ L_new_w, float* __restrict__ L_proj_w,
-    float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w, double* __restrict__ dctx_w) {
+    float* __restrict__ Li_proj_w, float* __restrict__ gL_tr_w, double* __restrict__ dctx_w,
+    XchgView X) {
   __shared__ float red[SNW];
   __shared__ float coef_s;
   const int tid = threadIdx.x;
@@ -1669,6 +1672,27 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
       grad[P + tid] = gvar;
     }
   }
+  // ---- env shards: the peers' gradients in rank order (one workgroup, one flag)
+  if (xchg_on(X)) {
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int p = tid + q * SBT;
+      if (p < P) xchg_put<float>(X, p, gr[q]);
+    }
+    if (w0 && live) xchg_put<float>(X, P + tid, gvar);
+    xchg_sync(X, 0);
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int p = tid + q * SBT, pc = p < P ? p : P - 1;
+      const float sum = xchg_get<float>(X, pc, gr[q]);
+      gr[q] = p < P ? sum : 0.f;
+      if (p < P) grad[p] = sum;
+    }
+    if (w0 && live) {
+      gvar = xchg_get<float>(X, P + tid, gvar);
+      grad[P + tid] = gvar;
+    }
+  }
   // ---- global norm, clip factor
   float sq = gvar * gvar;
 #pragma unroll
@@ -1711,16 +1735,13 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
     }
   }
   // ---- Adam on the registers
-  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
-  const float step_size = lr / bc1;
+  float step_size, bc2s;
+  adam_coef(lr, b1, b2, step, step_size, bc2s);
 #pragma unroll
   for (int q = 0; q < NPT; ++q) {
     const int p = tid + q * SBT;
-    float g = gr[q] * coef;
-    if (wd != 0.f) g += wd * pw[q];
-    const float mi = b1 * pm[q] + (1.f - b1) * g;
-    const float vi = b2 * pv[q] + (1.f - b2) * g * g;
-    const float wn = pw[q] - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    float wn = pw[q], mi = pm[q], vi = pv[q];
+    adam_elem(gr[q] * coef, wn, mi, vi, b1, b2, eps, wd, step_size, bc2s);
     if (p < P) {
       param[p] = wn;
       m[p] = mi;
@@ -1730,11 +1751,7 @@ __global__ __launch_bounds__(SBT) void bb_diag_finish_kernel(
   if (!w0) return;
   float var_n = var;
   if (live) {
-    float g = gvar * coef;
-    if (wd != 0.f) g += wd * var;
-    mv = b1 * mv + (1.f - b1) * g;
-    vv = b2 * vv + (1.f - b2) * g * g;
-    var_n = var - step_size * mv / (sqrtf(vv) / bc2s + eps);
+    adam_elem(gvar * coef, var_n, mv, vv, b1, b2, eps, wd, step_size, bc2s);
     param[P + tid] = var_n;
     m[P + tid] = mv;
     v[P + tid] = vv;
@@ -2034,9 +2051,11 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
                                float clip_critic, float* param, float* grad, float* m, float* v,
                                float* opt_state, float lr, float beta1, float beta2, float eps,
                                float weight_decay, float clip_grad, float grad_scale, int do_adam,
-                               int first_step, int epochs, float* ws, float* rec, void* stream) {
+                               int first_step, int epochs, float* ws, float* rec, void* xchg,
+                               void* stream) {
   TCE_CHECK_ARG(x && returns && param && grad && ws && rec && N > 0 && epochs > 0,
                 "smlp_critic_epochs: null buffer / empty batch");
+  TCE_CHECK_ARG(!xchg || do_adam, "smlp_critic_epochs: an exchange needs the Adam step");
   TCE_CHECK_ARG(!(clip_critic > 0.f) || old_values, "smlp_critic_epochs: old values missing");
   TCE_CHECK_ARG(!do_adam || (m && v && opt_state), "smlp_critic_epochs: optimizer state missing");
   TCE_CHECK_ARG(tce_smlp_supported(din, H, 1, HEAD_VALUE), "smlp_critic_epochs: unsupported shape");
@@ -2049,8 +2068,11 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
   s_reduce_ws(ws, N, din, H, 1, rd);
   const int g = s_grid(N);
   double* dsum = rd.dpart + (int64_t)g * 8;
-  // the Adam step rides on the slab reduction unless the clip factor needs the norm first
-  const bool fuse = do_adam && !(clip_grad > 0.f);
+  // the Adam step rides on the slab reduction unless the clip factor needs the norm
+  // first -- or the envs are sharded: the reduction grid is tens of workgroups, and
+  // workgroups that wait for a peer must be few (csrc/mlp_shared.h); the exchange +
+  // Adam follow as one small launch
+  const bool fuse = do_adam && !(clip_grad > 0.f) && !xchg;
   for (int e = 0; e < epochs; ++e) {
     int rc = s_dispatch_value(H, act, n, vh, rd, st);
     if (rc) return rc;
@@ -2064,7 +2086,13 @@ int tce_smlp_critic_epochs_f32(const float* x, int64_t x_stride, const float* re
     }
     rc = s_launch_reduce(f, st);
     if (rc) return rc;
-    if (do_adam && !fuse) {
+    if (do_adam && xchg) {
+      // rec row: {mean loss (local), |g| of the rank-averaged gradient, the same clipped}
+      rc = tce_xchg_adam_f32(xchg, param, grad, m, v, rd.P, opt_state, rec + 3 * e + 1,
+                             (float)(first_step + e), lr, beta1, beta2, eps, weight_decay,
+                             clip_grad, grad_scale, stream);
+      if (rc) return rc;
+    } else if (do_adam && !fuse) {
       rc = tce_adam_flat_f32(param, grad, m, v, rd.P, opt_state, rec + 3 * e + 1, lr, beta1, beta2,
                              eps, weight_decay, clip_grad, grad_scale, stream);
       if (rc) return rc;
@@ -2088,7 +2116,8 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                              float grad_scale, int do_adam, int diag, int epochs,
                              double* proj_ctx, float* ws, float* mats, float* rec,
                              int rec_stride, float* mean_new_out, float* proj_mean_out,
-                             void* stream) {
+                             void* xchg, void* stream) {
+  TCE_CHECK_ARG(!xchg || do_adam, "bb_policy_epochs: an exchange needs the Adam step");
   TCE_CHECK_ARG(rec_stride == 7 || rec_stride >= 19,
                 "bb_policy_epochs: rec_stride is 7 (losses / norms) or >= 19 (+ 12 KL means)");
   const int rec_kl = rec_stride >= 19;
@@ -2174,11 +2203,13 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                          tr_include_cov, ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2,
                          eps, weight_decay, clip_grad, grad_scale, do_adam, out16,
                          rec + (int64_t)rec_stride * e, 0, 0, 0.f, 0.0, nullptr, nullptr, nullptr,
-                         nullptr, nullptr);
+                         nullptr, nullptr, xchg_none());
       TCE_LAUNCH_CHECK();
       rc = tce_kl_cov_proj_bwd_f32(L_new, L_old, 0, L_proj, proj_ctx, g_pL, gL_p, 1, K, stream);
       if (rc) return rc;
     }
+    XchgView X;                                      // the epoch's gradient exchange (env shards)
+    if (xchg_next(do_adam ? xchg : nullptr, (int64_t)(P + nvec) * 4, 1, &X)) return 1;
     if (diag && do_adam && P <= SBT * FD_NPT && !g_bb_finish_general) {
       const int npt = (P + SBT - 1) / SBT;
 #define FD_LAUNCH(NN)                                                                             \
@@ -2187,7 +2218,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                      grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay, clip_grad,       \
                      grad_scale, out16, rec + (int64_t)rec_stride * e, rec_kl ? rec_stride : 0,   \
                      chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr, \
-                     proj_ctx)
+                     proj_ctx, X)
       if (npt <= 4) FD_LAUNCH(4);
       else if (npt <= 8) FD_LAUNCH(8);
       else if (npt <= 12) FD_LAUNCH(12);
@@ -2201,7 +2232,7 @@ int tce_bb_policy_epochs_f32(const float* x, int64_t x_stride, const float* acti
                        ent_coef, param, grad, m, v, opt_state, lr, beta1, beta2, eps, weight_decay,
                        clip_grad, grad_scale, do_adam, out16, rec + (int64_t)rec_stride * e, rec_kl,
                        chained && !lastep ? 1 : 0, min_std, eps_cov, L_new, L_proj, Li_proj, gL_tr,
-                       proj_ctx);
+                       proj_ctx, X);
     TCE_LAUNCH_CHECK();
   }
   return 0;

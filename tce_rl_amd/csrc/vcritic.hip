@@ -75,11 +75,13 @@ template <> struct VcApi<float> {
   static constexpr auto fwd = tce_pmlp_forward_f32;
   static constexpr auto bwd = tce_pmlp_backward_f32;
   static constexpr auto adam_once = tce_adam_once_f32;
+  static constexpr auto xadam = tce_xchg_adam_f32;
 };
 template <> struct VcApi<double> {
   static constexpr auto fwd = tce_pmlp_forward_f64;
   static constexpr auto bwd = tce_pmlp_backward_f64;
   static constexpr auto adam_once = tce_adam_once_f64;
+  static constexpr auto xadam = tce_xchg_adam_f64;
 };
 
 inline int64_t vc_up4(int64_t n) { return (n + 3) / 4 * 4; }
@@ -89,8 +91,9 @@ int critic_epoch(const real* x, int64_t x_stride, const real* returns, const rea
                  int64_t N, int din, int H, int NL, int act, real clip_critic, real* param,
                  real* grad, real* m, real* v, real* opt_state, real lr, real beta1, real beta2,
                  real eps, real weight_decay, real clip_grad, real grad_scale, int do_adam,
-                 real step, real* ws, real* partials, real* rec_row3, void* stream) {
+                 real step, real* ws, real* partials, real* rec_row3, void* xchg, void* stream) {
   typedef VcApi<real> A;
+  TCE_CHECK_ARG(!xchg || do_adam, "pmlp_critic_epoch: an exchange needs the Adam step");
   TCE_CHECK_ARG(x && returns && param && grad && ws && partials && rec_row3 && N > 0,
                 "pmlp_critic_epoch: null buffer / no rows");
   TCE_CHECK_ARG(clip_critic <= real(0) || old_values,
@@ -118,6 +121,9 @@ int critic_epoch(const real* x, int64_t x_stride, const real* returns, const rea
   rc = A::bwd(x, x_stride, N, din, H, NL, 1, act, param, h1, NL == 2 ? h2 : nullptr, g, partials,
               grad, stream);
   if (rc || !do_adam) return rc;
+  if (xchg)       // env shards: the peers' gradients are added inside the Adam launch
+    return A::xadam(xchg, param, grad, m, v, P, opt_state, rec_row3 + 1, step, lr, beta1, beta2,
+                    eps, weight_decay, clip_grad, grad_scale, stream);
   return A::adam_once(param, grad, m, v, P, opt_state, rec_row3 + 1, step, lr, beta1, beta2, eps,
                       weight_decay, clip_grad, grad_scale, stream);
 }
@@ -137,11 +143,11 @@ int tce_pmlp_critic_epoch_f32(const float* x, int64_t x_stride, const float* ret
                               float* m, float* v, float* opt_state, float lr, float beta1,
                               float beta2, float eps, float weight_decay, float clip_grad,
                               float grad_scale, int do_adam, float step, float* ws,
-                              float* partials, float* rec_row3, void* stream) {
+                              float* partials, float* rec_row3, void* xchg, void* stream) {
   return critic_epoch<float>(x, x_stride, returns, old_values, N, din, hidden, num_hidden, act,
                              clip_critic, param, grad, m, v, opt_state, lr, beta1, beta2, eps,
                              weight_decay, clip_grad, grad_scale, do_adam, step, ws, partials,
-                             rec_row3, stream);
+                             rec_row3, xchg, stream);
 }
 int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* returns,
                               const double* old_values, int64_t N, int din, int hidden,
@@ -149,11 +155,12 @@ int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* r
                               double* grad, double* m, double* v, double* opt_state, double lr,
                               double beta1, double beta2, double eps, double weight_decay,
                               double clip_grad, double grad_scale, int do_adam, double step,
-                              double* ws, double* partials, double* rec_row3, void* stream) {
+                              double* ws, double* partials, double* rec_row3, void* xchg,
+                              void* stream) {
   return critic_epoch<double>(x, x_stride, returns, old_values, N, din, hidden, num_hidden, act,
                               clip_critic, param, grad, m, v, opt_state, lr, beta1, beta2, eps,
                               weight_decay, clip_grad, grad_scale, do_adam, step, ws, partials,
-                              rec_row3, stream);
+                              rec_row3, xchg, stream);
 }
 
 }  // extern "C"

@@ -11,8 +11,19 @@ this is the new exchange step of the sharded path:
 
 Messages are tiny (<= ~300 KB): latency-bound, so exactly one collective per
 step on one flat buffer.
+
+The gradient exchange itself lives in the library (``Exchange`` below,
+csrc/xchg.h): the kernels that finish an epoch publish their gradient in a
+peer-visible buffer, add the peers' values over xGMI in rank order and apply
+Adam -- a sharded epoch stays ONE C call, as the un-sharded one.  The
+``torch.distributed`` all-reduce between two C calls remains selectable
+(``TCE_EXCHANGE=rccl``) and is what a job falls back to -- loudly -- when the
+ranks do not share a node or the start-up self-test of the exchange fails.
 """
+import ctypes
 import os
+import warnings
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -22,9 +33,20 @@ import torch.distributed as dist
 # bytes): bench.py reports them per step so that a reader of the scaling curve
 # can see what the wire carried.
 STATS = {"collectives": 0, "bytes": 0}
+_LIVE = weakref.WeakSet()           # the Exchange objects of this process
+
+
+def stats():
+    """Collectives issued by this process since the last reset: the
+    torch.distributed ones counted here plus those the library issued inside
+    its kernels (every live Exchange's counters)."""
+    for x in list(_LIVE):
+        x.drain_counters()
+    return dict(STATS)
 
 
 def reset_stats():
+    stats()
     STATS["collectives"] = STATS["bytes"] = 0
 
 
@@ -48,6 +70,162 @@ def broadcast(t, src=0, group=None):
     dist.broadcast(t, src=src, group=group)
 
 
+class Exchange:
+    """This rank's end of a one-shot in-library exchange (include/tce_hip.h:
+    tce_xchg_*).  ``handle`` is what the ``xchg`` argument of the epoch calls
+    takes.  Every rank must issue the same collectives on it, from one
+    stream."""
+
+    def __init__(self, rank, world, max_bytes):
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.max_bytes = rank, world, int(max_bytes)
+        h = ctypes.c_void_p()
+        if self._lib.tce_xchg_create(rank, world, self.max_bytes,
+                                     ctypes.byref(h)):
+            raise RuntimeError("tce_xchg_create: " +
+                               self._lib.tce_last_error().decode())
+        self.handle = h.value
+        self._counted = (0, 0)
+        _LIVE.add(self)
+
+    def export(self):
+        buf = ctypes.create_string_buffer(self._lib.tce_xchg_handle_bytes())
+        self._call("tce_xchg_export", self.handle, buf)
+        return buf.raw
+
+    def connect(self, handles):
+        """handles: the ``export()`` of every rank, in rank order."""
+        assert len(handles) == self.world
+        self._call("tce_xchg_connect", self.handle, b"".join(handles))
+
+    def connect_local(self, peer):
+        """A peer rank that lives in this process (tests)."""
+        self._call("tce_xchg_connect_local", self.handle, peer.rank,
+                   peer.handle)
+
+    def _call(self, name, *args):
+        if getattr(self._lib, name)(*args):
+            raise RuntimeError("%s: %s" % (
+                name, self._lib.tce_last_error().decode()))
+
+    def allreduce(self, t):
+        """In-place sum over ranks (rank order) of a contiguous device tensor."""
+        from ._lib import sfx, stream
+        assert t.is_contiguous() and t.is_cuda
+        self._call("tce_xchg_allreduce_" + sfx(t.dtype), self.handle,
+                   t.data_ptr(), t.numel(), stream())
+
+    def status(self):
+        return int(self._lib.tce_xchg_status(self.handle))
+
+    def check(self):
+        """Raise if a wait for a peer ran into the limit (the kernels go on
+        instead of hanging; what they computed since is not to be used)."""
+        st = self.status()
+        if st:
+            raise RuntimeError(
+                "gradient exchange: rank %d waited longer than the limit "
+                "(TCE_XCHG_TIMEOUT_MS) for rank %d -- a peer died or fell out "
+                "of step" % (self.rank, st - 1))
+
+    def counters(self):
+        n, b = ctypes.c_int64(), ctypes.c_int64()
+        self._call("tce_xchg_counters", self.handle, ctypes.byref(n),
+                   ctypes.byref(b))
+        return n.value, b.value
+
+    def drain_counters(self):
+        """Add the collectives issued since the last call to STATS."""
+        if not self.handle:
+            return
+        n, b = self.counters()
+        STATS["collectives"] += n - self._counted[0]
+        STATS["bytes"] += b - self._counted[1]
+        self._counted = (n, b)
+
+    def set_timeout_ms(self, ms):
+        self._call("tce_xchg_set_timeout_ms", self.handle, float(ms))
+
+    def close(self):
+        if self.handle:
+            self._lib.tce_xchg_destroy(self.handle)
+            self.handle = None
+
+    @classmethod
+    def over_group(cls, max_bytes, group=None):
+        """Collective: every rank of `group` creates its end, the IPC handles
+        travel through an all-gather, and a self-test (three all-reduces of
+        known integers, checked on every rank, agreed with a MIN all-reduce)
+        decides whether the exchange is used.  Returns None -- on EVERY rank --
+        when the ranks span hosts or the test fails."""
+        import socket
+        import torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if world > 8:
+            return None
+        x = cls(rank, world, max_bytes)
+        ok = True
+        if world > 1:
+            mine = (socket.gethostname(), x.export())
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine, group=group)
+            ok = all(h == mine[0] for h, _ in everyone)
+            if ok:
+                try:
+                    x.connect([b for _, b in everyone])
+                except RuntimeError as e:
+                    warnings.warn("gradient exchange: mapping the peers failed "
+                                  "(%s)" % e)
+                    ok = False
+            ok = _agree(ok, group)
+            if ok:
+                ok = _agree(x._self_test(), group)
+        if not ok:
+            if world > 1 and rank == 0:
+                warnings.warn(
+                    "gradient exchange: the in-library xGMI exchange is not "
+                    "usable on this job (ranks on several hosts, IPC mapping "
+                    "or self-test failed); falling back to "
+                    "torch.distributed all-reduces between the C calls")
+            x.close()
+            return None
+        return x
+
+    def _self_test(self):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        good = True
+        for dtype in (torch.float32, torch.float64):
+            cap = self.max_bytes // (4 if dtype == torch.float32 else 8)
+            for n in (1, min(cap, 4097), min(cap, 70001)):
+                base = (torch.arange(n, device=dev) % 1021).to(dtype)
+                t = base * (self.rank + 1)
+                self.allreduce(t)
+                want = base * (self.world * (self.world + 1) // 2)
+                good = good and bool(torch.equal(t, want))
+        torch.cuda.synchronize()
+        return good and self.status() == 0
+
+
+def _agree(flag, group=None):
+    """True on every rank iff `flag` is true on every rank."""
+    import torch
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
+def exchange_wanted():
+    """TCE_EXCHANGE: "xgmi" (default: the in-library one-shot exchange) or
+    "rccl" (torch.distributed all-reduces between the C calls)."""
+    mode = os.environ.get("TCE_EXCHANGE", "xgmi").lower()
+    if mode not in ("xgmi", "rccl"):
+        raise ValueError("TCE_EXCHANGE=%r (xgmi | rccl)" % mode)
+    return mode == "xgmi"
+
+
 def active(group=None):
     """True when the sharded code path (collectives included) is to be taken:
     a process group of more than one rank, or -- TCE_FORCE_DIST=1 -- any
@@ -68,6 +246,36 @@ class DistContext:
         self.active = active(group)
         self._flat = {}
         self._aux_group = None
+        self._exchanges = {}
+
+    def exchange(self, channel, max_bytes):
+        """The in-library exchange of one update chain ("critic" / "policy";
+        two chains run on two streams, so each has its own).  Collective on
+        first use; None when the torch.distributed path is to be taken."""
+        if not self.active or not exchange_wanted():
+            return None
+        if channel not in self._exchanges:
+            import torch
+            if not torch.cuda.is_available():
+                self._exchanges[channel] = None
+            else:
+                self._exchanges[channel] = Exchange.over_group(max_bytes,
+                                                               self.group)
+        return self._exchanges[channel]
+
+    def exchange_kind(self):
+        """What carries the gradients: "xgmi-oneshot" | "rccl" | "none"."""
+        if not self.active:
+            return "none"
+        xs = [x for x in self._exchanges.values()]
+        return "xgmi-oneshot" if xs and all(x is not None for x in xs) \
+            else "rccl"
+
+    def check_exchanges(self):
+        for x in self._exchanges.values():
+            if x is not None:
+                x.check()
+                x.drain_counters()
 
     def aux_group(self):
         """A second communicator over the same ranks (collective call: every

@@ -118,6 +118,13 @@ class MPExperiment:
             if self.verbose_level == 1:
                 return {k: v for k, v in result.items()
                         if "exploration" not in k}
+            # the reference's iterate() returns a plain dict that cw2's loggers
+            # json-encode / type-check: hand out the resolved metrics (one wait
+            # for the device) unless the caller opts into the lazy mapping
+            # (cw_config["lazy_result"]: util.LazyMetrics, read on first access)
+            if hasattr(result, "resolve") and not (
+                    cw_config or {}).get("lazy_result", False):
+                return result.resolve()
             return result
         return self.agent.evaluate(render=False)[0]
 

@@ -103,12 +103,29 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.sync_grads()
         self.host_step += 1
+        self._opt_called = True               # for LinearLR's order check
         call("tce_adam_once_" + sfx(self.flat_param.dtype), ptr(self.flat_param),
              ptr(self.flat_grad), ptr(self.m), ptr(self.v), n,
              ptr(self.dev_state), ptr(norms_out), float(self.host_step),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
              float(g["eps"]), float(g["weight_decay"]), float(clip),
              float(grad_scale), stream())
+
+    @torch.no_grad()
+    def step_exchange(self, xchg, clip=0.0, grad_scale=1.0, norms_out=None):
+        """Sum of the flat gradient over the ranks of `xchg` (a dist.Exchange;
+        the sum stays in ``flat_grad``) + ``step_once`` as ONE C call and --
+        without clipping -- ONE launch (tce_xchg_adam_*)."""
+        g = self.param_groups[0]
+        self.sync_grads()
+        self.host_step += 1
+        self._opt_called = True
+        call("tce_xchg_adam_" + sfx(self.flat_param.dtype), xchg.handle,
+             ptr(self.flat_param), ptr(self.flat_grad), ptr(self.m), ptr(self.v),
+             self.flat_param.numel(), ptr(self.dev_state), ptr(norms_out),
+             float(self.host_step), float(g["lr"]), float(g["betas"][0]),
+             float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+             float(clip), float(grad_scale), stream())
 
     def state_dict(self):
         sd = super().state_dict()

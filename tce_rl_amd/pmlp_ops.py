@@ -149,7 +149,11 @@ def critic_update(agent, states, returns, old_values):
     rec = torch.zeros(E, 3, dtype=dt, device=dev)
     g = opt.param_groups[0]
     opt.bind_grads()
-    sharded = agent.dist.active
+    # env shards: the Adam launch adds the peers' gradients (agent.xchg_critic);
+    # without an in-library exchange the call stops in front of the step
+    xch = agent.xchg_critic if agent.dist.active else None
+    sharded = agent.dist.active and xch is None
+    gscale = 1.0 / agent.dist.world if xch is not None else 1.0
     for e in range(E):
         if not sharded:
             opt.host_step += 1
@@ -159,9 +163,9 @@ def critic_update(agent, states, returns, old_values):
              float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
              ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-             float(g["weight_decay"]), float(agent.clip_grad_norm), 1.0,
+             float(g["weight_decay"]), float(agent.clip_grad_norm), gscale,
              int(not sharded), float(opt.host_step), ptr(ws), ptr(partials),
-             ptr(rec[e]), stream())
+             ptr(rec[e]), None if xch is None else xch.handle, stream())
         if sharded:
             # the loss is the shard's own mean (as on the other sharded paths);
             # sum of the shards' gradients, then clip + Adam + the two norms

@@ -53,10 +53,20 @@ class AbstractAgent(ABC):
         self.num_iterations = 0
         self.num_global_steps = 0
         self._policy_group = None
+        # the gradient exchanges of the two update chains (env shards): inside
+        # the library (dist.Exchange, one-shot over xGMI) or -- None -- as
+        # torch.distributed all-reduces between the C calls
+        self.xchg_critic = self.xchg_policy = None
         if self.dist.active:
             self.dist.broadcast_params(self.policy_net_params +
                                        self.critic_net_params)
             self._policy_group = self.dist.aux_group()
+            nbytes = lambda opt: (opt.flat_grad.numel() + 64) * \
+                opt.flat_grad.element_size()
+            self.xchg_critic = self.dist.exchange(
+                "critic", nbytes(self.critic_optimizer))
+            self.xchg_policy = self.dist.exchange(
+                "policy", nbytes(self.policy_optimizer))
 
     def get_optimizer(self, policy, critic):
         """Adam with L2-in-gradient weight decay (abstract_agent.py:62-82)."""
@@ -146,10 +156,22 @@ class AbstractAgent(ABC):
         the envs are sharded over ranks)."""
         if self.dist.active:
             opt.sync_grads()
-            # the policy's exchange has its own communicator (see dist.py)
-            self.dist.allreduce_flat(
-                opt.flat_grad, self._policy_group
-                if opt is self.policy_optimizer else None, average=False)
+            policy = opt is self.policy_optimizer
+            xch = self.xchg_policy if policy else self.xchg_critic
+            if xch is not None and opt.flat_grad.numel() <= (1 << 17):
+                # sum over the shards + clip + Adam: one C call (tce_xchg_adam_*)
+                opt.step_exchange(xch, clip, grad_scale=1.0 / self.dist.world)
+                if not want_norms:
+                    return None                 # the caller reads dev_state[1:3]
+                norms = opt.dev_state[1:3].clone()
+                return norms[0], norms[1]
+            if xch is not None:
+                xch.allreduce(opt.flat_grad)
+            else:
+                # the policy's exchange has its own communicator (see dist.py)
+                self.dist.allreduce_flat(
+                    opt.flat_grad, self._policy_group if policy else None,
+                    average=False)
         if self.dist.active and not want_norms:
             opt.step_once(clip, grad_scale=1.0 / self.dist.world)
             return None                         # the caller reads dev_state[1:3]
@@ -244,23 +266,39 @@ class _CriticEpochs:
         # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
         self.rows = torch.zeros(self.E, 4, dtype=agent.critic.net.dtype,
                                 device=agent.device)
-        self.fuse_adam = not agent.dist.active and \
-            not agent.clip_grad_norm > 0
+        # env shards: the exchange rides in the launch that applies Adam
+        self.xchg = agent.xchg_critic if agent.dist.active else None
+        self.gscale = 1.0 / agent.dist.world if agent.dist.active else 1.0
+        self.fuse_adam = (not agent.dist.active or self.xchg is not None) \
+            and not agent.clip_grad_norm > 0
         self.done = 0
 
     def run(self, n, max_workgroups=0):
         ag, opt, rows = self.agent, self.opt, self.rows
         for e in range(self.done, min(self.E, self.done + n)):
+            fused = self.fuse_adam
             self.runner.epoch(self.x, self.returns, self.old_values,
                               ag.clip_critic, max_workgroups, stats=rows[e],
-                              adam=opt if self.fuse_adam else None)
+                              adam=opt if fused else None,
+                              xchg=self.xchg if fused else None,
+                              grad_scale=self.gscale if fused else 1.0)
             if not self.fuse_adam:
-                if ag.dist.active:
+                if ag.dist.active and self.xchg is not None and \
+                        opt.flat_grad.numel() <= (1 << 17):
+                    # sum over the shards + clip + Adam + the record's norms:
+                    # one C call (tce_xchg_adam_*)
+                    opt.step_exchange(self.xchg, ag.clip_grad_norm,
+                                      grad_scale=self.gscale,
+                                      norms_out=rows[e, 2:4])
+                elif ag.dist.active:
                     # sum over the shards, then clip + Adam + the two norms of
                     # the record in ONE launch (tce_adam_once_*)
-                    ag.dist.allreduce_flat(opt.flat_grad, average=False)
+                    if self.xchg is not None:
+                        self.xchg.allreduce(opt.flat_grad)
+                    else:
+                        ag.dist.allreduce_flat(opt.flat_grad, average=False)
                     opt.step_once(ag.clip_grad_norm,
-                                  grad_scale=1.0 / ag.dist.world,
+                                  grad_scale=self.gscale,
                                   norms_out=rows[e, 2:4])
                 else:                   # |g|^2 comes with the reduction
                     opt.step(ag.clip_grad_norm, sumsq=rows[e, 1:2])
@@ -274,7 +312,8 @@ class _CriticEpochs:
                 "critic_arith=f16x2: the critic loss is not finite -- an "
                 "operand (observation, activation, weight) left the f16 range "
                 "(|x| < 65504); use critic_arith=f32 for this task")
-        if self.fuse_adam:                                   # no clipping
+        if self.fuse_adam and self.xchg is None:             # no clipping
+            # (env shards: the exchange's Adam launch has written both norms)
             host[:, 2] = host[:, 3] = np.sqrt(host[:, 1])
         return {**util.generate_stats(host[:, 0], "critic_loss"),
                 **util.generate_stats(host[:, 2], "critic_grad_norm"),
@@ -362,6 +401,8 @@ class TemporalCorrelatedAgent(AbstractAgent):
         while done and len(done) >= keep:
             ev, metrics = done.pop(0)
             ev.synchronize()
+            # (env shards: a wait for a peer that ran into its limit is fatal)
+            self.dist.check_exchanges()
             metrics.resolve()
 
     def flush_metrics(self):
@@ -465,6 +506,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         if self.schedule_lr_policy:
             self.policy_lr_scheduler.step()
         update_time = util.run_time_test(lock=False, key="update")
+        self.dist.check_exchanges()
 
         result_metrics = {
             **dataset_stats, **critic_loss_dict, **policy_loss_dict,
@@ -883,8 +925,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         use_direct = use_fused and self.direct_policy_epoch and \
             not self.graph_policy_update and \
             objective.DirectEpoch.supported(self, states)
-        if self.check_policy_balance and not (use_direct and
-                                              not self.dist.active):
+        if self.check_policy_balance and not (
+                use_direct and (not self.dist.active
+                                or self.xchg_policy is not None)):
             use_fused = use_direct = False
         fused_ctx = None
         if use_fused:
@@ -1319,6 +1362,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             critic_loss_dict = self.update_critic(dataset)
             policy_loss_dict = self.update_policy(dataset)
         update_time = util.run_time_test(lock=False, key="update")
+        self.dist.check_exchanges()
         result = {**dataset_stats, **critic_loss_dict, **policy_loss_dict,
                   "sampling_time": sampling_time, "update_time": update_time,
                   "num_global_steps": self.num_global_steps,
@@ -1550,8 +1594,8 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 self.num_iterations)
         if beta is not None and not torch.is_tensor(beta):
             beta = torch.as_tensor(float(beta), device=self.device)
-        # (a sharded run has no split epochs: its balance norms are left out)
-        balance = self._balance_iteration() and not self.dist.active
+        # (env shards: the two norms are those of the rank-averaged parts)
+        balance = self._balance_iteration()
         self.check_policy_balance = balance
         rec, mean_new, L_new, proj_mean, proj_L = smlp_ops.policy_update(
             self, states, dataset["segment_action"],
@@ -1584,8 +1628,10 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                   dataset["segment_log_prob"],
                                   dataset["segment_advantage"], beta)
         direct = objective.BBDirectEpoch(self, states, ctx)
-        # (a sharded run has no split epochs: its balance norms are left out)
-        balance = self._balance_iteration() and not self.dist.active
+        # (env shards without the in-library exchange stop the call in front of
+        # the step and cannot split the epoch: their balance norms are left out)
+        balance = self._balance_iteration() and (
+            not self.dist.active or self.xchg_policy is not None)
         self.check_policy_balance = balance
         E, N = self.epochs_policy, states.shape[0]
         # per epoch: 7 loss / norm scalars, 12 KL means, the two balance norms

@@ -314,8 +314,10 @@ class DirectEpoch:
         """One epoch; rec_row [19] receives {surrogate, entropy loss, trust
         region loss, total, entropy, |g|, |g| clipped, 12 KL means}; balance:
         bal [2] receives the gradient norms of the surrogate / trust region
-        loss alone.  A sharded run stops the call in front of the optimizer
-        step, all-reduces the flat gradient, then steps and records."""
+        loss alone.  Env shards: the epoch's last launch adds the peers'
+        gradients (``agent.xchg_policy``) -- still one call; without an
+        in-library exchange the call stops in front of the optimizer step, the
+        flat gradient is all-reduced, then stepped and recorded."""
         c, ag, opt = self.c, self.agent, self.opt
         x, N, K = self.x, self.N, self.K
         mp = c.mp
@@ -326,7 +328,11 @@ class DirectEpoch:
         opt.bind_grads()
         assert rec_row.is_contiguous() and rec_row.numel() == 19
         g = opt.param_groups[0]
-        do_adam = not ag.dist.active
+        # env shards: the gradient exchange rides in the epoch's last launch
+        # (ag.xchg_policy); without it the call stops in front of the step
+        xch = ag.xchg_policy if ag.dist.active else None
+        do_adam = not ag.dist.active or xch is not None
+        gscale = 1.0 / ag.dist.world if xch is not None else 1.0
         assert do_adam or not balance
         if do_adam:
             opt.host_step += 1
@@ -343,8 +349,9 @@ class DirectEpoch:
              ptr(self.partials), ptr(self.ol_ws), T, P, mp.num_dof, K,
              ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-             float(g["weight_decay"]), float(ag.clip_grad_norm), 1.0,
-             int(do_adam), int(balance), ptr(rec_row), ptr(bal), stream())
+             float(g["weight_decay"]), float(ag.clip_grad_norm), gscale,
+             int(do_adam), int(balance), ptr(rec_row), ptr(bal),
+             None if xch is None else xch.handle, stream())
         if not do_adam:
             ag._optimizer_step(opt, ag.policy_net_params, ag.clip_grad_norm,
                                want_norms=False)
@@ -433,7 +440,9 @@ class BBDirectEpoch:
         opt.bind_grads()
         assert rec_row.is_contiguous() and rec_row.numel() == 19
         g = opt.param_groups[0]
-        do_adam = not ag.dist.active
+        xch = ag.xchg_policy if ag.dist.active else None
+        do_adam = not ag.dist.active or xch is not None
+        gscale = 1.0 / ag.dist.world if xch is not None else 1.0
         assert do_adam or not balance
         if do_adam:
             opt.host_step += 1
@@ -448,9 +457,10 @@ class BBDirectEpoch:
              ptr(self.partials), ptr(self.ol_ws), K, ptr(opt.m), ptr(opt.v),
              ptr(opt.dev_state), float(g["lr"]), float(g["betas"][0]),
              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-             float(ag.clip_grad_norm), 1.0, int(do_adam), int(balance),
+             float(ag.clip_grad_norm), gscale, int(do_adam), int(balance),
              ptr(rec_row), ptr(bal), ptr(c.proj_mean) if last else None,
-             ptr(c.proj_L) if last else None, stream())
+             ptr(c.proj_L) if last else None,
+             None if xch is None else xch.handle, stream())
         if not do_adam:
             ag.dist.allreduce_flat(opt.flat_grad, ag._policy_group,
                                    average=False)

@@ -174,6 +174,17 @@ class BlackBoxSampler(AbstractSampler):
         self.task_specified_metrics = kwargs.get("task_specified_metrics", None)
         self.render_test_env = kwargs.get("render_test_env", False)
         self.env_args = kwargs.get("env_args", {}) or {}
+        # "synthetic": the GPU-resident env suite (envs/synthetic.py);
+        # "vec": any SB3-style vec env speaking the reference's protocol
+        # (list of per-env numpy info dicts) behind envs/vec_adapter.py --
+        # vec_env_fn(env_id=, num_env=, seed=, render=, mp_args=) builds it
+        # (a callable or "module:function"; default: the reference's own
+        # make_bb_vec_env over fancy_gym, mprl/util/util_mp.py:144-185)
+        self.env_backend = kwargs.get("env_backend", "synthetic")
+        self.vec_env_fn = kwargs.get("vec_env_fn", None)
+        if self.env_backend not in ("synthetic", "vec"):
+            raise ValueError("env_backend %r (synthetic | vec)"
+                             % (self.env_backend,))
         self.train_envs = self.get_env("training")
         self.test_envs = self.get_env("testing")
         self.debug_env = self.get_env("debugging")
@@ -187,6 +198,16 @@ class BlackBoxSampler(AbstractSampler):
             num_env, seed = 1, self.seed + 20000
         else:
             raise ValueError("Unknown env_type: {}".format(env_type))
+        if self.env_backend == "vec":
+            from ..envs import vec_adapter
+            fn = vec_adapter.resolve_callable(
+                self.vec_env_fn or vec_adapter.make_bb_vec_env)
+            vec = fn(env_id=self.env_id, num_env=num_env, seed=seed,
+                     render=self.render_test_env and env_type == "testing",
+                     mp_args=self.mp_args, **self.env_args)
+            return vec_adapter.VecEnvAdapter(
+                vec, dtype=self.dtype, device=self.device,
+                last_element_keys=self.task_specified_metrics)
         return make_env(self.env_id, num_env, seed, mp_args=self.mp_args,
                         black_box=self.black_box_env, dtype=self.dtype,
                         device=self.device, **self.env_args)

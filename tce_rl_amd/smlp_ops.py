@@ -101,7 +101,7 @@ def critic_update(agent, states, returns, old_values):
     g = opt.param_groups[0]
     opt.bind_grads()
 
-    def launch(epochs, do_adam, rec_rows, scale):
+    def launch(epochs, do_adam, rec_rows, scale, xch=None):
         call("tce_smlp_critic_epochs_f32", ptr(x), x.stride(0), ptr(ret),
              ptr(old), N, net.dim_in, H, _ACT[net.act_func_hidden_type],
              float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
@@ -109,18 +109,24 @@ def critic_update(agent, states, returns, old_values):
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
              float(g["weight_decay"]), float(agent.clip_grad_norm), scale,
              int(do_adam), opt.host_step + 1, epochs, ptr(ws), ptr(rec_rows),
-             stream())
-    if not agent.dist.active:
-        launch(E, True, rec, 1.0)
+             None if xch is None else xch.handle, stream())
+    xch = agent.xchg_critic if agent.dist.active else None
+    if not agent.dist.active or xch is not None:
+        # (env shards: a small launch behind the slab reduction adds the peers'
+        # gradients and applies Adam -- the E epochs stay ONE call)
+        scale = 1.0 / agent.dist.world if xch is not None else 1.0
+        launch(E, True, rec, scale, xch)
         opt.host_step += E
         opt._opt_called = True                # for LinearLR's order check
-        # the kernels leave |g|^2: the two norms of grad_norm_clip from it
-        before = rec[:, 1].sqrt()
-        after = before
-        if agent.clip_grad_norm > 0:
-            after = before * torch.clamp(
-                agent.clip_grad_norm / (before + 1e-6), max=1.0)
-        rec[:, 1], rec[:, 2] = before, after
+        if xch is None:
+            # the kernels leave |g|^2: the two norms of grad_norm_clip from it
+            # (env shards: the exchange's Adam launch has written both norms)
+            before = rec[:, 1].sqrt()
+            after = before
+            if agent.clip_grad_norm > 0:
+                after = before * torch.clamp(
+                    agent.clip_grad_norm / (before + 1e-6), max=1.0)
+            rec[:, 1], rec[:, 2] = before, after
     else:
         for e in range(E):
             launch(1, False, rec[e], 1.0)
@@ -181,6 +187,9 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
     g = opt.param_groups[0]
     opt.bind_grads()
 
+    xch = agent.xchg_policy if agent.dist.active else None
+    gscale = 1.0 / agent.dist.world if xch is not None else 1.0
+
     def launch(epochs, do_adam, rec_rows, adv=adv, tr_coeff=None,
                ent_coef=None, again=False):
         call("tce_bb_policy_epochs_f32", ptr(x), x.stride(0), ptr(actions),
@@ -195,11 +204,22 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
              ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v), ptr(opt.dev_state),
              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
              float(g["eps"]), float(g["weight_decay"]),
-             float(agent.clip_grad_norm), 1.0, int(do_adam),
-             diag | (2 if again else 0), epochs,
+             float(agent.clip_grad_norm), gscale if do_adam else 1.0,
+             int(do_adam), diag | (2 if again else 0), epochs,
              ptr(ctx), ptr(ws), ptr(mats), ptr(rec_rows), 19, ptr(mean_new),
-             ptr(proj_mean), stream())
-    if balance and not agent.dist.active:
+             ptr(proj_mean),
+             None if xch is None or not do_adam else xch.handle, stream())
+
+    def shard_norm(row):
+        """|mean over the ranks of the gradient the last launch left| -> row[5]
+        (a balance norm of a sharded run)."""
+        if xch is not None:
+            xch.allreduce(opt.flat_grad)
+        else:
+            agent.dist.allreduce_flat(opt.flat_grad, agent._policy_group,
+                                      average=False)
+        row[5] = opt.flat_grad.norm() / agent.dist.world
+    if balance:
         # an iteration with the policy balance check (black_box_agent.py:
         # 218-284): before every epoch the parameter-gradient norms of the
         # surrogate loss alone (no trust region / entropy term) and of the trust
@@ -210,12 +230,26 @@ def policy_update(agent, states, actions, logp_old, adv, mean_old, L_old,
         for e in range(E):
             # (again: L_old^-1 stays in `mats` from the update's first call)
             launch(1, False, bal[0, e], tr_coeff=0.0, ent_coef=0.0, again=e > 0)
+            if agent.dist.active:
+                shard_norm(bal[0, e])
             launch(1, False, bal[1, e], adv=zero_adv, ent_coef=0.0, again=True)
-            launch(1, True, rec[e], again=True)
-        opt.host_step += E
+            if agent.dist.active:
+                shard_norm(bal[1, e])
+            if not agent.dist.active or xch is not None:
+                launch(1, True, rec[e], again=True)
+                opt.host_step += 1
+            else:
+                launch(1, False, rec[e], again=True)
+                agent.dist.allreduce_flat(opt.flat_grad, agent._policy_group,
+                                          average=False)
+                opt.step_once(agent.clip_grad_norm,
+                              grad_scale=1.0 / agent.dist.world,
+                              norms_out=rec[e, 5:7])
         opt._opt_called = True
         rec = torch.cat([rec, bal[0, :, 5:6], bal[1, :, 5:6]], dim=1)
-    elif not agent.dist.active:
+    elif not agent.dist.active or xch is not None:
+        # (env shards: the finish kernel adds the peers' gradients before Adam
+        # -- the E epochs stay ONE call)
         launch(E, True, rec)
         opt.host_step += E
         opt._opt_called = True

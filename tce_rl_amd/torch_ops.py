@@ -285,7 +285,7 @@ def critic_values(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
     call("tce_mlp_critic_f32", ptr(x), 0, x.stride(0), R, R, din, ptr(w1),
          ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), _ACT[act], None, None,
          0.0, ptr(out), None, None, None, 0, None, None, None, None, 0.0, 0.0,
-         0.0, 0.0, 0.0, 0.0, stream())
+         0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
     return out
 
 
@@ -463,7 +463,7 @@ def critic_epoch(x: torch.Tensor, returns: torch.Tensor,
          ptr(c(b1)), ptr(c(w2)), ptr(c(b2)), ptr(c(w3)), ptr(c(b3)), _ACT[act],
          ptr(c(returns)), ptr(c(old_values)) if clip > 0 else None,
          float(clip), None, ptr(partials), ptr(grad), ptr(stats), 0, None,
-         None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, stream())
+         None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
     return stats, grad
 
 

@@ -301,8 +301,9 @@ def _rccl_one_rank_worker(port, q):
         flat = torch.cat([p.detach().reshape(-1).cpu() for p in
                           exp.agent.policy.parameters +
                           exp.agent.critic.parameters])
-        out[name] = (dict(tdist.STATS), flat.numpy(),
-                     float(res["critic_loss_mean"]), dist.get_backend())
+        kind = exp.agent.dist.exchange_kind()
+        out[name] = (tdist.stats(), flat.numpy(),
+                     float(res["critic_loss_mean"]), dist.get_backend(), kind)
     q.put(out)
     dist.barrier()
     dist.destroy_process_group()
@@ -351,8 +352,11 @@ def test_sharded_path_through_a_one_rank_rccl_world():
     p.join(timeout=60)
     assert p.exitcode == 0
     for name in ("tce", "bbrl"):
-        stats, flat, loss, backend = got[name]
+        stats, flat, loss, backend, kind = got[name]
         assert backend == "nccl"
+        # the gradients go through the library's own exchange (csrc/xchg.h),
+        # counted like the torch.distributed collectives
+        assert kind == "xgmi-oneshot"
         # 3 + 3 gradient all-reduces per step at least, plus statistics
         assert stats["collectives"] >= 6 and stats["bytes"] > 6 * 4 * 1000
         assert np.isfinite(flat).all() and np.isfinite(loss)

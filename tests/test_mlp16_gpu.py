@@ -99,12 +99,13 @@ def test_split_f16_values_output_and_overflow_is_reported():
     ws = [ptr(p) for p in mlp.parameters()]
     call("tce_mlp_critic_f16x2", ptr(x), 0, 24, 1000, 1000, 24, *ws, 0, ptr(ret),
          None, 0.0, ptr(vals), ptr(partials), ptr(grad), ptr(stats), 0, None,
-         None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, stream())
+         None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
     ref = critic_ops.forward(mlp, x.expand(5, 1000, 24).contiguous())[0, :, 0]
     torch.testing.assert_close(vals, ref, rtol=1e-5, atol=1e-6)
     stats.zero_()
     big = x * 1e6                                   # |x| > 65504
     call("tce_mlp_critic_f16x2", ptr(big), 0, 24, 1000, 1000, 24, *ws, 0,
          ptr(ret), None, 0.0, None, ptr(partials), ptr(grad), ptr(stats), 0,
-         None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, stream())
+         None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None,
+         stream())
     assert not torch.isfinite(stats[0]).item()

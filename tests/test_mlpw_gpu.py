@@ -151,7 +151,7 @@ def test_wide_critic_argument_checks():
     p = lambda t: t.data_ptr()
     base = [p(x), 0, 21, 64, 64, 21, 256, p(w), p(w), p(w), p(w), p(w), p(w), 1,
             None, None, 0.0, p(out), p(ws), None, None, None, 0, None, None,
-            None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0]
+            None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, 0]
     _lib.call("tce_mlpw_critic_f32", *base)
     for idx, bad in ((6, 192), (13, 9), (17, None), (5, 0)):
         args = list(base)
