@@ -108,9 +108,11 @@ def kernel_time_cold_us(fn, launches=5):
     return sorted(ts)[len(ts) // 2]
 
 
-PMC_TAGS = ("r04", "r03", "r02", "r01e", "r01c")
-STATS_CSV = ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv",
-             "r02_bench_kernel_stats.csv")
+PMC_TAGS = ("r05", "r04", "r03", "r02", "r01e", "r01c")
+# (r05: the timed window only -- scripts/profiles_r05.sh, rocpd_stats.py
+# --between-markers 1 2 --by-grid; earlier rounds: the whole run)
+STATS_CSV = ("r05_bench_kernel_stats_by_grid.csv", "r04_bench_kernel_stats.csv",
+             "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv")
 
 
 def pmc_lookup(kernel):
@@ -161,9 +163,15 @@ def profiled_us(kernel_substr):
         try:
             rel = os.path.join("profiles", name)
             with open(os.path.join(REPO, rel)) as f:
+                # (a by-grid summary has one row per workgroup count: the
+                # call-weighted average over them)
+                tot = calls = 0.0
                 for row in csv.DictReader(f):
                     if kernel_substr in row["Name"]:
-                        return round(float(row["AverageNs"]) / 1e3, 1), rel
+                        tot += float(row["TotalDurationNs"])
+                        calls += float(row["Calls"])
+                if calls:
+                    return round(tot / calls / 1e3, 1), rel
         except (OSError, KeyError, ValueError):
             pass
     return None, None
@@ -253,6 +261,12 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
               "mfma_busy_source": mfma_busy("mlp_critic_bwd_kernel")[1],
               "rocprof_us_per_launch": profiled_us("mlp_critic_bwd_kernel")[0],
               "rocprof_source": profiled_us("mlp_critic_bwd_kernel")[1],
+              # the same algorithmic flops / the committed trace's average
+              # duration of this kernel (timed window of the same command)
+              "frac_from_profile": None if not profiled_us(
+                  "mlp_critic_bwd_kernel")[0] else round(
+                  flops / profiled_us("mlp_critic_bwd_kernel")[0] / 1e6
+                  / F32_MFMA_PEAK_TF, 4),
               "algorithmic_flops": flops_step,
               "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     critic16 = None if us_c16 is None else {
@@ -464,6 +478,8 @@ def _run_config(name, spec, steps, warmup):
     one BASELINE config on this GPU, synchronised wall time, plus the roofline
     of its dominant kernel from the device time (HIP events on the critic's
     stream) of the critic epochs INSIDE those steps."""
+    from tce_rl_amd import mlp_ops
+    mlp_ops.LIBRARY_CALLS.clear()
     agent = build_config_agent(spec)
     T = getattr(agent.sampler, "num_times", None) or \
         agent.sampler.train_envs.num_times
@@ -486,9 +502,7 @@ def _run_config(name, spec, steps, warmup):
     bal_ms = None
     # (black-box agent: black_box_agent.py:218-284, two extra launches per
     # policy epoch without the optimizer step)
-    # (a sharded black-box run leaves the check's two norms out: rl/agent.py)
-    if isinstance(agent.balance_check, int) and not (
-            spec["kind"] != "tce" and agent.dist.active):
+    if isinstance(agent.balance_check, int):
         bal_ms = time_balance_iteration(agent, torch.cuda.synchronize)
     out = {"workload": spec["workload"], "num_env": N, "num_times": T,
            "epochs": "%d + %d" % (E, E), "dtype": spec["dtype"],
@@ -559,21 +573,49 @@ def _run_config(name, spec, steps, warmup):
                 ups.append(r2.get("update_time", 0.0))
             floor_us = sorted(ups)[len(ups) // 2] / E * 1e6
             agent = tiny
+        # kernel time of ONE policy epoch's dependent chain (the longer of
+        # the two chains that run side by side) from the COMMITTED kernel trace
+        # of this config (scripts/profiles_r05.sh -> scripts/rocpd_chain.py):
+        # what is left of an epoch pair is launch boundary / dependency gap
+        chain = None
+        try:
+            with open(os.path.join(REPO, "profiles",
+                                   "r05_C4_bbrl_shard_chain.json")) as f:
+                chain = json.load(f)
+        except (OSError, ValueError):
+            pass
+        pair_us = upd / E * 1e6 if upd else None
+        kern_us = chain["kernel_us_per_chain"] if chain and rows == 4096 \
+            else None
         out["roofline"] = {
             "kernel": "critic + policy epochs (%d -> %d -> %d nets, %d rows)"
                       % (din, hs[0], hs[1], rows),
             "bound": "latency",
-            "us_per_epoch_pair": round(upd / E * 1e6, 1) if upd else None,
+            "us_per_epoch_pair": round(pair_us, 1) if pair_us else None,
+            "kernel_us_per_epoch_pair": kern_us,
+            "gap_frac": None if not (kern_us and pair_us)
+            else round(1.0 - kern_us / pair_us, 3),
+            "chain": None if chain is None else {
+                k: chain[k] for k in ("links", "kernel_us", "gap_us",
+                                      "gap_to_next_chain_us")},
+            "chain_source": None if chain is None
+            else "profiles/r05_C4_bbrl_shard_chain.json",
             "chain_floor_us_per_epoch_pair": None if floor_us is None
             else round(floor_us, 1),
-            "frac_of_chain_floor": None if not (floor_us and upd)
-            else round(floor_us / (upd / E * 1e6), 3),
             "algorithmic_flops_per_epoch": flops,
             "note": "2 x %d dependent epochs of a few small kernels each: "
                     "launch / dependency latency, neither HBM nor MFMA.  "
+                    "kernel_us_per_epoch_pair = sum of the kernel durations of "
+                    "one policy epoch's chain (row kernel -> slab reduction -> "
+                    "finish) in the committed trace of this config; gap_frac = "
+                    "the share of an epoch pair that is launch boundary.  "
                     "chain_floor = the same update measured at 64 envs (one "
-                    "workgroup per kernel: the bare dependent chain of an "
-                    "epoch incl. its launch boundaries)" % E}
+                    "workgroup per kernel)" % E}
+    # every net of a BASELINE config runs on the hand-written kernels: a call
+    # that reached library GEMMs would be a regression of the product path
+    out["library_gemm_calls"] = sum(mlp_ops.LIBRARY_CALLS.values())
+    assert not mlp_ops.LIBRARY_CALLS, \
+        "config %s reached library GEMMs: %r" % (name, mlp_ops.LIBRARY_CALLS)
     del agent
     torch.cuda.empty_cache()
     return out
@@ -619,13 +661,24 @@ def cpu_baseline():
         steps = o.step()
         ts.append(time.perf_counter() - t)
     dt = sorted(ts)[len(ts) // 2]
+    # the same oracle at the HEADLINE size on every core, measured offline
+    # (scripts/cpu_full_size.py: one step takes minutes) and committed
+    full = ""
+    try:
+        with open(os.path.join(REPO, "profiles", "r05_cpu_4096.json")) as f:
+            d = json.load(f)
+        full = ("; the same oracle at the headline's 4096 envs on %d threads "
+                "(%s; profiles/r05_cpu_4096.json, one step, offline): %.0f "
+                "env-steps/s" % (d["cores"], d["cpu"], d["value"]))
+    except (OSError, KeyError, ValueError):
+        pass
     return {"value": round(steps / dt, 1), "unit": "env-steps/s",
             "cores": threads, "kind": "port", "cpu": cpu_model(),
             "visible_cores": avail,
             "sample": "torch-CPU oracle agent.step() at %d envs (T 500, 50 "
                       "critic + 50 policy epochs): 3 warm-up steps, median of "
-                      "10 timed steps = %.2f s (min %.2f, max %.2f)"
-                      % (n, dt, min(ts), max(ts))}
+                      "10 timed steps = %.2f s (min %.2f, max %.2f)%s"
+                      % (n, dt, min(ts), max(ts), full)}
 
 
 def _kill_tree(proc):
@@ -814,6 +867,11 @@ def main():
         print("[bench] warmup done", file=sys.stderr, flush=True)
     agent.dist.check_exchanges()
     tdist.reset_stats()
+    # marks in the kernel trace around the timed steps (scripts/rocpd_stats.py
+    # --between-markers 1 2: the committed profile covers exactly this window)
+    from tce_rl_amd import _lib as tlib
+    tlib.call("tce_marker", 1, tlib.stream())
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     pol_time = crit_time = 0.0
     results = []
@@ -824,6 +882,7 @@ def main():
         results.append(agent.step())
     barrier()
     elapsed = time.perf_counter() - t0
+    tlib.call("tce_marker", 2, tlib.stream())
     for res in results:
         pol_time += res["update_policy_time"]
         crit_time += res["update_critic_time"]      # device time (HIP events)

@@ -398,6 +398,16 @@ int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, i
 int tce_median_ws_len(void);
 int tce_median_f32(const float* x, int64_t n, double* out, unsigned* ws, void* stream);
 int tce_median_f64(const double* x, int64_t n, double* out, unsigned* ws, void* stream);
+/* All five entries of generate_stats (mprl/util/util_numerical.py:130-164) for
+ * one tensor in one chain of launches: out5 (double) = {mean, max, min, median
+ * (as tce_median_*), standard deviation with n - 1} of x [n].  The first pass of
+ * the select reads every element anyway and carries the sums / extrema (double
+ * accumulation of x - x[0], per-workgroup partials combined in a fixed order).
+ * ws: unsigned [tce_stats5_ws_len()], 8-byte aligned, zeroed once by the caller;
+ * one workspace per stream. */
+int tce_stats5_ws_len(void);
+int tce_stats5_f32(const float* x, int64_t n, double* out5, unsigned* ws, void* stream);
+int tce_stats5_f64(const double* x, int64_t n, double* out5, unsigned* ws, void* stream);
 
 /* ---- GPU-resident synthetic env suite ------------------------
  * Stands in for the env processes behind SubprocVecEnv.step
@@ -445,6 +455,11 @@ int tce_rms_merge_f64(const double* moment_partials, int64_t nparts, int D,
  * use units [first_cu, first_cu + cus_per_xcd) of each of the 8 XCDs.
  */
 int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream);
+/* No reference counterpart (measurement aid): an empty launch of `tag` workgroups
+ * named tce_marker_kernel -- a mark that a rocprofv3 kernel trace shows, so that
+ * a summary can be restricted to the dispatches between two marks (bench.py puts
+ * tag 1 / 2 around its timed steps; scripts/rocpd_stats.py --between-markers). */
+int tce_marker(int tag, void* stream);
 int tce_stream_destroy(void* stream);
 
 /* ---- policy objective, shared (non-contextual) covariance ------------------

@@ -7,7 +7,11 @@ rocprofv3 rocpd database:
 critic's persistent grid runs with 224 workgroups beside the policy stream and
 with 256 once that stream has drained, and the two have different durations; a
 column "Workgroups" is added.  --after-ms T: only dispatches that start at
-least T ms after the first one (e.g. to leave the warm-up steps out)."""
+least T ms after the first one (e.g. to leave the warm-up steps out).
+--between-markers A B: only dispatches between the LAST tce_marker_kernel launch
+of A workgroups and the first one of B workgroups after it (bench.py marks its
+timed steps with 1 and 2: the summary then covers exactly the window `value` is
+computed from); prints the window's length."""
 import csv
 import sqlite3
 import statistics
@@ -19,6 +23,10 @@ by_grid = "--by-grid" in sys.argv
 after = 0.0
 if "--after-ms" in sys.argv:
     after = float(sys.argv[sys.argv.index("--after-ms") + 1]) * 1e6
+markers = None
+if "--between-markers" in sys.argv:
+    i = sys.argv.index("--between-markers")
+    markers = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
 con = sqlite3.connect(db)
 cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
 
@@ -34,12 +42,32 @@ gx, wx = pick("grid_x", "grid_size_x", "grid_size"), \
     pick("workgroup_x", "workgroup_size_x", "workgroup_size")
 if by_grid and not (gx and wx):
     raise SystemExit("no grid / workgroup columns in `kernels`: %s" % cols)
-sel = "name, start, end - start" + (", %s, %s" % (gx, wx) if by_grid else "")
+if markers and not (gx and wx):
+    raise SystemExit("no grid / workgroup columns in `kernels`: %s" % cols)
+need_grid = by_grid or markers is not None
+sel = "name, start, end - start" + (", %s, %s" % (gx, wx) if need_grid else "")
 rows = con.execute("select %s from kernels" % sel).fetchall()
 t0 = min(r[1] for r in rows)
+lo, hi = None, None
+if markers:
+    marks = sorted((r[1], r[1] + r[2], r[3] // max(r[4], 1)) for r in rows
+                   if "tce_marker_kernel" in r[0])
+    starts = [m for m in marks if m[2] == markers[0]]
+    if not starts:
+        raise SystemExit("no tce_marker_kernel of %d workgroups in the trace" % markers[0])
+    lo = starts[-1][1]
+    ends = [m for m in marks if m[2] == markers[1] and m[0] > lo]
+    if not ends:
+        raise SystemExit("no closing tce_marker_kernel of %d workgroups" % markers[1])
+    hi = ends[0][0]
+    print("window between the markers: %.3f ms" % ((hi - lo) / 1e6))
 by = {}
 for r in rows:
     if r[1] - t0 < after:
+        continue
+    if lo is not None and not (lo <= r[1] < hi):
+        continue
+    if "tce_marker_kernel" in r[0]:
         continue
     key = (r[0], (r[3] // max(r[4], 1)) if by_grid else None)
     by.setdefault(key, []).append(r[2])

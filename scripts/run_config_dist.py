@@ -19,5 +19,5 @@ warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 spec = dict(bench.OTHER_CONFIGS)[name]
 out = bench.run_config(name, spec, steps, warmup)
 from tce_rl_amd import dist as tdist
-print(json.dumps({k: v for k, v in out.items() if k in ("ms_per_step", "balance_check_iteration_ms", "policy_updates_per_sec")}), tdist.STATS)
+print(json.dumps({k: v for k, v in out.items() if k in ("ms_per_step", "balance_check_iteration_ms", "policy_updates_per_sec")}), tdist.stats())
 dist.destroy_process_group()

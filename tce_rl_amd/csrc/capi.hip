@@ -5,6 +5,9 @@
 
 static thread_local char g_err[512] = "";
 
+// an empty kernel of `tag` workgroups: a mark in a kernel trace (tce_marker)
+__global__ void tce_marker_kernel() {}
+
 extern "C" {
 
 void tce_set_error(const char* msg) {
@@ -44,6 +47,17 @@ int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream) {
     return 2;
   }
   *stream = (void*)st;
+  return 0;
+}
+
+// Put a mark into the stream that a kernel trace shows: an empty launch of `tag`
+// workgroups named tce_marker_kernel (scripts/rocpd_stats.py --between-markers
+// A B keeps the dispatches between the marks with A and B workgroups: the timed
+// window of bench.py without its warm-up and its roofline launches).
+int tce_marker(int tag, void* stream) {
+  TCE_CHECK_ARG(tag >= 1 && tag <= 65535, "marker: 1 <= tag <= 65535");
+  hipLaunchKernelGGL(tce_marker_kernel, dim3((unsigned)tag), dim3(64), 0, (hipStream_t)stream);
+  TCE_LAUNCH_CHECK();
   return 0;
 }
 

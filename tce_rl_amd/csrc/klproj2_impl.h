@@ -431,6 +431,7 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
   const double logdetM = 2.0 * la;
   const double kl0 = 0.5 * (fro - (double)K - logdetM);
   const bool active = kl0 > eps;                         // block-uniform
+  bool bad = false;                                      // the search for eta failed
   double eta = 0;
   if (active) {
     mm_nt(B3, B2, B2, ln, Ident());                      // M
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
       if (eta_prev > 0.25 * eta && eta_prev < 4.0 * eta) eta = eta_prev;
     }
     int evals = 0;
+    bool met = false;                                    // (block-uniform, as eta)
     const bool refine = kl0 > 0.5;
     for (int it = 0; it < 60; ++it) {
       ++evals;
@@ -489,9 +491,20 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
       // the step falls under 1e-10 relative: h carries ~1e-15 of absolute noise
       // (sums of 64 small terms), i.e. ~1e-11 of eps -- asking for more made the
       // iteration wander (8 evaluations per call where 3 do)
-      if (fabs(h - eps) <= 1e-10 * eps || fabs(nxt - eta) <= 1e-10 * eta) break;
+      if (fabs(h - eps) <= 1e-10 * eps || fabs(nxt - eta) <= 1e-10 * eta) {
+        met = true;
+        break;
+      }
       eta = nxt;
     }
+    // The search ended without meeting its tolerance -- a factor that is not
+    // positive definite or not finite makes every comparison above false and
+    // eta double 60 times: nothing computed from this eta is a projection.
+    // Poison it so that the result is NaN and the caller's NaN check on the
+    // losses fires (the reference raises "NAN ... detected" in the same place,
+    // mprl/rl/agent/temporal_correlated_agent.py:569-577) instead of a
+    // plausible-looking context going into the backward pass.
+    bad = !met || !(eta == eta) || !(fabs(eta) < 1e300);
     if (threadIdx.x == 0) tail[5] = (double)evals;     // (diagnostic: evaluations of h)
     // ---- Mt = M W' -> B0, C~ = chol(Mt), L~ = Lo C~
     store_ctx(cb + 2 * KK, B1, K);
@@ -526,9 +539,10 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
   for (int e = threadIdx.x; e < K * K; e += BT) {
     const int r = e / K, c = e - r * K;
     out[e] = c <= r ? (real)(alpha * B2[r * P + c]) : real(0);
+    if (bad) out[e] = (real)__longlong_as_double(0x7ff8000000000000ll);
   }
   if (threadIdx.x == 0) {
-    tail[0] = eta;
+    tail[0] = bad ? __longlong_as_double(0x7ff8000000000000ll) : eta;
     tail[1] = active ? 1.0 : 0.0;
     tail[2] = alpha;
     tail[3] = kl0;

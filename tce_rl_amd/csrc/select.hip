@@ -67,16 +67,29 @@ __device__ inline int pick_bucket(unsigned h, int64_t& k, unsigned* sc, int* sel
   return b;
 }
 
+// STATS: the other four entries of generate_stats ride along -- pass 0 reads every
+// element anyway and also sums d = x - x[0], d^2 (double) and takes max / min per
+// workgroup (partials behind the histograms, fixed-order combination in the final
+// launch): out[0..4] = {mean, max, min, median, std (n - 1)} instead of out[0] =
+// median.  One chain of PASSES + 1 launches per tensor where the metric
+// dictionaries took four library reductions, a stack and the select.
+constexpr int ST_MAX_BLOCKS = 1024;
+__device__ inline double* stats_partials(unsigned* ghist) {
+  return reinterpret_cast<double*>(ghist + 8 * 256 + 2);
+}
+
 // pass == PASSES: the final launch (grid 1)
-template <typename real>
+template <typename real, bool STATS>
 __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict__ x, int64_t n,
                                                           int pass, unsigned* __restrict__ ghist,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out,
+                                                          unsigned nblocks0) {
   typedef KeyT<real> K;
   typedef typename K::key key;
   __shared__ unsigned sc[256];
   __shared__ int sel[2];
   __shared__ unsigned lh[256];
+  __shared__ double red[4];
   const int t = threadIdx.x;
   int64_t k = (n - 1) / 2;
   key prefix = 0, mask = 0;
@@ -88,8 +101,43 @@ __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict
   }
   unsigned* nan_count = ghist + 8 * 256;
   if (pass == K::PASSES) {
-    if (t == 0) {
-      out[0] = *nan_count ? __longlong_as_double(0x7FF8000000000000ll) : (double)K::back(prefix);
+    const double med =
+        *nan_count ? __longlong_as_double(0x7FF8000000000000ll) : (double)K::back(prefix);
+    if (STATS) {
+      // combine the workgroups' partials in workgroup order (wave 0; fixed order)
+      if (t < 64) {
+        const double* part = stats_partials(ghist);
+        double s1 = 0, s2 = 0, mx = -INFINITY, mn = INFINITY;
+        for (unsigned b = t; b < nblocks0; b += 64) {
+          s1 += part[4 * b];
+          s2 += part[4 * b + 1];
+          mx = fmax(mx, part[4 * b + 2]);
+          mn = fmin(mn, part[4 * b + 3]);
+        }
+        s1 = wave_sum_f64(s1);
+        s2 = wave_sum_f64(s2);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          mx = fmax(mx, __shfl_xor(mx, off, 64));
+          mn = fmin(mn, __shfl_xor(mn, off, 64));
+        }
+        if (t == 0) {
+          const double dn = (double)n, shift = (double)x[0];
+          const double md = s1 / dn;
+          out[0] = shift + md;
+          // (max / min of a tensor with a NaN are NaN in torch: the NaN count decides)
+          const double nanv = __longlong_as_double(0x7FF8000000000000ll);
+          out[1] = *nan_count ? nanv : mx;
+          out[2] = *nan_count ? nanv : mn;
+          out[3] = med;
+          out[4] = n > 1 ? sqrt(fmax(s2 - dn * md * md, 0.0) / (dn - 1.0)) : 0.0;
+          if (*nan_count) out[0] = out[4] = nanv;          // (fmax drops a NaN)
+        }
+      }
+      __syncthreads();
+      if (t == 0) *nan_count = 0;
+    } else if (t == 0) {
+      out[0] = med;
       *nan_count = 0;
     }
     for (int q = 0; q < K::PASSES; ++q) ghist[q * 256 + t] = 0;    // ready for the next call
@@ -99,25 +147,58 @@ __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict
   __syncthreads();
   const int shift = 8 * (K::PASSES - 1 - pass);
   unsigned nans = 0;
+  const bool st = STATS && pass == 0;
+  const double shift0 = st ? (double)x[0] : 0.0;
+  double s1 = 0, s2 = 0, mx = -INFINITY, mn = INFINITY;
   for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += (int64_t)gridDim.x * 256) {
     const real v = x[i];
     const key kk = K::of(v);
     if (pass == 0 && v != v) ++nans;
     if ((kk & mask) == prefix) atomicAdd(&lh[(unsigned)(kk >> shift) & 255u], 1u);
+    if (st) {
+      const double d = (double)v - shift0;
+      s1 += d;
+      s2 += d * d;
+      mx = fmax(mx, (double)v);
+      mn = fmin(mn, (double)v);
+    }
   }
   __syncthreads();
   if (lh[t]) atomicAdd(&ghist[pass * 256 + t], lh[t]);
   if (nans) atomicAdd(nan_count, nans);
+  if (st) {
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmax(mx, __shfl_xor(mx, off, 64));
+      mn = fmin(mn, __shfl_xor(mn, off, 64));
+    }
+    __shared__ double wpart[4][4];
+    if ((t & 63) == 0) {
+      wpart[t >> 6][0] = s1; wpart[t >> 6][1] = s2; wpart[t >> 6][2] = mx; wpart[t >> 6][3] = mn;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double* part = stats_partials(ghist) + 4 * (int64_t)blockIdx.x;
+      part[0] = wpart[0][0] + wpart[1][0] + wpart[2][0] + wpart[3][0];
+      part[1] = wpart[0][1] + wpart[1][1] + wpart[2][1] + wpart[3][1];
+      part[2] = fmax(fmax(wpart[0][2], wpart[1][2]), fmax(wpart[2][2], wpart[3][2]));
+      part[3] = fmin(fmin(wpart[0][3], wpart[1][3]), fmin(wpart[2][3], wpart[3][3]));
+    }
+  }
+  (void)red;
 }
 
-template <typename real>
+template <typename real, bool STATS>
 int median_launch(const real* x, int64_t n, double* out, unsigned* ws, hipStream_t st) {
   typedef KeyT<real> K;
   const int64_t want = (n + 4095) / 4096;
-  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  const unsigned grid =
+      (unsigned)(want < 1 ? 1 : (want > ST_MAX_BLOCKS ? ST_MAX_BLOCKS : want));
   for (int p = 0; p <= K::PASSES; ++p) {
-    hipLaunchKernelGGL(median_pass_kernel<real>, dim3(p == K::PASSES ? 1 : grid), dim3(256), 0,
-                       st, x, n, p, ws, out);
+    hipLaunchKernelGGL((median_pass_kernel<real, STATS>), dim3(p == K::PASSES ? 1 : grid),
+                       dim3(256), 0, st, x, n, p, ws, out, grid);
     TCE_LAUNCH_CHECK();
   }
   return 0;
@@ -132,13 +213,28 @@ int tce_median_ws_len(void) { return 8 * 256 + 1; }
 int tce_median_f32(const float* x, int64_t n, double* out, unsigned* ws, void* stream) {
   TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 31),
                 "median: null buffer / element count outside [1, 2^31)");
-  return median_launch<float>(x, n, out, ws, (hipStream_t)stream);
+  return median_launch<float, false>(x, n, out, ws, (hipStream_t)stream);
 }
 
 int tce_median_f64(const double* x, int64_t n, double* out, unsigned* ws, void* stream) {
   TCE_CHECK_ARG(x && out && ws && n > 0 && n < ((int64_t)1 << 31),
                 "median: null buffer / element count outside [1, 2^31)");
-  return median_launch<double>(x, n, out, ws, (hipStream_t)stream);
+  return median_launch<double, false>(x, n, out, ws, (hipStream_t)stream);
+}
+
+// out5 = {mean, max, min, median, std (n - 1)} of x [n] (doubles)
+int tce_stats5_ws_len(void) { return 8 * 256 + 2 + 2 * 4 * ST_MAX_BLOCKS; }
+
+int tce_stats5_f32(const float* x, int64_t n, double* out5, unsigned* ws, void* stream) {
+  TCE_CHECK_ARG(x && out5 && ws && n > 0 && n < ((int64_t)1 << 31),
+                "stats5: null buffer / element count outside [1, 2^31)");
+  return median_launch<float, true>(x, n, out5, ws, (hipStream_t)stream);
+}
+
+int tce_stats5_f64(const double* x, int64_t n, double* out5, unsigned* ws, void* stream) {
+  TCE_CHECK_ARG(x && out5 && ws && n > 0 && n < ((int64_t)1 << 31),
+                "stats5: null buffer / element count outside [1, 2^31)");
+  return median_launch<double, true>(x, n, out5, ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -656,6 +656,32 @@ def median(x):
     return out
 
 
+_STATS5_WS = {}
+
+
+def stats5(x, out=None):
+    """{mean, max, min, median, std (n - 1)} of all elements of a device tensor
+    as a float64 [5] tensor (csrc/select.hip: the radix select's first pass
+    carries the sums and extrema) -- the five entries of generate_stats
+    (util_numerical.py:130-164) in ONE chain of launches.  float32 / float64
+    as they are; bool / integer tensors as float32 (exact up to 2^24)."""
+    x = x.detach()
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = _c(x).reshape(-1)
+    s = stream()
+    key = (x.device, s)
+    ws = _STATS5_WS.get(key)
+    if ws is None:
+        ws = _STATS5_WS[key] = torch.zeros(
+            (_lib.load().tce_stats5_ws_len() + 1) // 2, dtype=torch.int64,
+            device=x.device)
+    if out is None:
+        out = torch.empty(5, dtype=torch.float64, device=x.device)
+    call("tce_stats5_" + sfx(x.dtype), ptr(x), x.numel(), ptr(out), ptr(ws), s)
+    return out
+
+
 def mdp_reward(step_rewards, event_flags):
     """make_mdp_reward: returns the re-shaped rewards (new tensor)."""
     check_dev(step_rewards, event_flags)

@@ -751,6 +751,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         share a hardware queue wait for each other's kernels (measured: the
         K x K kernels queued behind 2 ms critic launches, 2.7 ms per epoch)."""
         from .._lib import call
+        # (re-measured with the in-library exchange, where no communicator
+        # stream carries gradients any more: still 134 against 108 ms per C2 step
+        # through a one-rank RCCL world -- the communicators' streams exist)
         n = int(os.environ.get("TCE_OBJECTIVE_STREAMS", "0")) or \
             (1 if self.dist.active else 2)
         call("tce_policy_objective_streams", n)

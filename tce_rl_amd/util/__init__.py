@@ -140,22 +140,27 @@ def device_stats_async(tensors, name):
     """Enqueue the reductions now (current stream); the returned callable does
     the single host copy and builds the dict -- call it when the host would
     wait anyway."""
-    keys, rows = [], []
-    for k, v in tensors.items():
-        if not torch.is_tensor(v) or v.numel() == 0:
-            continue
-        x = v.detach().double().reshape(-1)
-        std = x.std() if x.numel() > 1 else x.new_zeros(())
-        if v.is_cuda and v.dtype in (torch.float32, torch.float64):
-            from .. import ops
-            med = ops.median(v)                   # radix select (csrc/select.hip)
-        else:
-            med = x.median()
-        rows.append(torch.stack([x.mean(), x.max(), x.min(), med, std]))
-        keys.append(k)
-    if not rows:
+    keys = [k for k, v in tensors.items()
+            if torch.is_tensor(v) and v.numel() > 0]
+    if not keys:
         return dict
-    stacked = torch.stack(rows)
+    if all(tensors[k].is_cuda for k in keys):
+        # one [keys, 5] buffer, one chain of launches per tensor
+        # (tce_stats5_*: the radix select's first pass carries mean / max /
+        # min / std; no library reduction, no sort)
+        from .. import ops
+        stacked = torch.empty(len(keys), 5, dtype=torch.float64,
+                              device=tensors[keys[0]].device)
+        for i, k in enumerate(keys):
+            ops.stats5(tensors[k], out=stacked[i])
+    else:
+        rows = []
+        for k in keys:
+            x = tensors[k].detach().double().reshape(-1)
+            std = x.std() if x.numel() > 1 else x.new_zeros(())
+            rows.append(torch.stack([x.mean(), x.max(), x.min(), x.median(),
+                                     std]))
+        stacked = torch.stack(rows)
 
     def finish():
         host = stacked.cpu().numpy()

@@ -198,9 +198,17 @@ def _equiv_run(kind, overlap, world, rank):
         captured["adv"] = out["segment_advantage"].detach().cpu().reshape(n, -1)
         return out
     agent.process_dataset = grab
+    bal = None
     for it in range(2):
         torch.manual_seed(20 + it)           # pair offsets (rank 0's are used)
         res = agent.step()
+        if it == 0:
+            # iteration 1 carries the policy balance check (1 in balance_check):
+            # the norms of the surrogate's / the trust region loss's gradient
+            # alone -- of the GLOBAL batch, however the envs are sharded
+            bal = [float(res.get(k, float("nan"))) for k in
+                   ("surrogate_grad_norm_mean", "trust_region_grad_norm_mean",
+                    "balance_ratio")]
     flat = [p.detach().reshape(-1).cpu().double()
             for p in agent.policy.parameters + agent.critic.parameters]
     rms = getattr(agent.sampler, "obs_rms", None)
@@ -209,7 +217,7 @@ def _equiv_run(kind, overlap, world, rank):
                  rms.var.reshape(-1).cpu().double(),
                  torch.tensor([float(rms.count)], dtype=torch.float64)]
     return torch.cat(flat).numpy(), captured["adv"].double().numpy(), \
-        int(res["num_global_steps"])
+        int(res["num_global_steps"]), bal, agent.dist.exchange_kind()
 
 
 def _equiv_worker(rank, world, port, kind, overlap, q):
@@ -257,9 +265,20 @@ def test_sharded_equals_single_process(kind, overlap):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (w0, a0, g0), (w1, a1, g1) = out[(2, 0)], out[(2, 1)]
-    ws, as_, gs = out[(1, 0)]
+    (w0, a0, g0, b0, k0), (w1, a1, g1, b1, k1) = out[(2, 0)], out[(2, 1)]
+    ws, as_, gs, bs, ks = out[(1, 0)]
     assert np.array_equal(w0, w1)                        # lock-step
+    # the gradients went through the library's one-shot exchange (two processes,
+    # buffers mapped through HIP IPC), not through torch.distributed
+    assert k0 == k1 == "xgmi-oneshot" and ks == "none"
+    # the balance check of iteration 1: reported by the sharded run too (ADVICE
+    # r4), as the norms of the rank-averaged split gradients == the single
+    # process's on the same 64 envs
+    # (BBRL's first iteration: new == old, the trust region gradient is 0 and
+    # the ratio inf on both sides)
+    assert np.isfinite(bs[:2]).all() and bs[0] > 0 and b0 == b1
+    np.testing.assert_allclose(b0[:2], bs[:2], rtol=2e-3, atol=1e-9)
+    assert b0[2] == bs[2] or abs(b0[2] - bs[2]) <= 5e-3 * abs(bs[2])
     assert g0 == g1 == gs == 2 * N_GLOBAL * 500
     # normalised advantages: global-batch mean / std on both sides
     np.testing.assert_allclose(np.concatenate([a0, a1]), as_, rtol=2e-4,

@@ -331,6 +331,54 @@ def test_kl_cov_projection_warm_start(ops, K, klp_impl):
                                    rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("K", [24, 36])
+def test_kl_cov_projection_says_so_when_the_dual_search_fails(ops, K):
+    """a factor that is not finite makes every comparison of the
+    eigen-free form's search for the dual variable false; it used to leave
+    after 60 evaluations with whatever it held and a context that looked valid.
+    Now the projection and the stored dual variable are NaN -- what the
+    agent's NaN check on the losses turns into "NAN ... detected", as the
+    reference does (temporal_correlated_agent.py:569-577)."""
+    from tce_rl_amd import _lib
+    from tce_rl_amd._lib import call, ptr, stream
+    lib = _lib.load()
+    lib.tce_kl_proj_impl(1)                          # the eigen-free form
+    try:
+        g = torch.Generator().manual_seed(9)
+        L_o = rand_chol(K, 1.0, g, 1).cuda()
+        L = rand_chol(K, 3.0, g, 1)                  # far away: the bound is active
+        ctx = torch.zeros(1, lib.tce_kl_cov_proj_ctx_len(K), dtype=F64,
+                          device="cuda")
+        good = torch.empty(1, K, K, dtype=F64, device="cuda")
+        call("tce_kl_cov_proj_fwd_f64", ptr(L.cuda()), ptr(L_o), 0, 5e-3, None,
+             0, ptr(good), ptr(ctx), 1, K, 0, stream())
+        assert torch.isfinite(good).all() and ctx[0, 4 * K * K + 1] == 1.0
+        # (a) an old factor so close to singular that the whitened covariance
+        # overflows: kl0 = inf, the bound is "active", every evaluation of h is
+        # NaN -- the search cannot end
+        bad_Lo = L_o.clone()
+        bad_Lo[0, K // 2, K // 2] = 1e-200
+        out = torch.zeros(1, K, K, dtype=F64, device="cuda")
+        ctx.zero_()
+        call("tce_kl_cov_proj_fwd_f64", ptr(L.cuda()), ptr(bad_Lo), 0, 5e-3,
+             None, 0, ptr(out), ptr(ctx), 1, K, 0, stream())
+        torch.cuda.synchronize()
+        low = torch.tril(torch.ones(K, K, device="cuda")).bool()
+        assert torch.isnan(out[0][low]).all()
+        assert torch.isnan(ctx[0, 4 * K * K])            # the stored dual variable
+        # (b) a non-finite entry: kl0 is NaN, the factor passes through as it
+        # is -- not finite either way
+        bad_L = L.clone()
+        bad_L[0, K // 2, 1] = float("inf")
+        ctx.zero_()
+        call("tce_kl_cov_proj_fwd_f64", ptr(bad_L.cuda()), ptr(L_o), 0, 5e-3,
+             None, 0, ptr(out), ptr(ctx), 1, K, 0, stream())
+        torch.cuda.synchronize()
+        assert not torch.isfinite(out).all()
+    finally:
+        lib.tce_kl_proj_impl(2)                      # the default choice by K
+
+
 @pytest.mark.parametrize("K", [4, 12, 24])
 def test_kl_cov_projection_kernel_is_the_constrained_optimum(ops, K, klp_impl):
     """The projection KERNEL (either form) against a direct SLSQP solution of

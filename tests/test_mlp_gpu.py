@@ -150,3 +150,32 @@ def test_hidden_layers_on_the_fused_kernels(act, din, rows, dout):
         e32 = (r32.double() - r64).abs().max().item()
         scale = r64.abs().max().item()
         assert e <= 4 * e32 + 1e-5 * scale + 1e-7, (a.shape, e, e32, scale)
+
+
+def test_library_gemm_fallback_is_counted_and_announced_once():
+    """a net no hand-written family covers used to take
+    F.linear + autograd silently.  It still computes (reference precision), but
+    the call is counted per shape and a RuntimeWarning names the shape once."""
+    import warnings
+    from tce_rl_amd import mlp_ops
+    from tce_rl_amd.nn import MLP
+    mlp_ops.LIBRARY_CALLS.clear()
+    mlp_ops._warned.clear()
+    odd = MLP("odd", 10, 3, [48, 48], "orthogonal", 1.0, "tanh", None,
+              torch.float32, torch.device("cuda"))
+    x = torch.randn(17, 10, device="cuda")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = odd(x)
+        odd(x)
+    assert y.shape == (17, 3) and y.requires_grad
+    assert len([m for m in w if "library GEMMs" in str(m.message)]) == 1
+    key = ("library", "torch.float32", 10, 48, 48, 3)
+    assert mlp_ops.LIBRARY_CALLS == {key: 2}
+    # a covered shape under no_grad leaves the counter alone
+    good = MLP("good", 39, 1, [32, 32], "orthogonal", 1.0, "relu", None,
+               torch.float32, torch.device("cuda"))
+    with torch.no_grad():
+        good(torch.randn(64, 39, device="cuda"))
+    assert mlp_ops.LIBRARY_CALLS == {key: 2}
+    mlp_ops.LIBRARY_CALLS.clear()

@@ -47,3 +47,54 @@ def test_device_stats_use_it():
     assert st["t_x_median"] == x.median().double().item()
     assert st["t_n_median"] == 3.0                           # integers: the library path
     assert abs(st["t_x_mean"] - x.double().mean().item()) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 2, 255, 4097, 2_048_000])
+def test_stats5_matches_torch(dtype, n):
+    """tce_stats5_*: the five entries of generate_stats
+    (util_numerical.py:130-164) from one chain of launches == torch's
+    reductions in float64 on the same tensor."""
+    from tce_rl_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, device="cuda", generator=g, dtype=dtype) * 3 + 100
+    got = ops.stats5(x).cpu()
+    xd = x.double()
+    want = torch.stack([xd.mean(), xd.max(), xd.min(), xd.median(),
+                        xd.std() if n > 1 else xd.new_zeros(())]).cpu()
+    assert got[1] == want[1] and got[2] == want[2] and got[3] == want[3]
+    tol = 1e-12 if dtype == torch.float64 else 1e-9
+    torch.testing.assert_close(got[0], want[0], rtol=tol, atol=0)
+    # (the sum of squares about x[0]: ~1e-7 relative in the worst float32 case)
+    torch.testing.assert_close(got[4], want[4], rtol=1e-6, atol=1e-12)
+    # twice in a row on one stream: the workspace is left ready
+    assert torch.equal(ops.stats5(x).cpu(), got)
+
+
+def test_stats5_bool_int_and_nan():
+    from tce_rl_amd import ops
+    b = torch.zeros(1000, 7, dtype=torch.bool, device="cuda")
+    b[:, -1] = True
+    got = ops.stats5(b).cpu()
+    bd = b.double()
+    assert got[:4].tolist() == [bd.mean().item(), 1.0, 0.0, 0.0]
+    torch.testing.assert_close(got[4], bd.std().cpu(), rtol=1e-9, atol=0)
+    i = torch.arange(-5, 6, device="cuda")
+    assert ops.stats5(i).cpu()[:4].tolist() == [0.0, 5.0, -5.0, 0.0]
+    x = torch.randn(5000, device="cuda")
+    x[17] = float("nan")
+    got = ops.stats5(x).cpu()
+    assert torch.isnan(got).all()                # as torch: every entry NaN
+
+
+def test_device_stats_uses_the_fused_chain():
+    from tce_rl_amd import util
+    d = {"a": torch.randn(300, 20, device="cuda"),
+         "flag": torch.rand(300, 20, device="cuda") > 0.5,
+         "skip": "not a tensor"}
+    out = util.device_stats(d, "pre")
+    ref = util.generate_many_stats({k: v for k, v in d.items()
+                                    if torch.is_tensor(v)}, "pre")
+    assert set(out) == set(ref)
+    for k in ref:
+        assert out[k] == pytest.approx(ref[k], rel=1e-6, abs=1e-9), k
