@@ -1256,9 +1256,16 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
             self._bb_stream = streams.get("policy", self.device)
         side = self._bb_stream
         side.wait_stream(main)
+        # The policy's chain is the longer one (3 dependent kernels per epoch,
+        # 38 - 40 us, against the critic's 2, 21 us): it is enqueued FIRST.  The
+        # kernels of a chain run back to back once they are queued (the trace
+        # shows no gap between them), so an update lasts as long as the policy
+        # chain plus whatever the host spent before it reached its first
+        # launch -- with the critic's 200 launches in front that was 1.1 ms of a
+        # 5.7 ms update (scripts/rocpd_seq.py on a C4 trace).
+        finish_policy = self.update_policy(dataset, defer=True)
         with torch.cuda.stream(side):
             finish_critic = self.update_critic(dataset, defer=True)
-        finish_policy = self.update_policy(dataset, defer=True)
         main.wait_stream(side)
         ev[2].record(main)
         steps = self.num_global_steps
@@ -1356,10 +1363,18 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 self._bb_stream = streams.get("policy", self.device)
             side = self._bb_stream
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                finish_critic = self.update_critic(dataset, defer=True)
-            policy_loss_dict = self.update_policy(dataset)
-            main.wait_stream(side)
+            if small:
+                # (the longer chain first: see _step_lazy)
+                finish_policy = self.update_policy(dataset, defer=True)
+                with torch.cuda.stream(side):
+                    finish_critic = self.update_critic(dataset, defer=True)
+                main.wait_stream(side)
+                policy_loss_dict = finish_policy()
+            else:
+                with torch.cuda.stream(side):
+                    finish_critic = self.update_critic(dataset, defer=True)
+                policy_loss_dict = self.update_policy(dataset)
+                main.wait_stream(side)
             critic_loss_dict = finish_critic()
         else:
             critic_loss_dict = self.update_critic(dataset)
