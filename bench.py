@@ -439,6 +439,18 @@ OTHER_CONFIGS = [
         dtype="float32",
         workload="BASELINE.json configs[4] as worded (ProDMP 8 basis, K 63), "
                  "otherwise as above")),
+    # NOT the headline's arithmetic: the same C2 steps with the 50 critic epochs on
+    # the split-f16 matrix-core kernel (22-bit operands, fp32 accumulate: narrower
+    # than the reference's fp32, hence an option and an extra entry, never `value`)
+    ("C2_split_f16_critic", dict(
+        kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
+        dtype="float32", critic_arith="f16x2",
+        workload="NOT BASELINE arithmetic -- configs[1] (TCE Metaworld-reach-"
+                 "like, 4096 envs, T 500, K 24, 50 + 50 epochs) with agent "
+                 "option critic_arith=f16x2: every fp32 operand of the critic "
+                 "epoch carried as two f16 parts (22 bits), fp32 accumulate, "
+                 "on v_mfma_f32_16x16x32_f16 (csrc/mlp16.hip); parity-tested to "
+                 "the fp32 kernel's own error bounds, but narrower than fp32")),
     # the multi-GPU configs at their FULL size on this one GPU (they fit: 288 GB):
     # the denominators of the strong-scaling curves (N GPUs x N-th of the envs)
     ("C4_bbrl_full_16384", dict(
@@ -466,6 +478,8 @@ def build_config_agent(spec, seed=0):
                          num_basis=spec["num_basis"], epochs=spec["epochs"],
                          dtype=spec["dtype"], device="cuda", seed=seed,
                          evaluation_interval=0)
+        if spec.get("critic_arith"):
+            cfg["params"]["agent"]["args"]["critic_arith"] = spec["critic_arith"]
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)
     return exp.agent
@@ -525,6 +539,10 @@ def _run_config(name, spec, steps, warmup):
     flops = 6.0 * (din * hs[0] + hs[0] * hs[1] + hs[1]) * rows
     f64 = spec["dtype"] == "float64"
     peak = F64_MFMA_PEAK_TF if f64 else F32_MFMA_PEAK_TF
+    if spec.get("critic_arith") == "f16x2":
+        # algorithmic (fp32-equivalent) flops against the dense f16 matrix peak;
+        # the kernel issues three f16 MFMAs per product
+        peak = F16_MFMA_PEAK_TF
     if spec["kind"] == "tce":
         us = crit / steps / E * 1e6
         out["policy_updates_per_sec"] = round(E * steps / pol, 2)
@@ -847,22 +865,27 @@ def main():
 
     is_dist = dist.is_initialized()
 
+    from tce_rl_amd import dist as tdist
+
     def barrier():
+        """Every rank's device work done, then a barrier over the ranks (on the
+        host -- a gloo twin of the RCCL group -- so that the barrier itself
+        puts nothing on the GPU), then the device once more."""
+        torch.cuda.synchronize()
         if is_dist:
-            dist.barrier()
+            tdist.host_barrier()
         torch.cuda.synchronize()
 
     def over_ranks(vals):
         """max over ranks of each value, plus every rank's first value."""
         if not is_dist:
             return vals, [vals[0]]
-        tt = torch.tensor(vals, device="cuda", dtype=torch.float64)
-        every = torch.empty(world, len(vals), device="cuda",
-                            dtype=torch.float64)
-        dist.all_gather_into_tensor(every, tt[None])
-        return every.max(0).values.tolist(), every[:, 0].tolist()
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, [float(v) for v in vals],
+                               group=tdist._boot_group())
+        return [max(e[i] for e in every) for i in range(len(vals))], \
+            [e[0] for e in every]
 
-    from tce_rl_amd import dist as tdist
     for _ in range(args.warmup):
         agent.step()
     barrier()
@@ -996,7 +1019,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if is_dist:
-        dist.barrier()
+        tdist.host_barrier()
         dist.destroy_process_group()
 
 

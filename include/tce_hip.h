@@ -460,6 +460,11 @@ int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream);
  * a summary can be restricted to the dispatches between two marks (bench.py puts
  * tag 1 / 2 around its timed steps; scripts/rocpd_stats.py --between-markers). */
 int tce_marker(int tag, void* stream);
+/* No reference counterpart (scheduling aid): one wave that spins for `us`
+ * microseconds of wall clock on `stream` -- the probe with which
+ * tce_rl_amd/streams.py finds out whether two streams run side by side (they do
+ * not when they were bound to the same hardware queue). 0 < us <= 100000. */
+int tce_spin_us(double us, void* stream);
 int tce_stream_destroy(void* stream);
 
 /* ---- policy objective, shared (non-contextual) covariance ------------------
@@ -541,6 +546,12 @@ int tce_policy_objective_streams(int n);
  * its own work against it -- the tests stall it to show that the deferred join
  * of tce_policy_objective_* does not depend on timing. */
 int tce_policy_objective_side_stream(void** stream);
+/* Hand the library the stream to use as its second one (instead of creating
+ * its own on first use): a HIP stream is bound to a hardware queue when it is
+ * created and streams that share a queue wait for each other, so the caller
+ * picks one it has PROBED to run beside its other streams (tce_spin_us below;
+ * tce_rl_amd/streams.py).  The stream must outlive the library's use of it. */
+int tce_policy_objective_use_stream(void* stream);
 int tce_policy_objective_f32(
     const float* mean_new, const float* L_new, const float* mean_old, const float* L_old,
     const float* traj, const float* logp_old, const float* adv, const int64_t* pairs,

@@ -8,6 +8,12 @@ static thread_local char g_err[512] = "";
 // an empty kernel of `tag` workgroups: a mark in a kernel trace (tce_marker)
 __global__ void tce_marker_kernel() {}
 
+// one wave busy for `ticks` of the 100 MHz wall clock (tce_spin_us)
+__global__ void tce_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 extern "C" {
 
 void tce_set_error(const char* msg) {
@@ -57,6 +63,14 @@ int tce_stream_create_cu_range(int first_cu, int cus_per_xcd, void** stream) {
 int tce_marker(int tag, void* stream) {
   TCE_CHECK_ARG(tag >= 1 && tag <= 65535, "marker: 1 <= tag <= 65535");
   hipLaunchKernelGGL(tce_marker_kernel, dim3((unsigned)tag), dim3(64), 0, (hipStream_t)stream);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
+int tce_spin_us(double us, void* stream) {
+  TCE_CHECK_ARG(us > 0 && us <= 100000.0, "spin_us: 0 < us <= 100000");
+  hipLaunchKernelGGL(tce_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (unsigned long long)(us * 100.0));
   TCE_LAUNCH_CHECK();
   return 0;
 }

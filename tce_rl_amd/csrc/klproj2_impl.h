@@ -451,6 +451,7 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
     }
     int evals = 0;
     bool met = false;                                    // (block-uniform, as eta)
+    double h_last = __longlong_as_double(0x7ff8000000000000ll);
     const bool refine = kl0 > 0.5;
     for (int it = 0; it < 60; ++it) {
       ++evals;
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
         t2 = block_sum(s2, red);                         // <I - M, W'^2>
       }
       const double h = 0.5 * (-t1 * re1 - logdetM + logdetN);
+      h_last = h;
       const double hp = 0.5 * ((t1 * re1 - t2 * re1 * re1) / eta - t1 * re1 * re1);
       if (h > eps) lo = eta; else hi = eta;
       const double rh = 1.0 / sqrt(h);
@@ -497,14 +499,18 @@ __global__ __launch_bounds__(BT) void fwd_kernel(
       }
       eta = nxt;
     }
-    // The search ended without meeting its tolerance -- a factor that is not
+    // The search ended without a usable dual variable -- a factor that is not
     // positive definite or not finite makes every comparison above false and
     // eta double 60 times: nothing computed from this eta is a projection.
     // Poison it so that the result is NaN and the caller's NaN check on the
     // losses fires (the reference raises "NAN ... detected" in the same place,
     // mprl/rl/agent/temporal_correlated_agent.py:569-577) instead of a
     // plausible-looking context going into the backward pass.
-    bad = !met || !(eta == eta) || !(fabs(eta) < 1e300);
+    // (an exit at the evaluation cap with the constraint met to 1e-6 relative is
+    // a slow but sound search -- far outside the trust region the last digits of h
+    // are noise --, not a failure)
+    bad = !(eta == eta) || !(fabs(eta) < 1e300) ||
+          (!met && !(fabs(h_last - eps) <= 1e-6 * eps));
     if (threadIdx.x == 0) tail[5] = (double)evals;     // (diagnostic: evaluations of h)
     // ---- Mt = M W' -> B0, C~ = chol(Mt), L~ = Lo C~
     store_ctx(cb + 2 * KK, B1, K);

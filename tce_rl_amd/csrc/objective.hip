@@ -285,15 +285,22 @@ struct ObjSide {
 int g_obj_streams = 2;            // tce_policy_objective_streams: 1 = everything on the caller's stream
 int g_inline_surrogate = 1;       // tce_policy_inline_surrogate (A / B runs, tests)
 
+// (tce_policy_objective_use_stream: a stream of the caller's choice instead of one
+// created here -- a HIP stream is bound to one of the device's few hardware
+// queues when it is created, and the caller can PROBE which of its streams run
+// beside its other ones: tce_rl_amd/streams.py)
+static hipStream_t g_obj_given = nullptr;
 inline ObjSide* obj_side() {
   static ObjSide s;
   static bool tried = false, ok = false;
   if (!tried) {
     tried = true;
-    ok = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess;
+    ok = g_obj_given != nullptr ||
+         hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 7; ++i)
       ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
   }
+  if (ok && g_obj_given) s.side = g_obj_given;
   return ok ? &s : nullptr;
 }
 
@@ -1442,6 +1449,12 @@ int64_t tce_bb_policy_objective_ws_len(int64_t N, int K) { return bb_obj_ws_len(
 
 int tce_policy_objective_streams(int n) {
   g_obj_streams = n < 2 ? 1 : 2;
+  return 0;
+}
+
+int tce_policy_objective_use_stream(void* stream) {
+  TCE_CHECK_ARG(stream != nullptr, "policy_objective_use_stream: null stream");
+  g_obj_given = (hipStream_t)stream;
   return 0;
 }
 

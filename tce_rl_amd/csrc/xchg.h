@@ -111,19 +111,25 @@ __device__ inline void xchg_sync(const XchgView& X, int block) {
   __threadfence_system();
 }
 
-// 3. the sum over ranks of element e in rank order; `mine` = what this rank put
+// 3. the sum over ranks of element e in rank order; `mine` = what this rank put.
+// All peers' loads are issued before the first add (a run-time loop over the
+// ranks would make them W - 1 dependent round trips over xGMI).
 template <typename real>
 __device__ inline real xchg_get(const XchgView& X, int64_t e, real mine) {
   typedef typename XchgBits<real>::type bits;
-  real s = 0;
-  for (int r = 0; r < X.world; ++r) {
-    real v = mine;
-    if (r != X.rank) {
+  real v[XCHG_MAX_WORLD];
+#pragma unroll
+  for (int r = 0; r < XCHG_MAX_WORLD; ++r) {
+    v[r] = mine;
+    if (r < X.world && r != X.rank) {
       const bits* p = reinterpret_cast<const bits*>(X.base[r] + X.data_off) + e;
-      v = XchgBits<real>::dec(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      v[r] = XchgBits<real>::dec(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
-    s = r == 0 ? v : s + v;
   }
+  real s = v[0];
+#pragma unroll
+  for (int r = 1; r < XCHG_MAX_WORLD; ++r)
+    if (r < X.world) s += v[r];
   return s;
 }
 

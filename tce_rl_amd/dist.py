@@ -55,17 +55,91 @@ def _count(t):
     STATS["bytes"] += t.numel() * t.element_size()
 
 
+# The small per-step collectives (statistics gathers, pair broadcast, the critic
+# split's MAX, column sums) ride on a third in-library exchange when one exists
+# ("aux", set up by the agent next to the two gradient exchanges): a sum over
+# ranks of a float64 image of the tensor -- a gather is the sum of images that
+# are zero outside the own row, a broadcast the sum of rank 0's tensor and
+# zeros -- so a steady-state step issues NO torch.distributed call and no
+# communicator stream is ever created by it.  The aux collectives are issued
+# from whatever stream is current; an event chain keeps them in stream order
+# (csrc/xchg.h: one exchange, one stream order on every rank).
+_AUX = {"x": None, "group": None, "event": None}
+_AUX_ELEMS = 1 << 16
+
+
+def set_aux(xchg, group=None):
+    _AUX["x"], _AUX["group"], _AUX["event"] = xchg, group, None
+
+
+def _aux_for(t, group):
+    x = _AUX["x"]
+    if x is None or not x.handle or not t.is_cuda or group is not _AUX["group"]:
+        return None
+    return x
+
+
+def _aux_sum(x, buf):
+    """In-place rank-ordered sum of a contiguous float64 device tensor."""
+    import torch
+    cur = torch.cuda.current_stream()
+    if _AUX["event"] is not None:
+        cur.wait_event(_AUX["event"])
+    flat = buf.reshape(-1)
+    for i in range(0, flat.numel(), _AUX_ELEMS):
+        x.allreduce(flat[i:i + _AUX_ELEMS])
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _AUX["event"] = ev
+
+
 def all_reduce(t, op=None, group=None):
+    import torch
+    x = _aux_for(t, group)
+    if x is not None and op in (None, dist.ReduceOp.SUM, dist.ReduceOp.MAX):
+        if op == dist.ReduceOp.MAX:
+            rows = torch.zeros((x.world,) + tuple(t.shape), dtype=torch.float64,
+                               device=t.device)
+            rows[x.rank] = t
+            _aux_sum(x, rows)
+            t.copy_(rows.amax(0))
+        else:
+            buf = t.to(torch.float64).contiguous()
+            if buf.data_ptr() == t.data_ptr():
+                _aux_sum(x, t)
+            else:
+                _aux_sum(x, buf)
+                t.copy_(buf)
+        return
     _count(t)
     dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op, group=group)
 
 
 def all_gather_into_tensor(out, t, group=None):
+    import torch
+    x = _aux_for(t, group)
+    if x is not None:
+        rows = torch.zeros((x.world, t.numel()), dtype=torch.float64,
+                           device=t.device)
+        rows[x.rank] = t.reshape(-1)
+        _aux_sum(x, rows)
+        out.copy_(rows.reshape(out.shape))
+        return
     _count(out)
     dist.all_gather_into_tensor(out, t, group=group)
 
 
 def broadcast(t, src=0, group=None):
+    import torch
+    x = _aux_for(t, group)
+    if x is not None:
+        buf = t.to(torch.float64).contiguous() if x.rank == src else \
+            torch.zeros(t.shape, dtype=torch.float64, device=t.device)
+        if buf.data_ptr() == t.data_ptr():
+            buf = buf.clone()
+        _aux_sum(x, buf)
+        t.copy_(buf)
+        return
     _count(t)
     dist.broadcast(t, src=src, group=group)
 
@@ -169,7 +243,9 @@ class Exchange:
         if world > 1:
             mine = (socket.gethostname(), x.export())
             everyone = [None] * world
-            dist.all_gather_object(everyone, mine, group=group)
+            # (host-side bootstrap: a gloo twin of the group, so that no
+            # communicator kernel -- and no communicator stream -- is needed)
+            dist.all_gather_object(everyone, mine, group=_boot_group(group))
             ok = all(h == mine[0] for h, _ in everyone)
             if ok:
                 try:
@@ -208,13 +284,33 @@ class Exchange:
         return good and self.status() == 0
 
 
+_BOOT = {}
+
+
+def _boot_group(group=None):
+    """A gloo group over the ranks of `group` (collective on first use) for the
+    host-side bootstrap; the group itself when it is gloo already."""
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = id(group)
+    if key not in _BOOT:
+        ranks = dist.get_process_group_ranks(group) if group is not None \
+            else list(range(dist.get_world_size()))
+        _BOOT[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _BOOT[key]
+
+
 def _agree(flag, group=None):
     """True on every rank iff `flag` is true on every rank."""
     import torch
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_boot_group(group))
     return bool(t.item())
+
+
+def host_barrier(group=None):
+    """A barrier that launches nothing on the device (gloo twin of the group)."""
+    dist.barrier(group=_boot_group(group))
 
 
 def exchange_wanted():
@@ -262,6 +358,16 @@ class DistContext:
                 self._exchanges[channel] = Exchange.over_group(max_bytes,
                                                                self.group)
         return self._exchanges[channel]
+
+    def setup_aux(self):
+        """The exchange of the small per-step collectives (collective call)."""
+        # (TCE_AUX_EXCHANGE=0: keep those on torch.distributed, for A / B runs)
+        if os.environ.get("TCE_AUX_EXCHANGE", "1") == "0":
+            return None
+        x = self.exchange("aux", 8 * _AUX_ELEMS)
+        if x is not None:
+            set_aux(x, self.group)
+        return x
 
     def exchange_kind(self):
         """What carries the gradients: "xgmi-oneshot" | "rccl" | "none"."""

@@ -58,15 +58,21 @@ class AbstractAgent(ABC):
         # torch.distributed all-reduces between the C calls
         self.xchg_critic = self.xchg_policy = None
         if self.dist.active:
-            self.dist.broadcast_params(self.policy_net_params +
-                                       self.critic_net_params)
-            self._policy_group = self.dist.aux_group()
             nbytes = lambda opt: (opt.flat_grad.numel() + 64) * \
                 opt.flat_grad.element_size()
             self.xchg_critic = self.dist.exchange(
                 "critic", nbytes(self.critic_optimizer))
             self.xchg_policy = self.dist.exchange(
                 "policy", nbytes(self.policy_optimizer))
+            # the small per-step collectives (statistics, pairs, critic split)
+            # ride on a third exchange: no torch.distributed call in a step
+            self.dist.setup_aux()
+            if self.xchg_policy is None:
+                # (torch.distributed path: the policy's all-reduces need their
+                # own communicator, see DistContext.aux_group)
+                self._policy_group = self.dist.aux_group()
+            self.dist.broadcast_params(self.policy_net_params +
+                                       self.critic_net_params)
 
     def get_optimizer(self, policy, critic):
         """Adam with L2-in-gradient weight decay (abstract_agent.py:62-82)."""
@@ -751,11 +757,13 @@ class TemporalCorrelatedAgent(AbstractAgent):
         share a hardware queue wait for each other's kernels (measured: the
         K x K kernels queued behind 2 ms critic launches, 2.7 ms per epoch)."""
         from .._lib import call
-        # (re-measured with the in-library exchange, where no communicator
-        # stream carries gradients any more: still 134 against 108 ms per C2 step
-        # through a one-rank RCCL world -- the communicators' streams exist)
         n = int(os.environ.get("TCE_OBJECTIVE_STREAMS", "0")) or \
-            (1 if self.dist.active else 2)
+            (1 if self.dist.active and self.xchg_policy is None else 2)
+        if n == 2 and self.device.type == "cuda":
+            # a stream that is PROBED to run beside the main and the policy
+            # stream (a stream that merely exists may share their hardware queue)
+            from .. import streams
+            streams.objective_side(self.device)
         call("tce_policy_objective_streams", n)
 
     def _update_policy_beside_critic(self, dataset):

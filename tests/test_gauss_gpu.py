@@ -346,7 +346,7 @@ def test_kl_cov_projection_says_so_when_the_dual_search_fails(ops, K):
     try:
         g = torch.Generator().manual_seed(9)
         L_o = rand_chol(K, 1.0, g, 1).cuda()
-        L = rand_chol(K, 3.0, g, 1)                  # far away: the bound is active
+        L = rand_chol(K, 1.0, g, 1)                  # an independent draw: the bound is active
         ctx = torch.zeros(1, lib.tce_kl_cov_proj_ctx_len(K), dtype=F64,
                           device="cuda")
         good = torch.empty(1, K, K, dtype=F64, device="cuda")
