@@ -5,7 +5,7 @@ baseline so; bench.py's in-run `cpu_baseline` is a 64-env sample because this
 one takes minutes).  Offline; the result is committed as
 profiles/r05_cpu_4096.json and cited by bench.py's cpu_baseline.sample.
 
-    python scripts/cpu_full_size.py [num_env] [out.json]
+    python scripts/cpu_full_size.py [num_env] [out.json] [threads ...]
 """
 import json
 import os
@@ -27,7 +27,11 @@ try:
 except AttributeError:
     avail = os.cpu_count() or 1
 res = []
-for threads in sorted({avail, min(avail, 64)}, reverse=True):
+# (thread counts: the GPU boxes show 256 cores but give a process a 16-core share;
+# 256 threads on that share thrash -- the count that is best of the ones tried
+# is the one reported, all are listed)
+counts = [int(a) for a in sys.argv[3:]] or sorted({min(avail, 16), min(avail, 64)})
+for threads in counts:
     torch.set_num_threads(threads)
     cfg = tce_config("metaworld", num_env=n, num_basis=bench.NUM_BASIS,
                      epochs=bench.EPOCHS, device="cpu")

@@ -21,7 +21,7 @@ for c in $CONFIGS; do
     python3 $R/scripts/rocpd_stats.py $db $OUT/r05_bench_kernel_stats_by_grid.csv --by-grid --between-markers 1 2 | tee $OUT/bench_window.txt
     python3 $R/scripts/rocpd_stats.py $db $OUT/r05_bench_kernel_stats.csv --between-markers 1 2
   else
-    timeout -k 10 500 rocprofv3 --kernel-trace -d /tmp/tr_$c -o p -- python3 $R/scripts/run_config.py $c 3 2 > $OUT/$c.log 2>&1 || { echo "trace $c failed"; tail -5 $OUT/$c.log; exit 1; }
+    timeout -k 10 500 rocprofv3 --kernel-trace -d /tmp/tr_$c -o p -- python3 $R/scripts/run_config.py $c 3 2 nofloor > $OUT/$c.log 2>&1 || { echo "trace $c failed"; tail -5 $OUT/$c.log; exit 1; }
     db=$(find /tmp/tr_$c -name "*.db" | head -1)
     python3 $R/scripts/rocpd_stats.py $db $OUT/r05_${c}_kernel_stats.csv
     python3 $R/scripts/rocpd_stats.py $db $OUT/r05_${c}_kernel_stats_by_grid.csv --by-grid || true

@@ -47,17 +47,25 @@ if best is None:
     raise SystemExit("chain not found")
 q, chains = best
 n = len(chains)
-dur = [sum(c[j][2] - c[j][1] for c in chains) / n / 1e3 for j in range(len(links))]
-gap = [sum(c[j + 1][1] - c[j][2] for c in chains) / n / 1e3 for j in range(len(links) - 1)]
-# chain-to-chain: only where the next chain follows within 200 us (same update)
-nxt = [b[0][1] - a[-1][2] for a, b in zip(chains, chains[1:]) if b[0][1] - a[-1][2] < 200e3]
-period = [b[0][1] - a[0][1] for a, b in zip(chains, chains[1:]) if b[0][1] - a[-1][2] < 200e3]
-out = {"queue": q, "chains": n, "links": links,
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else 0.0
+
+
+# medians: a trace holds other iterations too (balance-check epochs, whose chains are
+# interleaved with no-Adam launches; a 64-env agent) -- the typical chain is wanted
+dur = [med([c[j][2] - c[j][1] for c in chains]) / 1e3 for j in range(len(links))]
+gap = [med([c[j + 1][1] - c[j][2] for c in chains]) / 1e3 for j in range(len(links) - 1)]
+nxt = [b[0][1] - a[-1][2] for a, b in zip(chains, chains[1:])]
+period = [b[0][1] - a[0][1] for a, b in zip(chains, chains[1:])]
+out = {"queue": q, "chains": n, "links": links, "statistic": "median over the chains",
        "kernel_us": [round(d, 2) for d in dur],
        "gap_us": [round(g, 2) for g in gap],
-       "gap_to_next_chain_us": round(sum(nxt) / max(len(nxt), 1) / 1e3, 2),
+       "gap_to_next_chain_us": round(med(nxt) / 1e3, 2),
        "kernel_us_per_chain": round(sum(dur), 2),
-       "period_us": round(sum(period) / max(len(period), 1) / 1e3, 2)}
+       "period_us": round(med(period) / 1e3, 2)}
 out["gap_frac"] = round(1.0 - out["kernel_us_per_chain"] / out["period_us"], 4) \
     if out["period_us"] else None
 print(json.dumps(out))

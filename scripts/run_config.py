@@ -9,8 +9,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 name = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-spec = dict(bench.OTHER_CONFIGS)[name]
+nums = [a for a in sys.argv[2:] if a.isdigit()]
+steps = int(nums[0]) if len(nums) > 0 else 3
+warmup = int(nums[1]) if len(nums) > 1 else 2
+spec = dict(dict(bench.OTHER_CONFIGS)[name])
+if "nofloor" in sys.argv[2:]:          # (traces: no second, 64-env agent in the run)
+    spec["chain_floor"] = False
 out = bench.run_config(name, spec, steps, warmup)
 print(json.dumps({k: v for k, v in out.items() if k != "workload"}))
