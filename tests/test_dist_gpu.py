@@ -72,6 +72,59 @@ def test_two_ranks_stay_in_lock_step(overlap):
     assert r0 != r1                          # the shards really differ
 
 
+def _bbrl_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from tce_rl_amd.config import bbrl_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    torch.manual_seed(200 + rank)
+    cfg = bbrl_config(num_env=128, epochs=4, seed=0)
+    exp = MPExperiment()
+    exp.initialize(cfg, 0, None)
+    agent = exp.agent
+    assert agent.sampler.num_env_train == 128 // world
+    for _ in range(3):                       # iteration 1 carries the balance check
+        res = agent.step()
+    agent.flush_metrics()
+    flat = torch.cat([p.detach().reshape(-1).cpu()
+                      for p in agent.policy.parameters + agent.critic.parameters])
+    q.put((rank, flat.numpy(), agent.dist.exchange_kind(),
+           int(res["num_global_steps"]),
+           float(res["exploration_episode_reward_mean"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_of_the_black_box_agent_stay_in_lock_step():
+    """BASELINE configs[3] is a 4-GPU env shard: four ranks (processes on the one
+    GPU of the test box, buffers mapped through HIP IPC) run BlackBoxAgent steps
+    -- both update chains side by side, each with its own in-library exchange --
+    and end with bit-identical replicas."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_bbrl_worker, args=(r, 4, port, q))
+             for r in range(4)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(4)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w0 = out[0][1]
+    assert np.isfinite(w0).all()
+    for rank, w, kind, steps, rew in out:
+        assert kind == "xgmi-oneshot"
+        assert np.array_equal(w, w0), rank
+        assert steps == 3 * 128 * 500
+    assert len({o[4] for o in out}) == 4          # the shards really differ
+
+
 def _rms_worker(rank, world, port, q):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
