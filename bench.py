@@ -53,7 +53,7 @@ def time_balance_iteration(agent, sync):
     balance_check = num_iterations ((n + 1) % n == 1)."""
     keep = agent.balance_check
     out = []
-    for _ in range(2):
+    for _ in range(3):
         agent.balance_check = agent.num_iterations
         assert (agent.num_iterations + 1) % agent.balance_check == 1
         sync()
@@ -63,7 +63,11 @@ def time_balance_iteration(agent, sync):
         out.append((time.perf_counter() - t) * 1e3)
         assert "balance_ratio" in res, "not a balance-check iteration"
         agent.balance_check = None
-        agent.step()                       # an ordinary iteration in between
+        # ordinary iterations in between: the critic split of a balance
+        # iteration is taken from the previous one's device times, which a
+        # sharded run adopts two steps later (rl/agent.py:_adopt_split)
+        for _ in range(3):
+            agent.step()
     agent.balance_check = keep
     sync()
     return min(out)

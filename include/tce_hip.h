@@ -843,6 +843,8 @@ int tce_adam_once_f64(double* param, const double* grad, double* m, double* v, i
  *     kernel goes on instead of hanging, the caller must treat it as fatal.
  *   tce_xchg_counters: collectives issued and payload bytes, per rank.
  *   tce_xchg_allreduce_*: in-place sum over ranks of buf [n], rank order.
+ *   tce_xchg_allgather_f64: out [world][n] = every rank's mine [n] (one
+ *     workgroup; the small per-step statistics of a sharded run).
  *   tce_xchg_adam_*: all-reduce of grad (the sum stays there) + tce_adam_once_*
  *     in ONE launch (clip == 0; with clipping: all-reduce, then the step).
  * Every rank must issue the same sequence of collectives on an exchange, from
@@ -859,8 +861,13 @@ int tce_xchg_destroy(void* xchg);
 int tce_xchg_status(void* xchg);
 int tce_xchg_set_timeout_ms(void* xchg, double ms);
 int tce_xchg_counters(void* xchg, int64_t* collectives, int64_t* bytes);
+int tce_xchg_allgather_f64(void* xchg, const double* mine, double* out, int64_t n, void* stream);
 int tce_xchg_allreduce_f32(void* xchg, float* buf, int64_t n, void* stream);
 int tce_xchg_allreduce_f64(void* xchg, double* buf, int64_t n, void* stream);
+/* the same out of place: dst [n] = sum over ranks of src [n] (src is left as it is) */
+int tce_xchg_allreduce_to_f32(void* xchg, const float* src, float* dst, int64_t n, void* stream);
+int tce_xchg_allreduce_to_f64(void* xchg, const double* src, double* dst, int64_t n,
+                              void* stream);
 int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v, int64_t n,
                       float* state, float* norms_out, float step, float lr, float beta1,
                       float beta2, float eps, float weight_decay, float clip, float grad_scale,

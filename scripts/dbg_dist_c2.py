@@ -12,6 +12,8 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 import bench
 agent, cfg = bench.build_agent(4096, seed=0)
+if os.environ.get("DBG_BAL"):
+    agent.balance_check = 2            # every other iteration carries the balance check
 res = []
 for i in range(12):
     r = agent.step()

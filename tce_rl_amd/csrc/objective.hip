@@ -1045,6 +1045,7 @@ template <> struct EpApi<float> {
   static constexpr auto pm_fwd = tce_pmlp_forward_f32;
   static constexpr auto pm_bwd = tce_pmlp_backward_f32;
   static constexpr auto xsum = tce_xchg_allreduce_f32;
+  static constexpr auto xsum_to = tce_xchg_allreduce_to_f32;
 };
 template <> struct EpApi<double> {
   static constexpr auto begin = tce_policy_objective_begin_f64;
@@ -1055,6 +1056,7 @@ template <> struct EpApi<double> {
   static constexpr auto pm_fwd = tce_pmlp_forward_f64;
   static constexpr auto pm_bwd = tce_pmlp_backward_f64;
   static constexpr auto xsum = tce_xchg_allreduce_f64;
+  static constexpr auto xsum_to = tce_xchg_allreduce_to_f64;
 };
 
 inline int64_t epoch2_ws_len(int64_t N, int K, int H, int64_t nparam) {
@@ -1104,8 +1106,8 @@ inline int fast_bwd(const double*, int64_t, int64_t, int, int, const double*, co
 
 // |g| of one part of a balance epoch's split gradient (grad [n], head part
 // included).  Sharded: the norm of the MEAN over the ranks' gradients -- the
-// part is copied to `scratch` [n], summed over the exchange there (grad keeps
-// the local part) and its norm scaled by grad_scale = 1 / world.
+// part is summed over the exchange INTO `scratch` [n] (grad keeps the local
+// part) and its norm scaled by grad_scale = 1 / world.
 template <typename real>
 int balance_norm(const real* grad, int64_t n, real* scratch, void* xchg, real grad_scale,
                  real* out, hipStream_t st) {
@@ -1113,8 +1115,7 @@ int balance_norm(const real* grad, int64_t n, real* scratch, void* xchg, real gr
   const real* src = grad;
   real scale = 1;
   if (xchg) {
-    OBJ_HIP_ALWAYS(hipMemcpyAsync(scratch, grad, sizeof(real) * n, hipMemcpyDeviceToDevice, st));
-    OBJ_TRY(E::xsum(xchg, scratch, n, (void*)st));
+    OBJ_TRY(E::xsum_to(xchg, grad, scratch, n, (void*)st));      // (grad keeps the local part)
     src = scratch;
     scale = grad_scale;
   }

@@ -38,24 +38,33 @@ struct Xchg {
 
 constexpr int XA_BT = 1024, XA_EPT = 4, XA_PER = XA_BT * XA_EPT;
 
-// in-place sum over ranks of buf [n], rank order
+// dst [n] = sum over ranks of src [n], rank order (dst may be src)
 template <typename real>
-__global__ __launch_bounds__(XA_BT) void xchg_allreduce_kernel(XchgView X, real* __restrict__ buf,
-                                                               int64_t n) {
+__global__ __launch_bounds__(XA_BT) void xchg_allreduce_kernel(XchgView X, const real* src,
+                                                               real* dst, int64_t n) {
   const int64_t i0 = (int64_t)blockIdx.x * XA_PER;
   real mine[XA_EPT];
 #pragma unroll
   for (int q = 0; q < XA_EPT; ++q) {
     const int64_t i = i0 + threadIdx.x + q * XA_BT;
-    mine[q] = i < n ? buf[i] : real(0);
+    mine[q] = i < n ? src[i] : real(0);
     if (i < n && xchg_on(X)) xchg_put<real>(X, i, mine[q]);
   }
-  if (!xchg_on(X)) return;
+  if (!xchg_on(X)) {
+    if (dst != src) {
+#pragma unroll
+      for (int q = 0; q < XA_EPT; ++q) {
+        const int64_t i = i0 + threadIdx.x + q * XA_BT;
+        if (i < n) dst[i] = mine[q];
+      }
+    }
+    return;
+  }
   xchg_sync(X, blockIdx.x);
 #pragma unroll
   for (int q = 0; q < XA_EPT; ++q) {
     const int64_t i = i0 + threadIdx.x + q * XA_BT;
-    if (i < n) buf[i] = xchg_get<real>(X, i, mine[q]);
+    if (i < n) dst[i] = xchg_get<real>(X, i, mine[q]);
   }
 }
 
@@ -126,13 +135,39 @@ __global__ __launch_bounds__(XA_BT) void xchg_adam_kernel(
   *ticket = 0u;
 }
 
+// out [world][n] = every rank's mine [n] (one workgroup: the small per-step
+// statistics -- (count, mean, M2) triples, column sums, the critic split)
 template <typename real>
-int xchg_allreduce(void* x, real* buf, int64_t n, hipStream_t st) {
-  TCE_CHECK_ARG(x && buf && n > 0, "xchg_allreduce: null exchange / buffer, n <= 0");
+__global__ __launch_bounds__(XA_BT) void xchg_allgather_kernel(XchgView X,
+                                                               const real* __restrict__ mine,
+                                                               real* __restrict__ out, int n) {
+  const int world = X.world < 1 ? 1 : X.world;
+  if (xchg_on(X)) {
+    for (int i = threadIdx.x; i < n; i += XA_BT) xchg_put<real>(X, i, mine[i]);
+    xchg_sync(X, 0);
+  }
+  typedef typename XchgBits<real>::type bits;
+  for (int e = threadIdx.x; e < world * n; e += XA_BT) {
+    const int r = e / n, i = e - r * n;
+    real v;
+    if (r == X.rank || !xchg_on(X)) {
+      v = mine[i];
+    } else {
+      const bits* p = reinterpret_cast<const bits*>(X.base[r] + X.data_off) + i;
+      v = XchgBits<real>::dec(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+    out[e] = v;
+  }
+}
+
+template <typename real>
+int xchg_allreduce(void* x, const real* src, real* dst, int64_t n, hipStream_t st) {
+  TCE_CHECK_ARG(x && src && dst && n > 0, "xchg_allreduce: null exchange / buffer, n <= 0");
   const int blocks = (int)ceil_div(n, XA_PER);
   XchgView X;
   if (xchg_next(x, n * (int64_t)sizeof(real), blocks, &X)) return 1;
-  hipLaunchKernelGGL(xchg_allreduce_kernel<real>, dim3(blocks), dim3(XA_BT), 0, st, X, buf, n);
+  hipLaunchKernelGGL(xchg_allreduce_kernel<real>, dim3(blocks), dim3(XA_BT), 0, st, X, src, dst,
+                     n);
   TCE_LAUNCH_CHECK();
   return 0;
 }
@@ -279,11 +314,29 @@ int tce_xchg_counters(void* xv, int64_t* collectives, int64_t* bytes) {
   return 0;
 }
 
+int tce_xchg_allgather_f64(void* x, const double* mine, double* out, int64_t n, void* stream) {
+  TCE_CHECK_ARG(x && mine && out && n > 0 && n <= (1 << 20),
+                "xchg_allgather: null exchange / buffer, n outside [1, 2^20]");
+  XchgView X;
+  if (xchg_next(x, n * (int64_t)sizeof(double), 1, &X)) return 1;
+  hipLaunchKernelGGL(xchg_allgather_kernel<double>, dim3(1), dim3(XA_BT), 0, (hipStream_t)stream,
+                     X, mine, out, (int)n);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
+
 int tce_xchg_allreduce_f32(void* x, float* buf, int64_t n, void* stream) {
-  return xchg_allreduce<float>(x, buf, n, (hipStream_t)stream);
+  return xchg_allreduce<float>(x, buf, buf, n, (hipStream_t)stream);
 }
 int tce_xchg_allreduce_f64(void* x, double* buf, int64_t n, void* stream) {
-  return xchg_allreduce<double>(x, buf, n, (hipStream_t)stream);
+  return xchg_allreduce<double>(x, buf, buf, n, (hipStream_t)stream);
+}
+int tce_xchg_allreduce_to_f32(void* x, const float* src, float* dst, int64_t n, void* stream) {
+  return xchg_allreduce<float>(x, src, dst, n, (hipStream_t)stream);
+}
+int tce_xchg_allreduce_to_f64(void* x, const double* src, double* dst, int64_t n,
+                              void* stream) {
+  return xchg_allreduce<double>(x, src, dst, n, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -315,7 +368,7 @@ int xchg_adam(void* xv, real* param, real* grad, real* m, real* v, int64_t n, re
   if (clip > real(0)) {
     // the clip factor needs the norm of the WHOLE summed gradient before any
     // element is applied: all-reduce, then the one-launch step
-    if (xchg_allreduce<real>(xv, grad, n, st)) return 1;
+    if (xchg_allreduce<real>(xv, grad, grad, n, st)) return 1;
     TCE_CHECK_ARG(n <= (1 << 17), "xchg_adam: clipping needs n <= 2^17 (tce_adam_once)");
     return adam_once_any(param, grad, m, v, n, state, norms_out, step, lr, b1, b2, eps, wd, clip,
                          gscale, stream);

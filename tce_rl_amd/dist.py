@@ -79,6 +79,22 @@ def _aux_for(t, group):
     return x
 
 
+def _aux_gather(x, t):
+    """[world, n] float64 = every rank's t (flattened): ONE launch."""
+    import torch
+    cur = torch.cuda.current_stream()
+    if _AUX["event"] is not None:
+        cur.wait_event(_AUX["event"])
+    mine = t.reshape(-1).to(torch.float64).contiguous()
+    out = torch.empty(x.world, mine.numel(), dtype=torch.float64,
+                      device=t.device)
+    x.allgather(mine, out)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _AUX["event"] = ev
+    return out
+
+
 def _aux_sum(x, buf):
     """In-place rank-ordered sum of a contiguous float64 device tensor."""
     import torch
@@ -98,11 +114,10 @@ def all_reduce(t, op=None, group=None):
     x = _aux_for(t, group)
     if x is not None and op in (None, dist.ReduceOp.SUM, dist.ReduceOp.MAX):
         if op == dist.ReduceOp.MAX:
-            rows = torch.zeros((x.world,) + tuple(t.shape), dtype=torch.float64,
-                               device=t.device)
-            rows[x.rank] = t
-            _aux_sum(x, rows)
-            t.copy_(rows.amax(0))
+            t.copy_(_aux_gather(x, t).amax(0).reshape(t.shape))
+        elif t.numel() <= 4096:
+            # (small: gather + a sum in rank order, one exchange launch)
+            t.copy_(_aux_gather(x, t).sum(0).reshape(t.shape))
         else:
             buf = t.to(torch.float64).contiguous()
             if buf.data_ptr() == t.data_ptr():
@@ -118,12 +133,12 @@ def all_reduce(t, op=None, group=None):
 def all_gather_into_tensor(out, t, group=None):
     import torch
     x = _aux_for(t, group)
-    if x is not None:
-        rows = torch.zeros((x.world, t.numel()), dtype=torch.float64,
-                           device=t.device)
-        rows[x.rank] = t.reshape(-1)
-        _aux_sum(x, rows)
-        out.copy_(rows.reshape(out.shape))
+    if x is not None and t.numel() <= (1 << 16):
+        rows = _aux_gather(x, t)
+        if out.dtype == torch.float64 and out.is_contiguous():
+            out.copy_(rows.reshape(out.shape))       # (same dtype: a plain copy)
+        else:
+            out.copy_(rows.reshape(out.shape))
         return
     _count(out)
     dist.all_gather_into_tensor(out, t, group=group)
@@ -132,6 +147,9 @@ def all_gather_into_tensor(out, t, group=None):
 def broadcast(t, src=0, group=None):
     import torch
     x = _aux_for(t, group)
+    if x is not None and t.numel() <= 4096:
+        t.copy_(_aux_gather(x, t)[src].reshape(t.shape))
+        return
     if x is not None:
         buf = t.to(torch.float64).contiguous() if x.rank == src else \
             torch.zeros(t.shape, dtype=torch.float64, device=t.device)
@@ -189,6 +207,17 @@ class Exchange:
         assert t.is_contiguous() and t.is_cuda
         self._call("tce_xchg_allreduce_" + sfx(t.dtype), self.handle,
                    t.data_ptr(), t.numel(), stream())
+
+    def allgather(self, mine, out):
+        """out [world, n] = every rank's mine [n] (contiguous float64 device
+        tensors; one launch)."""
+        from ._lib import stream
+        import torch
+        assert mine.dtype == out.dtype == torch.float64 and mine.is_cuda \
+            and mine.is_contiguous() and out.is_contiguous() \
+            and out.numel() == self.world * mine.numel()
+        self._call("tce_xchg_allgather_f64", self.handle, mine.data_ptr(),
+                   out.data_ptr(), mine.numel(), stream())
 
     def status(self):
         return int(self._lib.tce_xchg_status(self.handle))

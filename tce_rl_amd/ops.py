@@ -37,6 +37,12 @@ def merge_stats(stats, group=None):
     w = dist.get_world_size(group)
     buf = stats.new_empty(w, 3)
     all_gather_into_tensor(buf, stats.reshape(1, 3), group=group)
+    if buf.is_cuda and buf.dtype == torch.float64:
+        # the ranks' (count, mean, M2) triples are partials like any others:
+        # the kernel that merges a launch's partials merges them (one launch)
+        out = torch.empty(3, dtype=torch.float64, device=buf.device)
+        call("tce_moments_finalize", ptr(buf), w, ptr(out), stream())
+        return out
     n = buf[:, 0].sum()
     mean = (buf[:, 0] * buf[:, 1]).sum() / n
     m2 = (buf[:, 2] + buf[:, 0] * (buf[:, 1] - mean) ** 2).sum()

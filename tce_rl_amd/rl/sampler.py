@@ -42,6 +42,20 @@ class RunningMeanStd:
         accumulated relative to the current running mean while the batch was
         being produced (the env rollout kernel): no second pass over it."""
         shift = self.mean.clone()
+        from ..dist import active, all_reduce
+        if active() and getattr(self, "equal_shards", False):
+            # env shards accumulate their column moments about the SAME shift
+            # (the running mean is replicated), so the shards' sums simply add:
+            # one reduction, one small exchange, then the single-process merge
+            # over the global row count -- instead of per-rank (mean, var, n)
+            # triples pooled by ~40 small device ops
+            import torch.distributed as dist
+            red = partials.reshape(-1, *partials.shape[-2:]).sum(0, keepdim=True)
+            all_reduce(red)
+            self.count = ops.rms_merge(red, rows * dist.get_world_size(),
+                                       self.mean, self.var, self.count,
+                                       shift=shift)
+            return
         self._merge(lambda mean, var, count:
                     ops.rms_merge(partials, rows, mean, var, count,
                                   shift=shift))
