@@ -267,15 +267,25 @@ class Exchange:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         if world > 8:
             return None
-        x = cls(rank, world, max_bytes)
+        # (a rank whose own end cannot be created must still take part in the
+        # collectives below, or its peers would wait for it forever)
+        x, handle = None, None
+        try:
+            x = cls(rank, world, max_bytes)
+            handle = x.export() if world > 1 else None
+        except RuntimeError as e:
+            warnings.warn("gradient exchange: creating the peer-visible buffer "
+                          "failed (%s)" % e)
+            if world == 1:
+                return None
         ok = True
         if world > 1:
-            mine = (socket.gethostname(), x.export())
+            mine = (socket.gethostname(), handle)
             everyone = [None] * world
             # (host-side bootstrap: a gloo twin of the group, so that no
             # communicator kernel -- and no communicator stream -- is needed)
             dist.all_gather_object(everyone, mine, group=_boot_group(group))
-            ok = all(h == mine[0] for h, _ in everyone)
+            ok = all(h == mine[0] and b is not None for h, b in everyone)
             if ok:
                 try:
                     x.connect([b for _, b in everyone])
@@ -285,7 +295,14 @@ class Exchange:
                     ok = False
             ok = _agree(ok, group)
             if ok:
+                # a short limit while probing: a mapping that does not show the
+                # peers' stores costs seconds here, not six times the default
+                x.set_timeout_ms(float(os.environ.get(
+                    "TCE_XCHG_SELFTEST_TIMEOUT_MS", "5000")))
                 ok = _agree(x._self_test(), group)
+                if ok:
+                    x.set_timeout_ms(float(os.environ.get(
+                        "TCE_XCHG_TIMEOUT_MS", "20000")))
         if not ok:
             if world > 1 and rank == 0:
                 warnings.warn(
@@ -293,7 +310,8 @@ class Exchange:
                     "usable on this job (ranks on several hosts, IPC mapping "
                     "or self-test failed); falling back to "
                     "torch.distributed all-reduces between the C calls")
-            x.close()
+            if x is not None:
+                x.close()
             return None
         return x
 
