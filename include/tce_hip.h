@@ -974,6 +974,28 @@ int tce_mlp_critic_f16x2(const float* x, int64_t env_stride, int64_t row_stride,
                          float weight_decay, float adam_step, float grad_scale, void* xchg,
                          void* stream);
 
+/* The backward launch of tce_mlp_critic_f32 (same buffers and contract;
+ * partials != NULL required) on the bf16 matrix cores with THREE-PART operands:
+ * every fp32 operand x is carried as b0 = bf16(x), b1 = bf16(x - b0), b2 =
+ * bf16(x - b0 - b1) -- x = b0 + b1 + b2 exactly: 24 significand bits, the
+ * exponent range of fp32, no range restriction -- and every product as its six
+ * partial products of order <= 2 (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0),
+ * each exact in the matrix core, accumulated in fp32.  The dropped terms are
+ * below 2^-25 of the product (35 x under the rounding noise of an fp32 FMA
+ * chain): loss and gradients are as close to the fp64 truth as the exact-fp32
+ * kernel's (tests/test_mlpb_gpu.py) at 6/16 of its matrix-core cycles
+ * (csrc/mlpb.hip).  Replaces the same reference lines as tce_mlp_critic_f32
+ * (mprl/rl/agent/temporal_correlated_agent.py:343-366, 688-716). */
+int tce_mlp_critic_bf16x3(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                          int64_t R, int din, const float* w1, const float* b1,
+                          const float* w2, const float* b2, const float* w3, const float* b3,
+                          int act, const float* returns, const float* old_values, float clip,
+                          float* values, float* partials, float* grad, float* stats,
+                          int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                          float* adam_state, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float adam_step, float grad_scale, void* xchg,
+                          void* stream);
+
 /* ---- policy mean net on rows (float32 / float64, one or two hidden layers) ----
  * D_in <= 64 -> hidden (-> hidden) -> D_out <= 64 over N rows, torch Linear
  * layout, parameters FLAT in the order of MLP.parameters()

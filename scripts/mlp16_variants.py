@@ -1,13 +1,17 @@
-"""Experiment harness for the split-f16 critic kernel: build mlp16.hip with -D
-switches and time each variant; the `stamp` variant prints cycles per phase.
+"""Experiment harness for the split-f16 (mlp16.hip) and three-part bf16
+(mlpb.hip: set M16_KERNEL=mlpb) critic kernels: build the file with -D switches
+and time each variant; the `stamp` variant prints cycles per phase.
    build:  python scripts/mlp16_variants.py build
-   run  :  python scripts/mlp16_variants.py run        (on the GPU box)"""
+   run  :  python scripts/mlp16_variants.py run        (on the GPU box)
+   extra variants: M16_EXTRA="name=-DFLAG ...;name2=..." """
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "tce_rl_amd", "csrc")
 OUT = os.path.join(HERE, "variants")
-VARIANTS = {"base": [], "stamp": ["-DM16_STAMP"]}
+KERNEL = os.environ.get("M16_KERNEL", "mlp16")
+ENTRY = {"mlp16": "tce_mlp_critic_f16x2", "mlpb": "tce_mlp_critic_bf16x3"}[KERNEL]
+VARIANTS = {"base": [], "stamp": ["-DM16_STAMP", "-DMLPB_STAMP"]}
 VARIANTS.update({k: v.split() for k, v in
                  (a.split("=", 1) for a in os.environ.get("M16_EXTRA", "").split(";") if a)})
 
@@ -18,8 +22,9 @@ def build():
     def one(kv):
         name, flags = kv
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared",
-               *flags, os.path.join(CSRC, "mlp16.hip"), os.path.join(CSRC, "capi.hip"),
-               "-o", os.path.join(OUT, "libmlp16_%s.so" % name)]
+               *flags, os.path.join(CSRC, KERNEL + ".hip"), os.path.join(CSRC, "capi.hip"),
+               os.path.join(CSRC, "xchg.hip"), os.path.join(CSRC, "optim.hip"),
+               "-o", os.path.join(OUT, "lib%s_%s.so" % (KERNEL, name))]
         r = subprocess.run(cmd, capture_output=True, text=True)
         print(name, "ok" if r.returncode == 0 else r.stderr[-2000:], flush=True)
     with ThreadPoolExecutor(4) as ex:
@@ -38,14 +43,14 @@ def run():
     w2 = torch.randn(H, H, device="cuda") * 0.1; b2 = torch.zeros(H, device="cuda")
     w3 = torch.randn(1, H, device="cuda") * 0.1; b3 = torch.zeros(1, device="cuda")
     for name in VARIANTS:
-        path = os.path.join(OUT, "libmlp16_%s.so" % name)
+        path = os.path.join(OUT, "lib%s_%s.so" % (KERNEL, name))
         if not os.path.exists(path):
             continue
         lib = ctypes.CDLL(path)
         P = H * din + H + H * H + H + H + 1; G = 256
         partials = torch.empty(G, P + 2, device="cuda"); flat = torch.empty(P, device="cuda"); stats = torch.empty(2, device="cuda")
         vp = ctypes.c_void_p
-        fn = lib.tce_mlp_critic_f16x2
+        fn = getattr(lib, ENTRY)
         fn.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [vp] * 6 + \
             [ctypes.c_int, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp] + [ctypes.c_float] * 7 + [vp, vp]
         def go():
@@ -63,11 +68,14 @@ def run():
             e.record(); torch.cuda.synchronize()
             best = min(best, s.elapsed_time(e) / 10)
         print(f"{name:12s} {best*1e3:8.1f} us/epoch", flush=True)
-        if "M16_STAMP" in " ".join(VARIANTS[name]) or name == "stamp":
+        if "_STAMP" in " ".join(VARIANTS[name]) or name == "stamp":
             go(); torch.cuda.synchronize()
             st = partials[0, :16].cpu().tolist()
             names = ["x split", "F2", "F4", "loss+dY2+pack", "barrier P1", "P2 writes", "barrier P2", "P3 dH1", "barrier P3",
                      "P4 writes", "barrier P4", "-", "G: dW1", "G: barriers 1+2", "G: dW2", "G: barriers 3+4"]
+            if KERNEL == "mlpb":
+                names = ["L1 + H1 image", "barrier A", "L2 + v partials", "barrier B",
+                         "loss + dY2 image", "barrier C", "dW2", "dH1 + dY1", "barrier D", "dY1 image + dW1", "barrier E", "X image", "barrier F", "-", "-", "tile head"]
             tiles = (N * T // 64) // G
             for n_, v_ in zip(names, st):
                 print(f"    {n_:16s} {v_ / tiles:9.0f} counter units/tile")

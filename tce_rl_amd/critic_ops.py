@@ -173,7 +173,7 @@ class EpochRunner:
         arith: "f32" (exact-fp32 matrix cores, csrc/mlp.hip) or "f16x2" (split
         f16 operands on the f16 matrix cores, csrc/mlp16.hip)."""
         assert narrow_supported(mlp)
-        assert arith in ("f32", "f16x2"), arith
+        assert arith in ("f32", "f16x2", "bf16x3"), arith
         self.arith = arith
         self.entry = "tce_mlp_critic_" + arith
         self.mlp = mlp
