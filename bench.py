@@ -245,6 +245,8 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
         run16 = critic_ops.EpochRunner(net, arith="f16x2")
         us_c16 = kernel_time_us(lambda: run16.epoch(xs, rets, rets, 0.0),
                                 launches=5)
+    runb = critic_ops.EpochRunner(net, arith="bf16x3")
+    us_cb = kernel_time_us(lambda: runb.epoch(xs, rets, rets, 0.0), launches=5)
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
@@ -276,6 +278,27 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
                          / F32_MFMA_PEAK_TF, 4),
               "algorithmic_flops": flops_step,
               "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+    if getattr(agent, "critic_arith", "f32") == "bf16x3":
+        # --critic-arith bf16x3: the timed steps ran csrc/mlpb.hip; algorithmic
+        # (fp32-equivalent) flops against the dense bf16 matrix peak, the six
+        # issued MFMAs per product beside it
+        a_ = flops_step / us_step / 1e6
+        critic.update({
+            "kernel": "mlp_critic_bwdb_kernel<relu,2> (+ mlp_finish_kernel)",
+            "achieved": round(a_, 2), "peak": F16_MFMA_PEAK_TF,
+            "frac": round(a_ / F16_MFMA_PEAK_TF, 4),
+            "frac_issued": round(6 * a_ / F16_MFMA_PEAK_TF, 4),
+            "of_fp32_mfma_peak": round(a_ / F32_MFMA_PEAK_TF, 3),
+            "traffic": None, "traffic_source": None,
+            "isolated_back_to_back": {
+                "us_per_launch": round(us_cb, 1),
+                "achieved": round(flops / us_cb / 1e6, 2),
+                "frac": round(flops / us_cb / 1e6 / F16_MFMA_PEAK_TF, 4)},
+            "mfma_busy": None, "mfma_busy_source": None,
+            "rocprof_us_per_launch": None, "rocprof_source": None,
+            "frac_from_profile": None,
+            "dtype": "bf16x3 operands (24 bits, fp32 range), six partial "
+                     "products, fp32 accumulate (v_mfma_f32_16x16x32_bf16)"})
     critic16 = None if us_c16 is None else {
         "kernel": "mlp_critic_bwd16_kernel<relu,2> (+ mlp_finish_kernel)",
         "bound": "mfma", "achieved": round(flops / us_c16 / 1e6, 2),
@@ -291,6 +314,25 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
                  "(v_mfma_f32_16x16x32_f16; 3 MFMAs per product)"}
     del full, xs
     extra = {} if critic16 is None else {"critic_split_f16": critic16}
+    extra["critic_bf16x3"] = {
+        "kernel": "mlp_critic_bwdb_kernel<relu,2> (+ mlp_finish_kernel)",
+        "bound": "mfma", "achieved": round(flops / us_cb / 1e6, 2),
+        "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": round(flops / us_cb / 1e6 / F16_MFMA_PEAK_TF, 4),
+        "traffic": None,
+        "us_per_launch": round(us_cb, 1),
+        "algorithmic_flops": flops,
+        "mfma_flops_issued": 6 * flops,
+        "frac_issued": round(6 * flops / us_cb / 1e6 / F16_MFMA_PEAK_TF, 4),
+        "speedup_over_exact_fp32_kernel": round(us_c / us_cb, 3),
+        "of_fp32_mfma_peak": round(flops / us_cb / 1e6 / F32_MFMA_PEAK_TF, 3),
+        "dtype": "bf16x3: three-part bf16 operands (24 bits, fp32 range), six "
+                 "partial products, fp32 accumulate (v_mfma_f32_16x16x32_bf16)",
+        "note": "isolated back to back, C2 rows; agent option critic_arith="
+                "bf16x3 (configs.C2_bf16x3_critic times whole steps with it); "
+                "bound by the VALU work of the three-way splits and the LDS "
+                "reads that share the issue port with the MFMAs at one wave per "
+                "SIMD (DESIGN section 4), not by the matrix cores"}
 
     def gae_case(n):
         r = torch.randn(n, T, device="cuda", generator=g)
@@ -443,6 +485,24 @@ OTHER_CONFIGS = [
         dtype="float32",
         workload="BASELINE.json configs[4] as worded (ProDMP 8 basis, K 63), "
                  "otherwise as above")),
+    # NOT the headline's instruction: the same C2 steps with the 50 critic epochs on
+    # the bf16 matrix cores with THREE-PART operands (csrc/mlpb.hip): every fp32
+    # operand as b0 + b1 + b2 exactly (24 bits, fp32's exponent range), six partial
+    # products per product, fp32 accumulate -- not narrower than fp32 and as close to
+    # the fp64 truth as the exact-fp32 kernel (tests/test_mlpb_gpu.py), but a change
+    # of arithmetic all the same: an extra entry, `value` stays on v_mfma_f32_16x16x4_f32
+    ("C2_bf16x3_critic", dict(
+        kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
+        dtype="float32", critic_arith="bf16x3",
+        workload="configs[1] (TCE Metaworld-reach-like, 4096 envs, T 500, K 24, "
+                 "50 + 50 epochs) with agent option critic_arith=bf16x3: every "
+                 "fp32 operand of the critic epoch carried as three bf16 parts "
+                 "(x = b0 + b1 + b2 exactly: 24 bits, fp32's range), six of the "
+                 "nine partial products (the dropped ones < 2^-25 of the "
+                 "product), fp32 accumulate, on v_mfma_f32_16x16x32_bf16 "
+                 "(csrc/mlpb.hip); loss and gradients no further from an fp64 "
+                 "reference than the exact-fp32 kernel's "
+                 "(tests/test_mlpb_gpu.py)")),
     # NOT the headline's arithmetic: the same C2 steps with the 50 critic epochs on
     # the split-f16 matrix-core kernel (22-bit operands, fp32 accumulate: narrower
     # than the reference's fp32, hence an option and an extra entry, never `value`)
@@ -543,9 +603,9 @@ def _run_config(name, spec, steps, warmup):
     flops = 6.0 * (din * hs[0] + hs[0] * hs[1] + hs[1]) * rows
     f64 = spec["dtype"] == "float64"
     peak = F64_MFMA_PEAK_TF if f64 else F32_MFMA_PEAK_TF
-    if spec.get("critic_arith") == "f16x2":
-        # algorithmic (fp32-equivalent) flops against the dense f16 matrix peak;
-        # the kernel issues three f16 MFMAs per product
+    if spec.get("critic_arith") in ("f16x2", "bf16x3"):
+        # algorithmic (fp32-equivalent) flops against the dense f16 / bf16 matrix
+        # peak; the kernels issue three (f16x2) / six (bf16x3) MFMAs per product
         peak = F16_MFMA_PEAK_TF
     if spec["kind"] == "tce":
         us = crit / steps / E * 1e6
@@ -744,6 +804,8 @@ def self_launch(args):
         cmd.append("--no-cpu-baseline")
     if args.with_split_f16:
         cmd.append("--with-split-f16")
+    if getattr(args, "critic_arith", "f32") != "f32":
+        cmd += ["--critic-arith", args.critic_arith]
     if getattr(args, "no_configs", False):
         cmd.append("--no-configs")
     if getattr(args, "scaling", "weak") != "weak":
@@ -793,6 +855,13 @@ def main():
                     help="add a second timed region with the agent option "
                          "critic_arith=f16x2 (split-f16 critic kernel: an "
                          "option, not the reported value)")
+    ap.add_argument("--critic-arith", choices=["f32", "bf16x3", "f16x2"],
+                    default="f32",
+                    help="arithmetic of the critic epochs of the TIMED steps "
+                         "(default f32 = the exact-fp32 matrix instructions, "
+                         "what `value` is quoted on; bf16x3 = three-part bf16 "
+                         "operands, 24 bits, csrc/mlpb.hip: the line then says "
+                         "so in `dtype` and `critic_arith`)")
     ap.add_argument("--no-split-f16", action="store_true",
                     help="accepted for older command lines (the default now)")
     ap.add_argument("--no-configs", action="store_true",
@@ -864,6 +933,7 @@ def main():
                          "over %d ranks" % (NUM_ENV, world))
     envs_per_rank = NUM_ENV // world if strong else NUM_ENV
     agent, cfg = build_agent(envs_per_rank * world, seed=0)
+    agent.critic_arith = args.critic_arith
     assert agent.sampler.num_env_train == envs_per_rank
     T = agent.sampler.num_times
 
@@ -945,7 +1015,7 @@ def main():
         for res in res16:
             pol16 += res["update_policy_time"]
         fast, _ = over_ranks([el16, pol16])
-        agent.critic_arith = "f32"
+        agent.critic_arith = args.critic_arith
 
     if rank == 0:
         env_steps = world * envs_per_rank * T * args.steps
@@ -973,7 +1043,9 @@ def main():
                  bal_ms) / agent.balance_check, 2),
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.critic_arith == "f32" else
+            "f32 (critic epochs: %s operands, fp32 accumulate)" % args.critic_arith,
+            "critic_arith": args.critic_arith, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: TCE, Metaworld-"
                        "reach-like synthetic env, 4096 envs per GPU, T 500, "
                        "P 24, dof 4, ProDMP 5 basis (K 24), 50 critic + 50 "

@@ -170,8 +170,10 @@ class EpochRunner:
     def __init__(self, mlp, flat=None, arith="f32"):
         """flat: gradient buffer to fill (the optimizer's flat gradient, in
         parameter order W1, b1, W2, b2, w3, b3); allocated if omitted.
-        arith: "f32" (exact-fp32 matrix cores, csrc/mlp.hip) or "f16x2" (split
-        f16 operands on the f16 matrix cores, csrc/mlp16.hip)."""
+        arith: "f32" (exact-fp32 matrix cores, csrc/mlp.hip), "bf16x3" (three-
+        part bf16 operands on the bf16 matrix cores, csrc/mlpb.hip: 24-bit
+        operands, fp32 range) or "f16x2" (split f16 operands on the f16 matrix
+        cores, csrc/mlp16.hip: 22-bit operands inside the f16 range)."""
         assert narrow_supported(mlp)
         assert arith in ("f32", "f16x2", "bf16x3"), arith
         self.arith = arith

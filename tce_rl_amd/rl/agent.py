@@ -357,10 +357,14 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # DirectEpoch): half the launches of an epoch
         self.direct_policy_epoch = kwargs.get("direct_policy_epoch", True)
         # arithmetic of the fused critic epoch: "f32" = exact-fp32 matrix cores
-        # (csrc/mlp.hip), "f16x2" = split-f16 operands on the f16 matrix cores
-        # (csrc/mlp16.hip: fp32-grade results, 2.4x faster)
+        # (csrc/mlp.hip); "bf16x3" = three-part bf16 operands on the bf16
+        # matrix cores (csrc/mlpb.hip: x = b0 + b1 + b2 exactly -- 24 bits,
+        # fp32's range -- six partial products, fp32 accumulate: as close to
+        # fp64 as the fp32 kernel, 1.4x faster); "f16x2" = split-f16 operands
+        # on the f16 matrix cores (csrc/mlp16.hip: 22-bit operands inside the
+        # f16 range, 2.4x faster)
         self.critic_arith = kwargs.get("critic_arith", "f32")
-        if self.critic_arith not in ("f32", "f16x2"):
+        if self.critic_arith not in ("f32", "f16x2", "bf16x3"):
             raise NotImplementedError("critic_arith %r" % (self.critic_arith,))
         self.critic_workgroups = int(kwargs.get(
             "critic_workgroups", os.environ.get("TCE_CRITIC_WORKGROUPS", 224)))

@@ -187,6 +187,14 @@ def test_agent_step_matches_cpu_oracle_split_f16_critic(overlap):
     _agent_vs_oracle(overlap, True, False, "metaworld", 5, critic_arith="f16x2")
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_agent_step_matches_cpu_oracle_bf16x3_critic(overlap):
+    """critic_arith="bf16x3" (three-part bf16 operands: 24 bits, fp32's range)
+    is held to the same tolerances against the CPU oracle as the exact-fp32
+    kernel."""
+    _agent_vs_oracle(overlap, True, False, "metaworld", 5, critic_arith="bf16x3")
+
+
 def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32",
                      iterations=1, rel_scale=1.0, num_env=16, epochs=3, **kw):
     from oracle.agent_oracle import OracleTCE

@@ -47,6 +47,14 @@ def test_c_abi_reports_bad_arguments():
         call("tce_mlp_critic_f16x2", ptr(x), 0, 8, 1, 1, 8, *([ptr(x)] * 6), 1,
              None, None, 0.0, ptr(x), None, None, None, 0, None, None, None,
              None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
+    with pytest.raises(RuntimeError, match="D_in"):
+        call("tce_mlp_critic_bf16x3", ptr(x), 0, 41, 1, 1, 41, *([ptr(x)] * 6),
+             1, ptr(x), None, 0.0, None, ptr(x), ptr(x), ptr(x), 0, None, None,
+             None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
+    with pytest.raises(RuntimeError, match="backward buffers"):
+        call("tce_mlp_critic_bf16x3", ptr(x), 0, 8, 1, 1, 8, *([ptr(x)] * 6), 1,
+             None, None, 0.0, ptr(x), None, None, None, 0, None, None, None,
+             None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, stream())
     with pytest.raises(RuntimeError, match="CU range"):
         import ctypes
         h = ctypes.c_void_p()
