@@ -220,13 +220,13 @@ __device__ inline void lds_barrier() {
 // ask the scheduler for N x (1 MFMA, V VALU instructions): the epilogue of the
 // previous row block rides in the issue slots the MFMAs of this one leave free
 // (an MFMA holds the issue port for 8 of its 16 cycles)
-template <int N, int ND, int V>
+template <int N, int ND, int V, int DPER = 1>
 __device__ inline void interleave() {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
-    if (i < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
-    __builtin_amdgcn_sched_group_barrier(0x002, V, 0);             // VALU
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
+    if (i * DPER < ND) __builtin_amdgcn_sched_group_barrier(0x100, DPER, 0);    // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x002, V, 0);                          // VALU
   }
 }
 
@@ -353,7 +353,10 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
   const float b3 = a.b3[0];
   const float inv_n = 1.f / (float)a.R;
 
-  // ---- X staging: thread -> (row tid >> 2, 16-feature chunk tid & 3)
+  // ---- X staging: thread -> (row tid >> 2, 16-feature chunk tid & 3): 16 scalar loads with
+  // clamped feature indices (float4 loads of the same chunks were tried: no faster, and the
+  // register allocation of the dH1 phase got worse); features >= D_in are masked when the
+  // image is written
   RowCursor cur(a, blockIdx.x, wave, lane >> 2);
   float xn[16];
   auto load_x = [&]() {
@@ -364,11 +367,13 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
       const int64_t ne = in ? cur.ne : cur.last_ne;
       const int t = in ? cur.t : cur.last_t;
       const float* xr = a.x + ne * a.env_stride + t * a.row_stride;
-      const int dl = fresh(din);                // (not a loop invariant: 16 hoisted 64-bit offsets otherwise)
+      {
+        const int dl = fresh(din);              // (not a loop invariant: 16 hoisted 64-bit offsets otherwise)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int f = 16 * xch + j;
-        xn[j] = xr[f < dl ? f : dl - 1];          // (masked in store_x: no use of the value here)
+        for (int j = 0; j < 16; ++j) {
+          const int f = 16 * xch + j;
+          xn[j] = xr[f < dl ? f : dl - 1];        // (masked in store_x: no use of the value here)
+        }
       }
     }
   };
@@ -398,9 +403,10 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
       }
     }
   };
+  auto advance_x = [&]() { cur.advance(a.T); };
   load_x();
   store_x();
-  cur.advance(a.T);
+  advance_x();
   __syncthreads();
 
 #ifdef MLPB_STAMP
@@ -430,15 +436,26 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
       const f32x4 bia0 = *reinterpret_cast<const f32x4*>(Bs + ub + 8 * g);
       const f32x4 bia1 = *reinterpret_cast<const f32x4*>(Bs + ub + 8 * g + 4);
       f32x4 acc[2][2];                           // [row block parity][unit block]
-      auto finish = [&](int nb) {
+      Frag hq[3];
+      // the epilogue of row block nb in NKB1 pieces: one unit block each (activation and
+      // the three-way split of its 4 units), the 16-byte stores with the last
+      auto finish = [&](int nb, int piece) {
         const f32x4* r = acc[nb & 1];
-        f32x4 h0, h1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          h0[i] = act_f<ACT>(r[0][i]);
-          h1[i] = act_f<ACT>(r[1][i]);
+        for (int mb = 0; mb < 2; ++mb)
+          if (NKB1 == 1 || mb == piece) {
+            f32x4 h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = act_f<ACT>(r[mb][i]);
+            split3(h[0], h[1], hq[0].r[2 * mb], hq[1].r[2 * mb], hq[2].r[2 * mb]);
+            split3(h[2], h[3], hq[0].r[2 * mb + 1], hq[1].r[2 * mb + 1], hq[2].r[2 * mb + 1]);
+          }
+        if (piece == NKB1 - 1) {
+          char* p = sm + OFF_H + (16 * nb + c) * PT + (ocol ^ swT);
+          *reinterpret_cast<Frag*>(p) = hq[0];
+          *reinterpret_cast<Frag*>(p + T_PART) = hq[1];
+          *reinterpret_cast<Frag*>(p + 2 * T_PART) = hq[2];
         }
-        st_row(sm + OFF_H, 16 * nb + c, ocol, swT, h0, h1);
       };
       Frag3 B[2];
       int bX[NKB1];
@@ -458,12 +475,12 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         f32x4* r = acc[nb & 1];
         if (kb == 0) { r[0] = bia0; r[1] = bia1; }
         mma6s(W1f[0][kb], W1f[1][kb], B[s & 1], r[0], r[0], r[1], r[1]);
-        if (kb == NKB1 - 1 && nb > 0) finish(nb - 1);
-        interleave<12, 3, 3>();
+        if (nb > 0) finish(nb - 1, kb);
+        interleave<12, 3, 4>();
         FENCE();
       }
-      FENCE();
-      finish(NRB - 1);
+#pragma unroll
+      for (int k = 0; k < NKB1; ++k) finish(NRB - 1, k);
     }
     STAMP(0)
     lds_barrier();                             // A: H1 image complete
@@ -618,11 +635,11 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
       auto finish = [&](int nb, int j) {
         const f32x4* r = acc[nb & 1];
         const Frag3& h = hp[nb & 1];
-        const float lo = (__uint_as_float(h.p[0].r[j] << 16) + __uint_as_float(h.p[1].r[j] << 16)) +
-                         __uint_as_float(h.p[2].r[j] << 16);
-        const float hi = (__uint_as_float(h.p[0].r[j] & 0xffff0000u) +
-                          __uint_as_float(h.p[1].r[j] & 0xffff0000u)) +
-                         __uint_as_float(h.p[2].r[j] & 0xffff0000u);
+        float lo = __uint_as_float(h.p[0].r[j] << 16), hi = __uint_as_float(h.p[0].r[j] & 0xffff0000u);
+        if (ACT != ACT_RELU && ACT != ACT_LEAKY) {   // (those two need the sign only: part 0 has it)
+          lo = (lo + __uint_as_float(h.p[1].r[j] << 16)) + __uint_as_float(h.p[2].r[j] << 16);
+          hi = (hi + __uint_as_float(h.p[1].r[j] & 0xffff0000u)) + __uint_as_float(h.p[2].r[j] & 0xffff0000u);
+        }
         const int mb = j >> 1, i0 = 2 * (j & 1);
         const float ea = r[mb][i0] * act_d<ACT>(lo);
         const float eb = r[mb][i0 + 1] * act_d<ACT>(hi);
@@ -665,7 +682,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         }
         if (kb == 1) {
 #pragma unroll
-          for (int q3 = 0; q3 < 3; ++q3)
+          for (int q3 = 0; q3 < ((ACT == ACT_RELU || ACT == ACT_LEAKY) ? 1 : 3); ++q3)
             hp[nb & 1].p[q3] = *reinterpret_cast<const Frag*>(sm + bHo + 16 * nb * PT + q3 * T_PART);
         }
       };
@@ -681,7 +698,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         mma6w(W2t[0][kb], rr.w0, W2t[1][kb], rr.w1, rr.b, r[0], r[0], r[1], r[1]);
         if (nb > 0) finish(nb - 1, kb);
         if (kb == 1) ld_b<PT, T_PART>(sm + OFF_H, 16 * nb + c, ocol, swT, hp[nb & 1]);
-        interleave<12, 12, 2>();
+        interleave<12, 14, 2, 2>();   // (the reads early in the step: they feed the next one)
         FENCE();
       }
 #pragma unroll
@@ -693,7 +710,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
     // the next tile's rows are fetched behind dW1 (nothing in this kernel is reloaded
     // from scratch any more, so no wait in front of an MFMA shares their counter)
     load_x();
-    cur.advance(a.T);
+    advance_x();
     // ---- dY1 over this wave's slice of the dY2 image (read back by this wave only), then
     // dW1[unit][f] += sum_b dY1[b][unit] X[b][f]: the rows of k-step 1 are written while
     // the MFMAs of k-step 0 run
