@@ -11,7 +11,10 @@ from test_mlp_gpu import make, torch_ref
 pytestmark = pytest.mark.gpu
 
 
-def run_case(act, din, N, T, seed=0, scale_x=1.0, scale_ret=3.0):
+ARITHS = ["bf16x3"]
+
+
+def run_case(act, din, N, T, seed=0, scale_x=1.0, scale_ret=3.0, arith="bf16x3"):
     from tce_rl_amd import critic_ops
     mlp = make(din, act, seed)
     D = din + 8
@@ -30,7 +33,7 @@ def run_case(act, din, N, T, seed=0, scale_x=1.0, scale_ret=3.0):
         ref = critic_ops.EpochRunner(mlp, arith="f32")
         ref.epoch(x, ret, old, clip)
         gf32 = [p.grad.clone() for p in mlp.parameters()]
-        run = critic_ops.EpochRunner(mlp, arith="bf16x3")
+        run = critic_ops.EpochRunner(mlp, arith=arith)
         stats = run.epoch(x, ret, old, clip).cpu()
         out.append((stats, l64, g64, g32, gf32,
                     [p.grad.clone() for p in mlp.parameters()]))
@@ -41,8 +44,9 @@ def run_case(act, din, N, T, seed=0, scale_x=1.0, scale_ret=3.0):
 @pytest.mark.parametrize("din,N,T", [(40, 7, 33), (21, 5, 64), (32, 3, 1),
                                      (17, 130, 10), (31, 9, 21), (39, 4, 70),
                                      (33, 3, 40), (1, 6, 11)])
-def test_bf16x3_epoch_vs_torch(act, din, N, T):
-    for stats, l64, g64, g32, gf32, grads in run_case(act, din, N, T):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_bf16x3_epoch_vs_torch(act, din, N, T, arith):
+    for stats, l64, g64, g32, gf32, grads in run_case(act, din, N, T, arith=arith):
         assert abs(stats[0].item() - l64.item()) <= 1e-5 * abs(l64.item()) + 1e-6
         gn2 = sum((gg.double() ** 2).sum() for gg in g64).item()
         assert abs(stats[1].item() - gn2) <= 1e-4 * gn2 + 1e-9
@@ -63,13 +67,15 @@ def test_bf16x3_epoch_vs_torch(act, din, N, T):
 @pytest.mark.parametrize("scale_x,scale_ret", [(1e-3, 1e-3), (30.0, 500.0),
                                                (1.0, 1e-4), (1e6, 1e8),
                                                (1e-12, 1e-10)])
-def test_bf16x3_operand_ranges(scale_x, scale_ret):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_bf16x3_operand_ranges(scale_x, scale_ret, arith):
     """No range restriction: bf16 parts have the exponent range of fp32, so
     operands far outside the f16 range (where the split-f16 kernel reports
     inf) and tiny ones keep their 24 bits."""
     for stats, l64, g64, g32, gf32, grads in run_case("relu", 40, 33, 50, seed=3,
                                                       scale_x=scale_x,
-                                                      scale_ret=scale_ret):
+                                                      scale_ret=scale_ret,
+                                                      arith=arith):
         assert abs(stats[0].item() - l64.item()) <= 1e-5 * abs(l64.item()) + 1e-30
         for gk, a, b in zip(grads, g64, g32):
             e = (gk.double() - a).abs().max().item()
@@ -78,7 +84,8 @@ def test_bf16x3_operand_ranges(scale_x, scale_ret):
             assert e <= 4 * e32 + 2e-5 * scale, (gk.shape, e, e32, scale)
 
 
-def test_bf16x3_c2_shape_is_as_close_to_fp64_as_the_fp32_kernel():
+@pytest.mark.parametrize("arith", ARITHS)
+def test_bf16x3_c2_shape_is_as_close_to_fp64_as_the_fp32_kernel(arith):
     """BASELINE C2 rows (4096 x 500, D_in 40): relative error of the whole
     flat gradient against an fp64 PyTorch reference -- the three-part kernel
     may not be further away than the exact-fp32 kernel (x 1.25 for the noise
@@ -95,7 +102,7 @@ def test_bf16x3_c2_shape_is_as_close_to_fp64_as_the_fp32_kernel():
     a = critic_ops.EpochRunner(mlp, arith="f32")
     sa = a.epoch(x, ret, ret, 0.0).cpu()
     ea = ((a.flat.double() - truth).norm() / truth.norm()).item()
-    b = critic_ops.EpochRunner(mlp, arith="bf16x3")
+    b = critic_ops.EpochRunner(mlp, arith=arith)
     sb = b.epoch(x, ret, ret, 0.0).cpu()
     eb = ((b.flat.double() - truth).norm() / truth.norm()).item()
     print("relative gradient error vs fp64: fp32 kernel %.3e, bf16x3 %.3e" % (ea, eb))
@@ -104,7 +111,8 @@ def test_bf16x3_c2_shape_is_as_close_to_fp64_as_the_fp32_kernel():
     assert abs(sa[0] - sb[0]).item() <= 2e-6 * abs(sa[0]).item()
 
 
-def test_bf16x3_values_output_and_workgroup_cap():
+@pytest.mark.parametrize("arith", ARITHS)
+def test_bf16x3_values_output_and_workgroup_cap(arith):
     """The launch can also emit the values; a capped grid (the 224-workgroup
     epochs beside the policy stream) gives the same gradient up to the
     summation order of the slabs."""
@@ -122,7 +130,7 @@ def test_bf16x3_values_output_and_workgroup_cap():
         grad, stats = torch.empty(P, device="cuda"), torch.zeros(4, device="cuda")
         vals = torch.empty(70000, device="cuda")
         ws = [ptr(p) for p in mlp.parameters()]
-        call("tce_mlp_critic_bf16x3", ptr(x), 0, 24, 70000, 70000, 24, *ws, 0,
+        call("tce_mlp_critic_" + arith, ptr(x), 0, 24, 70000, 70000, 24, *ws, 0,
              ptr(ret), None, 0.0, ptr(vals), ptr(partials), ptr(grad), ptr(stats),
              cap, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None,
              stream())
