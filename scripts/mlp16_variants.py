@@ -75,7 +75,7 @@ def run():
                      "P4 writes", "barrier P4", "-", "G: dW1", "G: barriers 1+2", "G: dW2", "G: barriers 3+4"]
             if KERNEL == "mlpb":
                 names = ["L1 + H1 image", "barrier A", "L2 + v partials", "barrier B",
-                         "loss + dY2 image", "barrier C", "dW2", "dH1 + dY1", "barrier D", "dY1 image + dW1", "barrier E", "X image", "barrier F", "-", "-", "tile head"]
+                         "loss + dY2 image", "barrier C", "dW2", "dH1 + dY1", "barrier D", "dY1 image + dW1", "barrier E", "X image", "barrier F", "dW1: row loads issued", "dW1: dY1 rows 0-31 written", "tile head"]
             tiles = (N * T // 64) // G
             for n_, v_ in zip(names, st):
                 print(f"    {n_:16s} {v_ / tiles:9.0f} counter units/tile")
