@@ -389,34 +389,40 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
       }
     }
   };
-  auto store_x = [&]() {
-    const int lf = fresh(lane);
-    const int xch = lf & 3, xrow = 16 * wave + (lf >> 2);
-    const bool xact = xch < 2 * NKB1;
-    if (xact) {
-      Frag p0[2], p1[2], p2[2];
+  // the three-way split of the fetched rows (VALU: rides behind the MFMAs of dW1) and, after
+  // everyone is done with the X image, their six 16-byte stores
+  Frag xq[3][2];
+  auto split_x = [&]() {
+    const int xch = fresh(lane) & 3;
+    if (xch < 2 * NKB1) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-        {
+        for (int i = 0; i < 4; ++i) {
           const int f = 16 * xch + 8 * h + 2 * i;
           split3(f < din ? xn[8 * h + 2 * i] : 0.f, f + 1 < din ? xn[8 * h + 2 * i + 1] : 0.f,
-                 p0[h].r[i], p1[h].r[i], p2[h].r[i]);
+                 xq[0][h].r[i], xq[1][h].r[i], xq[2][h].r[i]);
         }
+    }
+  };
+  auto store_x = [&]() {
+    const int lf = fresh(lane);
+    const int xch = lf & 3, xrow = 16 * wave + (lf >> 2);
+    if (xch < 2 * NKB1) {
       char* xb = sm + OFF_X + xrow * PX;
       const int sw = swzX(xrow);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int off = (32 * xch + 16 * h) ^ sw;
-        *reinterpret_cast<Frag*>(xb + off) = p0[h];
-        *reinterpret_cast<Frag*>(xb + X_PART + off) = p1[h];
-        *reinterpret_cast<Frag*>(xb + 2 * X_PART + off) = p2[h];
+        *reinterpret_cast<Frag*>(xb + off) = xq[0][h];
+        *reinterpret_cast<Frag*>(xb + X_PART + off) = xq[1][h];
+        *reinterpret_cast<Frag*>(xb + 2 * X_PART + off) = xq[2][h];
       }
     }
   };
   auto advance_x = [&]() { cur.advance(a.T); };
   load_x();
+  split_x();
   store_x();
   advance_x();
   __syncthreads();
@@ -748,8 +754,10 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         if (kb == 0) {
           st_row(sm + OFF_D, 32 + c, ocol, swD, e1v[0][2], e1v[1][2]);
           st_row(sm + OFF_D, 48 + c, ocol, swD, e1v[0][3], e1v[1][3]);
-          interleave<12 * NCB, 0, 2>();
+        } else {
+          split_x();                             // (the rows were requested a phase ago)
         }
+        interleave<12 * NCB, 0, 3>();
         FENCE();
       }
     }
