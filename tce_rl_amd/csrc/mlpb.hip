@@ -641,7 +641,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
     }
     STAMP(6)
     // ---- dH1^T[own units][rows] = W2^T dY2^T; dY1 = dH1 act'(H1) stays in registers
-    f32x4 e1v[2][NRB];
+    Frag dq[NRB][3];                             // dY1 of this lane's 8 units, split, per row block
     {
       LANE_ROLES();
       const int swT = swzT(c), swD = swzD(c);
@@ -661,8 +661,8 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         const int mb = j >> 1, i0 = 2 * (j & 1);
         const float ea = r[mb][i0] * act_d<ACT>(lo);
         const float eb = r[mb][i0 + 1] * act_d<ACT>(hi);
-        e1v[mb][nb][i0] = ea;
-        e1v[mb][nb][i0 + 1] = eb;
+        // (split at once, behind the MFMAs of the next block: after barrier D only stores are left)
+        split3(ea, eb, dq[nb][0].r[j], dq[nb][1].r[j], dq[nb][2].r[j]);
         gb1[mb][i0] += ea;
         gb1[mb][i0 + 1] += eb;
       };
@@ -737,8 +737,16 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
     {
       LANE_ROLES();
       const int swD = swzD(c), swDk = swzD(krow), swXk = swzX(krow);
-      st_row(sm + OFF_D, c, ocol, swD, e1v[0][0], e1v[1][0]);
-      st_row(sm + OFF_D, 16 + c, ocol, swD, e1v[0][1], e1v[1][1]);
+      auto st_dq = [&](int nb) {
+        char* p = sm + OFF_D + (16 * nb + c) * PT + (ocol ^ swD);
+        *reinterpret_cast<Frag*>(p) = dq[nb][0];
+        *reinterpret_cast<Frag*>(p + T_PART) = dq[nb][1];
+        *reinterpret_cast<Frag*>(p + 2 * T_PART) = dq[nb][2];
+      };
+      st_dq(0);
+      st_dq(1);
+      st_dq(2);
+      st_dq(3);
       FENCE();
       STAMP(14)
 #pragma unroll
@@ -751,12 +759,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
         FENCE();
 #pragma unroll
         for (int n = 0; n < NCB; ++n) mma6x2(a0, a1, b[n], gW1[0][n], gW1[1][n]);
-        if (kb == 0) {
-          st_row(sm + OFF_D, 32 + c, ocol, swD, e1v[0][2], e1v[1][2]);
-          st_row(sm + OFF_D, 48 + c, ocol, swD, e1v[0][3], e1v[1][3]);
-        } else {
-          split_x();                             // (the rows were requested a phase ago)
-        }
+        if (kb == 1) split_x();                    // (the rows were requested a phase ago)
         interleave<12 * NCB, 0, 3>();
         FENCE();
       }
