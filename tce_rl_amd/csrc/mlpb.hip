@@ -24,23 +24,38 @@
 // it around):
 //   * a workgroup is 4 waves, ONE per SIMD, 512 registers each; wave w owns the
 //     hidden units [32 w, 32 w + 32) of BOTH layers for the whole launch: its
-//     slices of W1, W2 and W2^T sit in registers as three-part A fragments
-//     (240 registers), its rows of dW1 / dW2 in accumulators (88);
-//   * activations live in LDS as [64 batch rows][units] images x 3 parts: X
-//     (two buffers), H1, and dY2 later overwritten by dY1.  Every wave reads ALL
-//     of an image as B fragments (16-byte row reads), computes its 32 units for
-//     the 64 rows of the tile and writes its slice of the next image.  The
-//     weight gradients contract over the batch: A (own dY slice) and B (H1, X)
-//     come back through the transpose read ds_read_b64_tr_b16, as in mlp16.hip;
+//     slices of W1 (three parts) and of W2 / W2^T (parts 0 and 1, pinned to the
+//     accumulation half of the register file, where the matrix core reads A
+//     operands from) never move; its rows of dW1 / dW2 sit in accumulators;
+//   * the THIRD parts of W2 are one [h2][h1] image in LDS (32 KB): row reads give
+//     the forward A fragments, transpose reads those of W2^T -- whose register
+//     parts, and dY2 as their B operand, follow the k order of the transpose
+//     read.  (All three parts in registers: 240 + 88 accumulators + the working
+//     set is 94 % of the register file; the allocator spilled 100 - 190.)
+//   * activations live in LDS as [64 batch rows][units] images x 3 parts: X, H1,
+//     and dY2 later overwritten by dY1.  Every wave reads ALL of an image as B
+//     fragments, computes its 32 units for the 64 rows of the tile and writes its
+//     slice of the next image.  The weight gradients contract over the batch: A
+//     (own dY slice) and B (H1, X) come back through ds_read_b64_tr_b16;
 //   * the unit a result row m of block mb stands for is 32 w + 8 (m >> 2) +
 //     4 mb + (m & 3): a lane then holds 8 CONSECUTIVE units of one batch row
 //     (both blocks) and stores them with one 16-byte write per part;
-//   * images sit at power-of-two pitches with XOR swizzles found by
-//     scripts/lds_banks.py (swizzle search: scripts/lds_swizzle_search.py):
-//     the 16-byte writes, the 16-byte row reads and the transpose reads are all
-//     bank-conflict free.
-//   Four workgroup barriers per tile: H1 image complete | per-row value
-//   partials complete | dY2 image complete | everyone done with H1 / dY2.
+//   * images sit at power-of-two pitches with XOR swizzles (scripts/lds_banks.py,
+//     scripts/lds_swizzle_search.py): the 16-byte writes, the row reads and the
+//     transpose reads of the activation images are bank-conflict free (the
+//     transpose reads of the W2 image: 2-way);
+//   * every lane role (c, g, q, pp, swizzles) is recomputed from the lane id where
+//     a phase starts (LANE_ROLES): as loop invariants they were two dozen
+//     registers the allocator spilled -- and a reload in front of an MFMA waits
+//     for EVERY outstanding load (one counter), the prefetched rows included.
+//   Six workgroup barriers per tile (LDS-only: fence "local" + s_barrier, so that
+//   the prefetched rows stay in flight): H1 image | value partials | dY2 image |
+//   H1 and dY2 free | X image free | next X image.  Inside a phase the LDS reads
+//   of the next step, the epilogue of the previous row block and the three-way
+//   splits ride between the MFMAs of the current step (sched_group_barrier).
+//   One wave per SIMD is issue-bound: an MFMA holds the port ~10 cycles, a VALU
+//   instruction beside it costs ~5 (scripts/probe_mfma_fill.hip) -- DESIGN.md
+//   section 4 has the cycle budget of a tile and what was tried.
 #include "mlp_shared.h"
 
 extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v,
@@ -127,8 +142,6 @@ __device__ inline u32x2 lds_tr64(const char* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 __device__ inline int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
-__device__ inline void pin_v(f32x4& v) { asm volatile("" : "+v"(v)); }
-__device__ inline void pin_a(f32x4& v) { asm volatile("" : "+a"(v)); }
 __device__ inline void pin_acc(Frag& f) {
   u32x4 v = {f.r[0], f.r[1], f.r[2], f.r[3]};
   asm volatile("" : "+a"(v));
@@ -259,9 +272,7 @@ void mlp_critic_bwdb_kernel(MlpArgs a) {
   const int din = a.din;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, g = lane >> 4;
-  const int q = (lane >> 2) & 3, pp = lane & 3;                // transpose-read roles
-  const int krow = 4 * g + q;
+  const int c = lane & 15, g = lane >> 4;                      // (prologue / epilogue; the phases recompute them)
   float* Bs = reinterpret_cast<float*>(sm + OFF_BS);
   float* vpart = reinterpret_cast<float*>(sm + OFF_VP);
   for (int e = tid; e < HID; e += MLP_BT) {
