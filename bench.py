@@ -153,6 +153,19 @@ def pmc_traffic(kernel):
     return pmc_lookup(kernel)[0]
 
 
+def mlpb_pmc(*keys):
+    """A value of the committed counter summary of the three-part bf16 critic
+    kernel (profiles/r05_pmc_mlpb.json: scripts/pmc_mlpb.sh), None if absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r05_pmc_mlpb.json")) as f:
+            v = json.load(f)
+        for k in keys:
+            v = v[k]
+        return v
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_source(kernel):
     return pmc_lookup(kernel)[1]
 
@@ -289,12 +302,14 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
             "frac": round(a_ / F16_MFMA_PEAK_TF, 4),
             "frac_issued": round(6 * a_ / F16_MFMA_PEAK_TF, 4),
             "of_fp32_mfma_peak": round(a_ / F32_MFMA_PEAK_TF, 3),
-            "traffic": None, "traffic_source": None,
+            "traffic": mlpb_pmc("hbm", "traffic_bytes"),
+            "traffic_source": "profiles/r05_pmc_mlpb.json",
             "isolated_back_to_back": {
                 "us_per_launch": round(us_cb, 1),
                 "achieved": round(flops / us_cb / 1e6, 2),
                 "frac": round(flops / us_cb / 1e6 / F16_MFMA_PEAK_TF, 4)},
-            "mfma_busy": None, "mfma_busy_source": None,
+            "mfma_busy": mlpb_pmc("mfma_busy"),
+            "mfma_busy_source": "profiles/r05_pmc_mlpb.json",
             "rocprof_us_per_launch": None, "rocprof_source": None,
             "frac_from_profile": None,
             "dtype": "bf16x3 operands (24 bits, fp32 range), six partial "
@@ -319,7 +334,9 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
         "bound": "mfma", "achieved": round(flops / us_cb / 1e6, 2),
         "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": round(flops / us_cb / 1e6 / F16_MFMA_PEAK_TF, 4),
-        "traffic": None,
+        "traffic": mlpb_pmc("hbm", "traffic_bytes"),
+        "traffic_source": "profiles/r05_pmc_mlpb.json",
+        "mfma_busy": mlpb_pmc("mfma_busy"),
         "us_per_launch": round(us_cb, 1),
         "algorithmic_flops": flops,
         "mfma_flops_issued": 6 * flops,

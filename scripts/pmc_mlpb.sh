@@ -10,3 +10,8 @@ for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS
   timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mlpb/p$i -o p -- python3 $GRAFT_REPO_ROOT/scripts/pmc_mlp.py bf16x3 > $GRAFT_REPO_ROOT/gpurun_out/pmc_mlpb_p$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i done"
 done
+# HBM bytes (separate passes, as MI355X_MICROARCH.md prescribes): FETCH_SIZE, WRITE_SIZE
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 120 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mlpb/$c -o p -- python3 $GRAFT_REPO_ROOT/scripts/pmc_mlp.py bf16x3 > $GRAFT_REPO_ROOT/gpurun_out/pmc_mlpb_$c.log 2>&1 || echo "pass $c failed"
+  echo "pass $c done"
+done
