@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, critic_arith="f32"):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
@@ -27,6 +27,7 @@ def _worker(rank, world, port, overlap, q):
     cfg = tce_config("metaworld", num_env=64, num_basis=5, epochs=3,
                      evaluation_interval=0, seed=0)
     cfg["params"]["agent"]["args"]["overlap_updates"] = overlap
+    cfg["params"]["agent"]["args"]["critic_arith"] = critic_arith
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)             # ... made equal by the broadcast
     agent = exp.agent
@@ -49,14 +50,18 @@ def _worker(rank, world, port, overlap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_stay_in_lock_step(overlap):
+@pytest.mark.parametrize("overlap,critic_arith", [(False, "f32"), (True, "f32"),
+                                                  (True, "bf16x3")])
+def test_two_ranks_stay_in_lock_step(overlap, critic_arith):
+    """(critic_arith bf16x3: the exchange behind csrc/mlpb.hip's slab reduction,
+    tce_mlp_critic_bf16x3(..., xchg).)"""
     import numpy as np
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + (50 if overlap else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q))
+    port = 29600 + (os.getpid() % 200) + (50 if overlap else 0) + \
+        (25 if critic_arith != "f32" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, critic_arith))
              for r in range(2)]
     for p in procs:
         p.start()
