@@ -925,7 +925,8 @@ def test_agent_options_match_cpu_oracle(opts):
                                                        rel=1e-12)
 
 
-def test_full_size_step_is_repeatable_and_inside_the_trust_region():
+@pytest.mark.parametrize("critic_arith", ["f32", "bf16x3"])
+def test_full_size_step_is_repeatable_and_inside_the_trust_region(critic_arith):
     """BASELINE configs[1] at full size (4096 envs, T 500, 50 + 50 epochs), the
     size-independent properties: two runs from the same seeds end bit-identical
     (every reduction has a fixed order, also with the critic, the policy and
@@ -938,7 +939,7 @@ def test_full_size_step_is_repeatable_and_inside_the_trust_region():
     for _ in range(2):
         torch.manual_seed(11)
         agent, cfg = build(4096, 50, True, num_basis=5,
-                           adaptive_critic_split=False)
+                           adaptive_critic_split=False, critic_arith=critic_arith)
         torch.manual_seed(12)
         res = [agent.step() for _ in range(2)][-1]
         runs.append((res, to_cpu_params(agent.policy.mean_net),
