@@ -8,6 +8,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 cfg = tce_config("metaworld", num_env=N, num_basis=5, epochs=epochs, evaluation_interval=0, iterations=iters)
+if len(sys.argv) > 4:                      # critic arithmetic: f32 | bf16x3 | f16x2
+    cfg["params"]["agent"]["args"]["critic_arith"] = sys.argv[4]
 exp = MPExperiment(); exp.initialize(cfg, 0, None)
 t = time.perf_counter()
 for i in range(iters):
