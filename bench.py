@@ -1107,6 +1107,21 @@ def main():
                 print("[bench] config %s: %.1f ms/step" % (
                     name, out["configs"][name]["ms_per_step"]),
                     file=sys.stderr, flush=True)
+            b3 = out["configs"].get("C2_bf16x3_critic")
+            if b3 and args.critic_arith == "f32":
+                # the same workload with the fp32-grade critic epochs on the bf16 matrix
+                # cores: beside `value` (exact-fp32 instructions), not instead of it
+                out["with_critic_arith_bf16x3"] = {
+                    "value": b3["env_steps_per_sec"], "unit": "env-steps/s",
+                    "ms_per_step": b3["ms_per_step"],
+                    "policy_updates_per_sec": b3.get("policy_updates_per_sec"),
+                    "see": "configs.C2_bf16x3_critic, roofline_extra.critic_bf16x3; "
+                           "`bench.py --critic-arith bf16x3` times the K steps of the "
+                           "headline with it (profiles/r05_bench_line_bf16x3.json)",
+                    "operands": "x = b0 + b1 + b2 exactly (3 bf16 parts: 24 bits, fp32 "
+                                "range), six partial products, fp32 accumulate; gradient "
+                                "error vs fp64 at C2: 1.65e-6 (exact-fp32 kernel: 2.02e-6; "
+                                "tests/test_mlpb_gpu.py)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
