@@ -664,6 +664,7 @@ def _run_config(name, spec, steps, warmup):
         # launch boundaries between them; nothing is throughput-bound
         floor_us = None
         if spec.get("chain_floor", True):
+            agent.close()
             del agent
             torch.cuda.empty_cache()
             tiny = build_config_agent(dict(spec, num_env=64))
@@ -718,6 +719,7 @@ def _run_config(name, spec, steps, warmup):
     out["library_gemm_calls"] = sum(mlp_ops.LIBRARY_CALLS.values())
     assert not mlp_ops.LIBRARY_CALLS, \
         "config %s reached library GEMMs: %r" % (name, mlp_ops.LIBRARY_CALLS)
+    agent.close()
     del agent
     torch.cuda.empty_cache()
     return out
@@ -783,6 +785,36 @@ def cpu_baseline():
                       % (n, dt, min(ts), max(ts), full)}
 
 
+def exchange_report_over_ranks(agent, is_dist):
+    """DistContext.exchange_report of every rank folded into one dict per
+    channel: kind, self-test (all ranks), wait per collective (max over ranks
+    of the mean and of the maximum, microseconds)."""
+    if not agent.dist.active:
+        return None
+    from tce_rl_amd import dist as tdist
+    mine = agent.dist.exchange_report()
+    every = [mine]
+    if is_dist and dist.get_world_size() > 1:
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, mine, group=tdist._boot_group())
+    out = {}
+    for ch in mine:
+        rows = [e.get(ch, {}) for e in every]
+        rep = {"kind": mine[ch]["kind"]}
+        if mine[ch]["kind"] == "xgmi-oneshot":
+            means = [r["wait_us_mean"] for r in rows
+                     if r.get("wait_us_mean") is not None]
+            rep.update({
+                "self_test": all(r.get("self_test") in (True, None)
+                                 for r in rows),
+                "collectives": mine[ch]["collectives"],
+                "wait_us_mean_max_over_ranks": max(means) if means else None,
+                "wait_us_max_over_ranks": max(
+                    r.get("wait_us_max", 0.0) for r in rows)})
+        out[ch] = rep
+    return out
+
+
 def _kill_tree(proc):
     """End the launcher child and everything it started (it runs in its own
     session, so its process group holds exactly its descendants)."""
@@ -799,61 +831,120 @@ def _kill_tree(proc):
             continue
 
 
+def _launch_attempts(base_env):
+    """The environments self_launch tries, in order: the
+    job as configured; the other HIP IPC mode (the in-library exchange and
+    RCCL both map peer memory through it, and which one a host driver supports
+    is the one assumption no one-GPU box can test); the configured IPC mode
+    with the gradients on torch.distributed all-reduces instead of the
+    in-library exchange."""
+    ipc = base_env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    other = "1" if ipc == "0" else "0"
+    return [("as configured", {}),
+            ("HSA_ENABLE_IPC_MODE_LEGACY=%s" % other,
+             {"HSA_ENABLE_IPC_MODE_LEGACY": other}),
+            ("TCE_EXCHANGE=rccl", {"TCE_EXCHANGE": "rccl"})]
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` from a plain shell (WORLD_SIZE unset): this
     process has not touched the GPU and never will -- it starts the N ranks as
     fresh children through torch.distributed.run (no exec), relays rank 0's
-    JSON line and returns the children's exit code.  The children get
+    JSON line and returns the children's exit code.
+
+    A child set that fails (non-zero exit, or no "warmup done" within
+    ``--startup-timeout`` seconds) BEFORE rank 0 has finished its warm-up steps
+    is replaced ONCE per entry of ``_launch_attempts`` by a fresh child set
+    with the next environment -- new processes, never a re-exec; the line
+    records which attempt produced it (``launch_attempt``).  A failure after
+    the warm-up is a real failure and is returned.  All attempts together get
     ``--launch-timeout`` seconds (default 900: a hung collective must not sit
-    until the driver's limit); past it the whole child tree is killed and the
-    exit code is 124."""
+    until the driver's limit); past it the child tree is killed and the exit
+    code is 124."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__),
-           "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup)]
+    import tempfile
+    base_cmd = ["--gpus", str(args.gpus), "--steps", str(args.steps),
+                "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
-        cmd.append("--no-cpu-baseline")
+        base_cmd.append("--no-cpu-baseline")
     if args.with_split_f16:
-        cmd.append("--with-split-f16")
+        base_cmd.append("--with-split-f16")
     if getattr(args, "critic_arith", "f32") != "f32":
-        cmd += ["--critic-arith", args.critic_arith]
+        base_cmd += ["--critic-arith", args.critic_arith]
     if getattr(args, "no_configs", False):
-        cmd.append("--no-configs")
+        base_cmd.append("--no-configs")
     if getattr(args, "scaling", "weak") != "weak":
-        cmd += ["--scaling", args.scaling]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+        base_cmd += ["--scaling", args.scaling]
+    base_env = dict(os.environ)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base_env.setdefault("OMP_NUM_THREADS", "4")
     limit = float(getattr(args, "launch_timeout", 900.0))
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
-                            start_new_session=True)
-    try:
-        stdout, _ = proc.communicate(timeout=limit)
-        rc = proc.returncode
-    except subprocess.TimeoutExpired:
-        print("[bench] the %d ranks did not finish within %.0f s: killing "
-              "the child tree" % (args.gpus, limit), file=sys.stderr)
-        _kill_tree(proc)
-        try:
-            stdout, _ = proc.communicate(timeout=10)
-        except Exception:
-            stdout = b""
-        rc = 124
-    except BaseException:
-        _kill_tree(proc)
-        raise
-    line = None
-    for ln in (stdout or b"").decode(errors="replace").splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-        else:
-            print(ln, file=sys.stderr)
+    startup = float(getattr(args, "startup_timeout", 300.0))
+    deadline = time.monotonic() + limit
+    attempts = _launch_attempts(base_env)
+    if os.environ.get("TCE_BENCH_NO_RETRY") == "1":
+        attempts = attempts[:1]
+    rc, line = 1, None
+    scratch = tempfile.mkdtemp(prefix="tce_bench_")
+    for no, (label, extra) in enumerate(attempts, 1):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + base_cmd
+        sentinel = os.path.join(scratch, "warm_%d" % no)
+        env = dict(base_env)
+        env.update(extra)
+        env["TCE_BENCH_SENTINEL"] = sentinel
+        env["TCE_BENCH_LAUNCH_ATTEMPT"] = "%d: %s" % (no, label)
+        out_path = os.path.join(scratch, "stdout_%d" % no)
+        timed_out = False
+        with open(out_path, "wb") as out_f:
+            proc = subprocess.Popen(cmd, env=env, stdout=out_f,
+                                    start_new_session=True)
+            t_start = time.monotonic()
+            try:
+                while proc.poll() is None:
+                    now = time.monotonic()
+                    warm = os.path.exists(sentinel)
+                    if now > deadline or (not warm and
+                                          now - t_start > startup):
+                        timed_out = True
+                        print("[bench] attempt %d (%s): the %d ranks %s: "
+                              "killing the child tree" % (
+                                  no, label, args.gpus,
+                                  "did not finish within %.0f s" % limit
+                                  if now > deadline else
+                                  "had not finished their warm-up after "
+                                  "%.0f s" % startup),
+                              file=sys.stderr, flush=True)
+                        _kill_tree(proc)
+                        break
+                    time.sleep(0.2)
+            except BaseException:
+                _kill_tree(proc)
+                raise
+            rc = 124 if timed_out else proc.returncode
+        line = None
+        with open(out_path, "rb") as f:
+            for ln in f.read().decode(errors="replace").splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    line = ln
+                else:
+                    print(ln, file=sys.stderr)
+        warm = os.path.exists(sentinel)
+        if rc == 0 or warm or time.monotonic() > deadline:
+            break
+        if no < len(attempts):
+            print("[bench] attempt %d (%s) ended with exit code %d before the "
+                  "warm-up was done: starting a fresh child set (%s)"
+                  % (no, label, rc, attempts[no][0]), file=sys.stderr,
+                  flush=True)
+    import shutil
+    shutil.rmtree(scratch, ignore_errors=True)
     if line is not None and rc == 0:
         print(line, flush=True)
     elif rc == 0:
@@ -892,6 +983,10 @@ def main():
                          "4096 / N per GPU (SURVEY 8d)")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="seconds the self-launched ranks may take")
+    ap.add_argument("--startup-timeout", type=float, default=300.0,
+                    help="seconds a self-launched child set may take until "
+                         "rank 0 has finished its warm-up steps; past it the "
+                         "set is killed and the next launch attempt starts")
     ap.add_argument("--collective-timeout", type=float, default=120.0,
                     help="seconds a collective may take before the process "
                          "group aborts (a hang must not sit until the "
@@ -982,8 +1077,12 @@ def main():
     barrier()
     if rank == 0:
         print("[bench] warmup done", file=sys.stderr, flush=True)
+        if os.environ.get("TCE_BENCH_SENTINEL"):
+            # (self_launch: a failure from here on is not a launch problem)
+            open(os.environ["TCE_BENCH_SENTINEL"], "w").close()
     agent.dist.check_exchanges()
     tdist.reset_stats()
+    agent.dist.reset_wait_stats()
     # marks in the kernel trace around the timed steps (scripts/rocpd_stats.py
     # --between-markers 1 2: the committed profile covers exactly this window)
     from tce_rl_amd import _lib as tlib
@@ -1006,6 +1105,7 @@ def main():
     agent.dist.check_exchanges()        # (a wait that ran into its limit is fatal)
     coll = tdist.stats()                # torch.distributed + in-library collectives
     (elapsed, pol_time), per_rank = over_ranks([elapsed, pol_time])
+    xreport = exchange_report_over_ranks(agent, is_dist)
     # one iteration in `balance_check` (25) carries the policy balance check:
     # timed by itself, outside the K steps
     bal_ms = None
@@ -1081,6 +1181,17 @@ def main():
             # exchange inside the finish kernels (csrc/xchg.h), "rccl" =
             # torch.distributed all-reduces between the C calls
             "gradient_exchange": agent.dist.exchange_kind(),
+            # per channel (critic / policy gradients, the small per-step
+            # collectives): the start-up self-test's result and how long
+            # workgroup 0 of a collective waited for its slowest peer
+            # (device clock inside xchg_sync, csrc/xchg.h) -- mean per
+            # collective and maximum, each the MAX over ranks; what a
+            # straggler costs is readable from this line alone
+            "exchange": xreport,
+            "launch_attempt": os.environ.get("TCE_BENCH_LAUNCH_ATTEMPT",
+                                             "driver-launched"),
+            "hsa_ipc_mode_legacy": os.environ.get(
+                "HSA_ENABLE_IPC_MODE_LEGACY"),
             "collectives_per_step": round(coll["collectives"] / args.steps, 1),
             "collective_bytes_per_step": round(coll["bytes"] / args.steps),
             "roofline": roof, "roofline_extra": extra,
@@ -1098,6 +1209,7 @@ def main():
                     EPOCHS * args.steps / fast[1], 2),
                 "roofline": extra["critic_split_f16"]}
         if world == 1 and not args.no_configs:
+            agent.close()
             del agent
             torch.cuda.empty_cache()
             out["configs"] = {}
@@ -1127,6 +1239,8 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if is_dist:
+        if "agent" in locals():
+            agent.close()               # (collective: buffers, IPC mappings)
         tdist.host_barrier()
         dist.destroy_process_group()
 

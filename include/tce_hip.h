@@ -842,6 +842,10 @@ int tce_adam_once_f64(double* param, const double* grad, double* m, double* v, i
  *     (TCE_XCHG_TIMEOUT_MS, default 20000; tce_xchg_set_timeout_ms): the
  *     kernel goes on instead of hanging, the caller must treat it as fatal.
  *   tce_xchg_counters: collectives issued and payload bytes, per rank.
+ *   tce_xchg_wait_stats: how long workgroup 0 of this rank's collectives waited
+ *     for its slowest peer since the last reset (sum / maximum in microseconds,
+ *     number of collectives): what a straggler costs, per exchange.  Blocking
+ *     (a device -> host copy of four words); reset != 0 clears the words.
  *   tce_xchg_allreduce_*: in-place sum over ranks of buf [n], rank order.
  *   tce_xchg_allgather_f64: out [world][n] = every rank's mine [n] (one
  *     workgroup; the small per-step statistics of a sharded run).
@@ -861,6 +865,7 @@ int tce_xchg_destroy(void* xchg);
 int tce_xchg_status(void* xchg);
 int tce_xchg_set_timeout_ms(void* xchg, double ms);
 int tce_xchg_counters(void* xchg, int64_t* collectives, int64_t* bytes);
+int tce_xchg_wait_stats(void* xchg, double* total_us, double* max_us, int64_t* collectives, int reset);
 int tce_xchg_allgather_f64(void* xchg, const double* mine, double* out, int64_t n, void* stream);
 int tce_xchg_allreduce_f32(void* xchg, float* buf, int64_t n, void* stream);
 int tce_xchg_allreduce_f64(void* xchg, double* buf, int64_t n, void* stream);

@@ -40,16 +40,22 @@ __host__ __device__ inline size_t pl_lds_reals(const PLShape& s, bool bwd) {
   return n;
 }
 
-template <typename real, bool BWD>
+// io = the dtype of the buffers, real = double: as in pair_prep_kernel below, the
+// small-matrix arithmetic (M, C, Cholesky, solves, and with them the backward
+// products) runs in double also for float32 buffers -- C is nearly singular and
+// float32 there costs 1 - 3e-5 of max |logp|.  The basis rows
+// stay in the buffers' precision (they are not what limits it).
+template <typename io, typename real, bool BWD>
 __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
-    const real* __restrict__ traj, const real* __restrict__ mean,
-    const real* __restrict__ L, int64_t sL, const int64_t* __restrict__ pairs,
-    const real* __restrict__ B, const int* __restrict__ nonuniform,
-    MPParams<real> mp, const real* __restrict__ times, int times_general,
-    const real* __restrict__ t0, const real* __restrict__ y0,
-    const real* __restrict__ v0, real reg, real* __restrict__ logp,
-    const real* __restrict__ gout, real* __restrict__ gmean,
-    real* __restrict__ gL, int T, PLShape s, int skip_if_uniform) {
+    const io* __restrict__ traj, const io* __restrict__ mean,
+    const io* __restrict__ L, int64_t sL, const int64_t* __restrict__ pairs,
+    const io* __restrict__ B, const int* __restrict__ nonuniform,
+    MPParams<io> mp, const io* __restrict__ times, int times_general,
+    const io* __restrict__ t0, const io* __restrict__ y0,
+    const io* __restrict__ v0, io reg_io, io* __restrict__ logp,
+    const io* __restrict__ gout, io* __restrict__ gmean,
+    io* __restrict__ gL, int T, PLShape s, int skip_if_uniform) {
+  const real reg = (real)reg_io;
   if (skip_if_uniform && !times_general && *nonuniform == 0) return;   // fast path ran
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   real* smem = reinterpret_cast<real*>(smem_raw);
@@ -68,24 +74,24 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
 
   const int tid = threadIdx.x;
   const int64_t n = blockIdx.x;
-  const real* Ln = L + n * sL;
+  const io* Ln = L + n * sL;
   const bool general = times_general || (*nonuniform != 0);
 
   for (int i = tid; i < K * K; i += PL_BT) {
     const int r = i / K, c = i - r * K;
-    Ls[r * KP + c] = (c <= r) ? Ln[i] : real(0);
+    Ls[r * KP + c] = (c <= r) ? (real)Ln[i] : real(0);
   }
-  for (int i = tid; i < K; i += PL_BT) ms[i] = mean[n * K + i];
+  for (int i = tid; i < K; i += PL_BT) ms[i] = (real)mean[n * K + i];
   for (int i = tid; i < P * 2; i += PL_BT) {
     const int ti = (int)pairs[i];          // pairs[p][j], i = 2p + j
-    real row[TCE_ROWLEN];
+    io row[TCE_ROWLEN];
     if (general) prodmp_row(mp, times[n * T + ti], t0[n], row);
     else mp_row_load(B + (int64_t)ti * (4 + 2 * nbg), nbg, row);
 #pragma unroll
     for (int b = 0; b < TCE_MAXB; ++b)
-      if (b < nbg) Hs[i * nbg + b] = row[4 + b];
-    cs[i * 2 + 0] = row[0];
-    cs[i * 2 + 1] = row[1];
+      if (b < nbg) Hs[i * nbg + b] = (real)row[4 + b];
+    cs[i * 2 + 0] = (real)row[0];
+    cs[i * 2 + 1] = (real)row[1];
   }
 
   // backward accumulators: entry e = tid + i*256 of the K x K gradient
@@ -113,12 +119,12 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
       const int d = r >> 1, j = r & 1;
       const int pj = (p0 + pc) * 2 + j;
       const real* h = Hs + pj * nbg;
-      real mu = cs[pj * 2] * y0[n * dof + d] + cs[pj * 2 + 1] * v0[n * dof + d];
+      real mu = cs[pj * 2] * (real)y0[n * dof + d] + cs[pj * 2 + 1] * (real)v0[n * dof + d];
       for (int b = 0; b < nbg; ++b) mu += h[b] * ms[d * nbg + b];
-      const real y = traj[(n * T + (int)pairs[pj]) * (int64_t)(2 * dof) + d];
+      const real y = (real)traj[(n * T + (int)pairs[pj]) * (int64_t)(2 * dof) + d];
       dv[i] = y - mu;
     }
-    if (BWD) for (int i = tid; i < npc; i += PL_BT) gs[i] = gout[n * P + p0 + i];
+    if (BWD) for (int i = tid; i < npc; i += PL_BT) gs[i] = (real)gout[n * P + p0 + i];
     __syncthreads();
     // 2. C = M M^T + reg I (lower triangle)
     for (int i = tid; i < npc * R * R; i += PL_BT) {
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
       }
       if (!BWD)
         logp[n * P + p0 + tid] =
-            real(-0.5) * quad - logdet - real(0.5) * (real)R * real(1.8378770664093453);
+            (io)(real(-0.5) * quad - logdet - real(0.5) * (real)R * real(1.8378770664093453));
     }
     if (BWD) {
       __syncthreads();
@@ -249,9 +255,9 @@ __global__ __launch_bounds__(PL_BT) void pair_logprob_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int e = tid + i * PL_BT;
-      if (e < K * K) gL[n * (int64_t)K * K + e] = accL[i];
+      if (e < K * K) gL[n * (int64_t)K * K + e] = (io)accL[i];
     }
-    if (tid < K) gmean[n * K + tid] = accm;
+    if (tid < K) gmean[n * K + tid] = (io)accm;
   }
 }
 
@@ -296,19 +302,30 @@ __host__ __device__ inline int pf_ws_pair(const PFShape& s) {          // reals 
 // loops -- as until round 3 -- every term was an L2 round trip of its own, K of
 // them in a row per element of C; the kernel sits on the critical path of every
 // policy epoch: 67 us at K 24, 91 us at K 63 beside the critic)
+// Everything between the factor L and the pair's record -- M = H_p L,
+// C = M M^T + reg I, its Cholesky factor, the inverse factor, C^-1, log det --
+// is formed in DOUBLE, also for float32 I/O (round 6): C is nearly singular by
+// construction (reg = 1e-4 under variances of order one, and the trajectory
+// variance vanishes towards the initial condition), and forming / factoring it
+// in float32 is what put the float32 log-prob 1 - 3e-5 of max |logp| away from
+// the float64 value (scripts/probe_logp_tol.py; the reference's own float32
+// result sits there too).  With this kernel in double the record's rounding to
+// float32 and the float32 per-env arithmetic leave <= 6e-7.
+// 24 workgroups per launch: the double arithmetic costs nothing measurable.
 template <typename real>
 __global__ __launch_bounds__(256) void pair_prep_kernel(
     const real* __restrict__ L, const int64_t* __restrict__ pairs, const real* __restrict__ B,
     const int* __restrict__ nonuniform, real reg, real* __restrict__ ws, PFShape s) {
   if (*nonuniform != 0) return;
+  typedef double wide;
   extern __shared__ __attribute__((aligned(16))) char prep_raw[];
-  __shared__ real C[PL_MAXR][PL_MAXR + 1];
-  __shared__ real X[PL_MAXR][PL_MAXR + 1];
-  __shared__ real Hl[2 * TCE_MAXB];
+  __shared__ wide C[PL_MAXR][PL_MAXR + 1];
+  __shared__ wide X[PL_MAXR][PL_MAXR + 1];
+  __shared__ wide Hl[2 * TCE_MAXB];
   const int K = s.K, R = s.R, nbg = s.nbg;
   const int KP = pl_pitch(K);
-  real* Ls = reinterpret_cast<real*>(prep_raw);     // [K][KP]
-  real* Ms = Ls + K * KP;                            // [R][KP]
+  wide* Ls = reinterpret_cast<wide*>(prep_raw);     // [K][KP]
+  wide* Ms = Ls + K * KP;                            // [R][KP]
   const int p = blockIdx.x, tid = threadIdx.x;
   real* w = ws + (int64_t)p * pf_ws_pair(s);
   real* Hs = w;                       // [2][nbg]
@@ -319,71 +336,71 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(
   real* ld = Ci + R * R;              // logdet
   for (int e = tid; e < K * K; e += 256) {
     const int r = e / K, c = e - r * K;
-    Ls[r * KP + c] = L[e];
+    Ls[r * KP + c] = (wide)L[e];
   }
   if (tid < 2 * nbg) {
     const int j = tid / nbg, b = tid - j * nbg;
     const real h = B[pairs[2 * p + j] * (4 + 2 * nbg) + 4 + b];
     Hs[tid] = h;
-    Hl[tid] = h;
+    Hl[tid] = (wide)h;
   }
   if (tid < 4) cs[tid] = B[pairs[2 * p + (tid >> 1)] * (4 + 2 * nbg) + (tid & 1)];
   __syncthreads();
   for (int e = tid; e < R * K; e += 256) {
     const int r = e / K, k = e - r * K;
     const int d = r >> 1, j = r & 1;
-    real acc = 0;
+    wide acc = 0;
     for (int b = 0; b < nbg; ++b) {
       const int row = d * nbg + b;
       if (k <= row) acc += Hl[j * nbg + b] * Ls[row * KP + k];
     }
     Ms[r * KP + k] = acc;
-    M[e] = acc;
+    M[e] = (real)acc;
   }
   __syncthreads();
   for (int e = tid; e < R * R; e += 256) {
     const int r = e / R, c = e - r * R;
-    real acc = 0;
+    wide acc = 0;
     for (int k = 0; k < K; ++k) acc += Ms[r * KP + k] * Ms[c * KP + k];
-    C[r][c] = acc + (r == c ? reg : real(0));
+    C[r][c] = acc + (r == c ? (wide)reg : wide(0));
   }
   __syncthreads();
   if (tid < 64) {
     // Cholesky, column by column, lane i = row i (R <= 16): the same sums in the
     // same order as one thread would form them, R dependent steps instead of
     // R^3 / 6 (the kernel sits on the critical path of every policy epoch)
-    real logdet = 0;
+    wide logdet = 0;
     for (int j = 0; j < R; ++j) {
-      real v = 0;
+      wide v = 0;
       if (tid >= j && tid < R) {
         v = C[tid][j];
         for (int k = 0; k < j; ++k) v -= C[tid][k] * C[j][k];
       }
-      const real ljj = sqrt(__shfl(v, j, 64));
+      const wide ljj = sqrt(__shfl(v, j, 64));
       logdet += log(ljj);
       if (tid == j) C[j][j] = ljj;
       else if (tid > j && tid < R) C[tid][j] = v / ljj;
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
-    if (tid == 0) ld[0] = logdet;
+    if (tid == 0) ld[0] = (real)logdet;
   }
   __syncthreads();
   if (tid < R) {                       // column tid of Lc^-1
     const int c = tid;
     for (int r = 0; r < R; ++r) {
-      real v = (r == c) ? real(1) : real(0);
+      wide v = (r == c) ? wide(1) : wide(0);
       for (int k = c; k < r; ++k) v -= C[r][k] * X[k][c];
-      X[r][c] = (r < c) ? real(0) : v / C[r][r];
+      X[r][c] = (r < c) ? wide(0) : v / C[r][r];
     }
   }
   __syncthreads();
   for (int e = tid; e < R * R; e += 256) {
     const int r = e / R, c = e - r * R;
-    Li[e] = X[r][c];
-    real acc = 0;
+    Li[e] = (real)X[r][c];
+    wide acc = 0;
     for (int m = (r > c ? r : c); m < R; ++m) acc += X[m][r] * X[m][c];
-    Ci[e] = acc;
+    Ci[e] = (real)acc;
   }
 }
 
@@ -875,7 +892,7 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
     real* spart = wsp + (int64_t)P * pf_ws_pair(f);        // [nblk][P][R*R+1]
     if (!prep_ready) {
       hipLaunchKernelGGL(pair_prep_kernel<real>, dim3(P), dim3(256),
-                         (size_t)(K + f.R) * pl_pitch(K) * sizeof(real), stream, L, pairs, B,
+                         (size_t)(K + f.R) * pl_pitch(K) * sizeof(double), stream, L, pairs, B,
                          flag, reg, wsp, f);
       TCE_LAUNCH_CHECK();
     }
@@ -933,10 +950,11 @@ int pl_launch(bool bwd, const real* traj, const real* mean, const real* L, int64
 
   PLShape s{K, 2 * dof, P, P, nbg, dof};
   const size_t budget = 60 * 1024;
-  while (s.PC > 1 && pl_lds_reals(s, bwd) * sizeof(real) > budget) --s.PC;
-  const size_t lds = pl_lds_reals(s, bwd) * sizeof(real);
+  while (s.PC > 1 && pl_lds_reals(s, bwd) * sizeof(double) > budget) --s.PC;
+  const size_t lds = pl_lds_reals(s, bwd) * sizeof(double);
   TCE_CHECK_ARG(lds <= 150 * 1024, "pair_logprob: problem too large for LDS");
-  auto kern = bwd ? pair_logprob_kernel<real, true> : pair_logprob_kernel<real, false>;
+  auto kern = bwd ? pair_logprob_kernel<real, double, true>
+                  : pair_logprob_kernel<real, double, false>;
   if (lds > 48 * 1024)
     tce_lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds));
   TCE_CHECK_ARG(N < (1ll << 31), "pair_logprob: too many envs");

@@ -40,6 +40,10 @@ struct XchgView {
   unsigned long long limit;        // wall_clock64 ticks (100 MHz) a wait may take
   int* status;                     // host-mapped word: 0 ok, 1 + peer that timed out
   double* partial;                 // [XCHG_MAX_BLOCKS] per-workgroup scratch (|g|^2 partial sums)
+  // wait telemetry (device memory, 4 words): [0] += ticks workgroup 0 spent
+  // waiting for its slowest peer, [1] = max over collectives of that, [2] += 1
+  // per collective, [3] scratch.  100 MHz ticks; read by tce_xchg_wait_stats.
+  unsigned long long* wait;
 };
 
 inline XchgView xchg_none() {
@@ -48,6 +52,7 @@ inline XchgView xchg_none() {
   v.rank = 0; v.world = 1; v.seq = 0; v.flag_off = v.data_off = 0; v.limit = 0;
   v.status = nullptr;
   v.partial = nullptr;
+  v.wait = nullptr;
   return v;
 }
 
@@ -105,6 +110,21 @@ __device__ inline void xchg_sync(const XchgView& X, int block) {
           __hip_atomic_store(X.status, 1 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
+    }
+    // how long the slowest peer kept workgroup 0 waiting (one straggler's
+    // jitter is everyone's: the N > 1 line reports it per exchange)
+    if (block == 0 && X.wait) {
+      const unsigned long long dt = wall_clock64() - t0;
+      atomicMax(X.wait + 3, dt);           // scratch: max over the peers of THIS collective
+    }
+  }
+  if (block == 0 && X.wait) {
+    __syncthreads();
+    if (t == 0) {
+      const unsigned long long w = atomicExch(X.wait + 3, 0ull);
+      X.wait[0] += w;
+      if (w > X.wait[1]) X.wait[1] = w;
+      X.wait[2] += 1;
     }
   }
   __syncthreads();

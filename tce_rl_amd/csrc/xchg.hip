@@ -25,6 +25,7 @@ struct Xchg {
   int64_t n_coll = 0, n_bytes = 0;
   double* partial = nullptr;             // scratch of xchg_adam_kernel
   unsigned* ticket = nullptr;
+  unsigned long long* wait = nullptr;    // telemetry words of xchg_sync (csrc/xchg.h)
 };
 
 #define X_HIP(call)                                                     \
@@ -195,6 +196,7 @@ int xchg_next(void* xv, int64_t bytes, int blocks, XchgView* out) {
   out->limit = x->limit;
   out->status = x->status_dev;
   out->partial = x->partial;
+  out->wait = x->wait;
   return 0;
 }
 
@@ -233,6 +235,8 @@ int tce_xchg_create(int rank, int world, int64_t max_bytes, void** out) {
   X_HIP(hipMalloc((void**)&x->partial, sizeof(double) * XCHG_MAX_BLOCKS));
   X_HIP(hipMalloc((void**)&x->ticket, 64));
   X_HIP(hipMemset(x->ticket, 0, 64));
+  X_HIP(hipMalloc((void**)&x->wait, 64));
+  X_HIP(hipMemset(x->wait, 0, 64));
   X_HIP(hipDeviceSynchronize());
   const char* ms = getenv("TCE_XCHG_TIMEOUT_MS");
   const double lim_ms = ms ? atof(ms) : 20000.0;
@@ -289,6 +293,7 @@ int tce_xchg_destroy(void* xv) {
   if (x->status_host) (void)hipHostFree(x->status_host);
   if (x->partial) (void)hipFree(x->partial);
   if (x->ticket) (void)hipFree(x->ticket);
+  if (x->wait) (void)hipFree(x->wait);
   delete x;
   return 0;
 }
@@ -311,6 +316,22 @@ int tce_xchg_counters(void* xv, int64_t* collectives, int64_t* bytes) {
   Xchg* x = static_cast<Xchg*>(xv);
   *collectives = x->n_coll;
   *bytes = x->n_bytes;
+  return 0;
+}
+
+// How long workgroup 0 of this rank's collectives waited for its slowest peer
+// since the last reset: sum and maximum in microseconds, number of collectives.
+// Waits for the device (a blocking copy of the four telemetry words).
+int tce_xchg_wait_stats(void* xv, double* total_us, double* max_us, int64_t* collectives,
+                        int reset) {
+  TCE_CHECK_ARG(xv && total_us && max_us && collectives, "xchg_wait_stats: null argument");
+  Xchg* x = static_cast<Xchg*>(xv);
+  unsigned long long w[4] = {0, 0, 0, 0};
+  X_HIP(hipMemcpy(w, x->wait, sizeof(w), hipMemcpyDeviceToHost));
+  *total_us = (double)w[0] * 1e-2;                          // 100 MHz ticks
+  *max_us = (double)w[1] * 1e-2;
+  *collectives = (int64_t)w[2];
+  if (reset) X_HIP(hipMemset(x->wait, 0, 64));
   return 0;
 }
 
@@ -368,8 +389,10 @@ int xchg_adam(void* xv, real* param, real* grad, real* m, real* v, int64_t n, re
   if (clip > real(0)) {
     // the clip factor needs the norm of the WHOLE summed gradient before any
     // element is applied: all-reduce, then the one-launch step
-    if (xchg_allreduce<real>(xv, grad, grad, n, st)) return 1;
+    // (checked BEFORE the collective is issued: a caller that falls back on the
+    // error must find grad untouched and the sequence numbers in step)
     TCE_CHECK_ARG(n <= (1 << 17), "xchg_adam: clipping needs n <= 2^17 (tce_adam_once)");
+    if (xchg_allreduce<real>(xv, grad, grad, n, st)) return 1;
     return adam_once_any(param, grad, m, v, n, state, norms_out, step, lr, b1, b2, eps, wd, clip,
                          gscale, stream);
   }

@@ -64,34 +64,49 @@ def _count(t):
 # communicator stream is ever created by it.  The aux collectives are issued
 # from whatever stream is current; an event chain keeps them in stream order
 # (csrc/xchg.h: one exchange, one stream order on every rank).
-_AUX = {"x": None, "group": None, "event": None}
+# One aux exchange per set of ranks, shared (reference-counted) by every
+# DistContext over those ranks: a process that builds several agents under one
+# process group (bench `configs`, the tests) neither leaks a buffer + W - 1 IPC
+# mappings per agent nor has an earlier agent silently ride on a later agent's
+# exchange.
+_AUX = {}                           # ranks tuple -> {"x", "event", "refs"}
 _AUX_ELEMS = 1 << 16
 
 
-def set_aux(xchg, group=None):
-    _AUX["x"], _AUX["group"], _AUX["event"] = xchg, group, None
+def _group_key(group=None):
+    """The ranks of `group` (None: the default group) as a tuple."""
+    if group is None:
+        return tuple(range(dist.get_world_size()))
+    return tuple(dist.get_process_group_ranks(group))
+
+
+def _aux_slot(group):
+    if not _AUX or not (dist.is_available() and dist.is_initialized()):
+        return None
+    return _AUX.get(_group_key(group))
 
 
 def _aux_for(t, group):
-    x = _AUX["x"]
-    if x is None or not x.handle or not t.is_cuda or group is not _AUX["group"]:
+    slot = _aux_slot(group)
+    if slot is None or not t.is_cuda:
         return None
-    return x
+    x = slot["x"]
+    return x if x is not None and x.handle else None
 
 
 def _aux_gather(x, t):
     """[world, n] float64 = every rank's t (flattened): ONE launch."""
     import torch
     cur = torch.cuda.current_stream()
-    if _AUX["event"] is not None:
-        cur.wait_event(_AUX["event"])
+    if x.order_event is not None:
+        cur.wait_event(x.order_event)
     mine = t.reshape(-1).to(torch.float64).contiguous()
     out = torch.empty(x.world, mine.numel(), dtype=torch.float64,
                       device=t.device)
     x.allgather(mine, out)
     ev = torch.cuda.Event()
     ev.record(cur)
-    _AUX["event"] = ev
+    x.order_event = ev
     return out
 
 
@@ -99,14 +114,14 @@ def _aux_sum(x, buf):
     """In-place rank-ordered sum of a contiguous float64 device tensor."""
     import torch
     cur = torch.cuda.current_stream()
-    if _AUX["event"] is not None:
-        cur.wait_event(_AUX["event"])
+    if x.order_event is not None:
+        cur.wait_event(x.order_event)
     flat = buf.reshape(-1)
     for i in range(0, flat.numel(), _AUX_ELEMS):
         x.allreduce(flat[i:i + _AUX_ELEMS])
     ev = torch.cuda.Event()
     ev.record(cur)
-    _AUX["event"] = ev
+    x.order_event = ev
 
 
 def all_reduce(t, op=None, group=None):
@@ -179,6 +194,10 @@ class Exchange:
                                self._lib.tce_last_error().decode())
         self.handle = h.value
         self._counted = (0, 0)
+        # the last collective issued on this exchange (one exchange = one
+        # stream order on every rank: issuers on other streams wait for it)
+        self.order_event = None
+        self.self_test = None           # True / False once over_group has run it
         _LIVE.add(self)
 
     def export(self):
@@ -247,6 +266,15 @@ class Exchange:
         STATS["bytes"] += b - self._counted[1]
         self._counted = (n, b)
 
+    def wait_stats(self, reset=False):
+        """(total_us, max_us, collectives): how long workgroup 0 of this rank's
+        collectives waited for its slowest peer (device-side clock, csrc/xchg.h).
+        Blocking."""
+        tot, mx, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        self._call("tce_xchg_wait_stats", self.handle, ctypes.byref(tot),
+                   ctypes.byref(mx), ctypes.byref(n), int(bool(reset)))
+        return tot.value, mx.value, n.value
+
     def set_timeout_ms(self, ms):
         self._call("tce_xchg_set_timeout_ms", self.handle, float(ms))
 
@@ -299,7 +327,8 @@ class Exchange:
                 # peers' stores costs seconds here, not six times the default
                 x.set_timeout_ms(float(os.environ.get(
                     "TCE_XCHG_SELFTEST_TIMEOUT_MS", "5000")))
-                ok = _agree(x._self_test(), group)
+                x.self_test = x._self_test()
+                ok = _agree(x.self_test, group)
                 if ok:
                     x.set_timeout_ms(float(os.environ.get(
                         "TCE_XCHG_TIMEOUT_MS", "20000")))
@@ -339,11 +368,18 @@ def _boot_group(group=None):
     host-side bootstrap; the group itself when it is gloo already."""
     if dist.get_backend(group) == "gloo":
         return group
-    key = id(group)
+    key = _group_key(group)
     if key not in _BOOT:
-        ranks = dist.get_process_group_ranks(group) if group is not None \
-            else list(range(dist.get_world_size()))
-        _BOOT[key] = dist.new_group(ranks=ranks, backend="gloo")
+        # dist.new_group is collective over the DEFAULT group: every process of
+        # the job must reach this point.  DistContext creates the twin eagerly
+        # in its constructor and accepts only groups that span the whole job,
+        # so the lazy callers below always find it (ADVICE r5).
+        if len(key) != dist.get_world_size():
+            raise ValueError(
+                "tce_rl_amd.dist: a process group over a strict subset of the "
+                "job's ranks is not supported (the host-side gloo twin is "
+                "created collectively over the default group)")
+        _BOOT[key] = dist.new_group(ranks=list(key), backend="gloo")
     return _BOOT[key]
 
 
@@ -390,6 +426,12 @@ class DistContext:
         self._flat = {}
         self._aux_group = None
         self._exchanges = {}
+        self._owns_aux = False
+        self._closed = False
+        if self.enabled:
+            # collective contract: a DistContext (an agent) is constructed by
+            # every rank of the job at the same point
+            _boot_group(group)
 
     def exchange(self, channel, max_bytes):
         """The in-library exchange of one update chain ("critic" / "policy";
@@ -411,10 +453,71 @@ class DistContext:
         # (TCE_AUX_EXCHANGE=0: keep those on torch.distributed, for A / B runs)
         if os.environ.get("TCE_AUX_EXCHANGE", "1") == "0":
             return None
-        x = self.exchange("aux", 8 * _AUX_ELEMS)
-        if x is not None:
-            set_aux(x, self.group)
-        return x
+        if not self.active or not exchange_wanted():
+            return None
+        key = _group_key(self.group)
+        slot = _AUX.get(key)
+        if slot is None or slot["x"] is None or not slot["x"].handle:
+            import torch
+            x = Exchange.over_group(8 * _AUX_ELEMS, self.group) \
+                if torch.cuda.is_available() else None
+            if x is None:
+                return None
+            slot = _AUX[key] = {"x": x, "refs": 0}
+        if not self._owns_aux:
+            slot["refs"] += 1
+            self._owns_aux = True
+        self._exchanges["aux"] = slot["x"]
+        return slot["x"]
+
+    def close(self):
+        """Collective: host barrier (no peer may still be reading this rank's
+        buffers), then the gradient exchanges of this context are destroyed and
+        its share of the aux exchange released.  The agents call it from
+        ``close()``; bench.py before ``destroy_process_group``."""
+        if self._closed:
+            return
+        self._closed = True
+        live = [x for k, x in self._exchanges.items()
+                if x is not None and k != "aux"]
+        aux_last = False
+        if self._owns_aux:
+            slot = _AUX.get(_group_key(self.group))
+            if slot is not None:
+                slot["refs"] -= 1
+                aux_last = slot["refs"] <= 0
+        if (live or aux_last) and self.enabled and dist.is_initialized():
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            host_barrier(self.group)
+        for x in live:
+            x.close()
+        if aux_last:
+            slot = _AUX.pop(_group_key(self.group), None)
+            if slot is not None and slot["x"] is not None:
+                slot["x"].close()
+        self._exchanges = {}
+        self._owns_aux = False
+
+    def exchange_report(self):
+        """Per channel: kind, self-test result, wait telemetry (blocking)."""
+        out = {}
+        for k, x in self._exchanges.items():
+            if x is None:
+                out[k] = {"kind": "rccl"}
+                continue
+            tot, mx, n = x.wait_stats()
+            out[k] = {"kind": "xgmi-oneshot", "self_test": x.self_test,
+                      "collectives": n,
+                      "wait_us_mean": round(tot / n, 2) if n else None,
+                      "wait_us_max": round(mx, 2)}
+        return out
+
+    def reset_wait_stats(self):
+        for x in self._exchanges.values():
+            if x is not None:
+                x.wait_stats(reset=True)
 
     def exchange_kind(self):
         """What carries the gradients: "xgmi-oneshot" | "rccl" | "none"."""

@@ -51,10 +51,18 @@ class VecEnvAdapter:
     # the sampler's reference-protocol branch (no fused observation moments)
     fused_obs_moments = False
 
+    # per-step event flags make_mdp_reward reads in full
+    # (mprl/util/util_experiment.py:290-300): never reduced here, even when a
+    # config also lists them as task metrics
+    # (mprl/config/table_tennis_4d/tcp/entire/shared.yaml:136) -- the sampler
+    # takes the last element for the log itself
+    EVENT_KEYS = ("hit_ball", "has_left_floor")
+
     def __init__(self, vec_env, dtype=torch.float32, device="cuda",
                  last_element_keys=()):
         """last_element_keys: info keys whose per-env value is a per-step
-        sequence of which the LAST element is wanted (the task metrics)."""
+        sequence of which only the LAST element is wanted (the task metrics);
+        EVENT_KEYS always come up as the full per-step array."""
         self.vec = vec_env
         self.num_env = int(vec_env.num_envs)
         self.dtype, self.device = dtype, torch.device(device)
@@ -180,7 +188,7 @@ class VecEnvAdapter:
         keys = [k for k in infos[0] if all(k in d for d in infos)]
         for k in keys:
             v0 = infos[0][k]
-            if k in self.last_element_keys:
+            if k in self.last_element_keys and k not in self.EVENT_KEYS:
                 out[k] = self._stack(k, [np.asarray(d[k])[-1] for d in infos])
             elif isinstance(v0, (np.ndarray, list, tuple, float, int, bool,
                                  np.generic)):

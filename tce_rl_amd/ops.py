@@ -691,6 +691,11 @@ def stats5(x, out=None):
 def mdp_reward(step_rewards, event_flags):
     """make_mdp_reward: returns the re-shaped rewards (new tensor)."""
     check_dev(step_rewards, event_flags)
+    if tuple(event_flags.shape) != tuple(step_rewards.shape) or \
+            step_rewards.dim() != 2:
+        raise ValueError(
+            "mdp_reward: per-step event flags %s must match step_rewards %s "
+            "([N, T])" % (tuple(event_flags.shape), tuple(step_rewards.shape)))
     r = _c(step_rewards).clone()
     N, T = r.shape
     call("tce_mdp_reward_" + sfx(r.dtype), ptr(r), ptr(_bool_u8(event_flags)),

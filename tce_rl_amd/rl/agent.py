@@ -234,15 +234,38 @@ class AbstractAgent(ABC):
             for _ in range(E):
                 epoch()
 
+    def _nan_over_ranks(self, losses):
+        """losses [E, 3] (surrogate, entropy, trust-region loss per epoch, on
+        the device) -> [3] float64 device tensor, 1 where a loss was NaN in any
+        epoch ON ANY RANK.  Env shards: the flags ride on the small-collective
+        exchange (one launch, enqueued in step with the peers; no host wait),
+        so the check of temporal_correlated_agent.py:569-577 raises on every
+        rank in the same iteration -- not on the rank with the bad shard alone
+        while its peers run into their next bounded wait."""
+        f = torch.isnan(losses).any(dim=0).to(torch.float64)
+        if self.dist.active:
+            import torch.distributed as tdist
+            from ..dist import all_reduce
+            all_reduce(f, op=tdist.ReduceOp.MAX,
+                       group=self._policy_group or self.dist.group)
+        return f
+
     @staticmethod
-    def _check_nan(flags):
-        """One host read for all NaN flags of an update."""
-        if flags:
-            bad = torch.stack(flags).any(dim=0).cpu().numpy()
-            for name, b in zip(("surrogate_loss", "entropy_loss",
-                                "trust_region_loss"), bad):
-                if b:
-                    raise Exception("NAN %s detected" % name)
+    def _raise_on_nan(flags_host):
+        for name, bad in zip(("surrogate_loss", "entropy_loss",
+                              "trust_region_loss"), flags_host):
+            if bad:
+                raise Exception("NAN %s detected" % name)
+
+    def close(self):
+        """Env shards: release the peer-visible exchange buffers (collective --
+        every rank calls it at the same point, before the process group is
+        destroyed).  A no-op for a single-process agent."""
+        flush = getattr(self, "flush_metrics", None)
+        if flush is not None:
+            flush()
+        self.dist.close()
+        self.xchg_critic = self.xchg_policy = None
 
 
 class _CriticEpochs:
@@ -1051,14 +1074,14 @@ class TemporalCorrelatedAgent(AbstractAgent):
         projection_time = util.run_time_test(lock=False, key="projection",
                                              sync=False)
 
+        if self.dist.active:
+            # (every rank raises together: the flags of all shards in row 0)
+            rec_all[0, 19:22] = self._nan_over_ranks(rec_all[:, :3]) \
+                .to(rec_all.dtype)
         rec_host = rec_all.cpu().numpy()                  # ONE copy
-        if direct is not None:
+        if direct is not None and not self.dist.active:
             rec_host[:, 19:22] = np.isnan(rec_host[:, :3])
-        for name, bad in zip(("surrogate_loss", "entropy_loss",
-                              "trust_region_loss"),
-                             rec_host[:, 19:22].any(axis=0)):
-            if bad:
-                raise Exception("NAN %s detected" % name)
+        self._raise_on_nan(rec_host[:, 19:22].any(axis=0))
         host, kl_host = rec_host[:, :7], rec_host[:, 7:19]
         names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
                  "policy_loss", "entropy", "policy_grad_norm",
@@ -1694,13 +1717,16 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                                         self.num_iterations)
                 self.policy.set_cov_variable(pL)
 
+        # (env shards: the flags of every rank, enqueued here in step with the
+        # peers -- the deferred host read below must not issue a collective)
+        gflags = self._nan_over_ranks(rec[:, :3]) if self.dist.active else None
+
         def read():
             host = rec.cpu().numpy()                      # ONE copy
-            for name, bad in zip(("surrogate_loss", "entropy_loss",
-                                  "trust_region_loss"),
-                                 np.isnan(host[:, :3]).any(axis=0)):
-                if bad:
-                    raise Exception("NAN %s detected" % name)
+            bad = np.isnan(host[:, :3]).any(axis=0)
+            if gflags is not None:
+                bad = bad | (gflags.cpu().numpy() > 0)
+            self._raise_on_nan(bad)
             names = ("surrogate_loss", "entropy_loss", "trust_region_loss",
                      "policy_loss", "entropy", "policy_grad_norm",
                      "clipped_policy_grad_norm")

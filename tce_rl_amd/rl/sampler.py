@@ -265,7 +265,7 @@ class BlackBoxSampler(AbstractSampler):
             num_steps += info.get("num_steps_host",
                                   None) or info["trajectory_length"].sum()
             for m in metrics:
-                metrics[m].append(info[m].to(self.dtype))
+                metrics[m].append(_last_element(info[m]).to(self.dtype))
         res = {}
         for k, v in out.items():
             res[k] = _cat_L(v) if k == "segment_params_L" else torch.cat(v, 0)
@@ -273,6 +273,14 @@ class BlackBoxSampler(AbstractSampler):
         for m, v in metrics.items():
             res[m] = torch.cat(v, 0)
         return res, int(num_steps)
+
+
+def _last_element(v):
+    """A task metric as the reference logs it: the LAST element of a per-step
+    sequence (``get_item_from_dicts(infos, metric, lambda x: x[-1])``,
+    mprl/rl/sampler/temporal_correlated_sampler.py:309-310); envs and adapters
+    that reduced it already hand over [N]."""
+    return v[..., -1] if v.dim() > 1 else v
 
 
 def _cat_L(Ls):
@@ -447,7 +455,7 @@ class TemporalCorrelatedSampler(BlackBoxSampler):
             num_steps = num_steps + (infos.get("num_steps_host", None) or
                                      infos["segment_length"].sum())
             for m in metrics:
-                metrics[m].append(infos[m].to(self.dtype))
+                metrics[m].append(_last_element(infos[m]).to(self.dtype))
             init_state = next_state
         res = {}
         for k, v in out.items():

@@ -263,8 +263,11 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32",
     #  * values: three 128-wide layers (2e-6); returns / advantages: the
     #    lambda-discounted scan over T steps adds the value errors of the later
     #    steps, relative to max |return| that is still 3e-7;
-    #  * log-prob: the pair covariance has a 1e-4 floor, so a mean error is
-    #    amplified by up to 1 / sigma_min = 100 (seen 4e-6 of max |logp|);
+    #  * log-prob: north_star's 1e-5.  The pair covariance has a 1e-4 floor;
+    #    the kernels form and factor it in double (round 6) and sit <= 1e-6
+    #    of max |logp| from the float64 value (tests/test_prodmp_gpu.py), so
+    #    what is seen here (3.7e-6) is the float32 ORACLE's own distance from
+    #    it -- the reference's float32 arithmetic has the same;
     #  * parameters after EPOCHS Adam steps: Adam's step lr m / (sqrt v + eps)
     #    is scale free, so a relative gradient error delta moves a parameter by
     #    ~ lr * delta per step; the policy's gradient passes the projection's
@@ -287,8 +290,9 @@ def _agent_vs_oracle(overlap, fused, graph, env, nb, dtype="float32",
           ref["step_advantages"], 5e-6)
     close("segment_advantage", captured["segment_advantage"],
           ref["segment_advantage"], 5e-6)
-    close("segment_log_prob_estimate", captured["segment_log_prob_estimate"],
-          ref["segment_log_prob_estimate"], 4e-5)
+    # (north_star's bound as it stands, also after a second iteration)
+    _close("segment_log_prob_estimate", captured["segment_log_prob_estimate"],
+           ref["segment_log_prob_estimate"], 1e-5)
     # parameters after EPOCHS critic + policy updates
     for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
         close("critic", pg.detach().cpu(), po.detach(), 1e-7 if f64 else 5e-5)

@@ -19,29 +19,47 @@ def _bench():
     return mod
 
 
+def _args(**kw):
+    base = dict(gpus=4, steps=3, warmup=1, no_cpu_baseline=True,
+                with_split_f16=False, no_configs=False, scaling="weak",
+                launch_timeout=77.0, startup_timeout=60.0)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def _fake_children(monkeypatch, tmp_path, body):
+    """Popen of the launcher command -> a tiny script (its body sees ATTEMPT =
+    1, 2, 3 ... and the launcher's environment); returns the list the
+    launcher's (cmd, env) pairs are appended to."""
+    seen = []
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import json, os, sys\n"
+        "ATTEMPT = int(os.environ['TCE_BENCH_LAUNCH_ATTEMPT'].split(':')[0])\n"
+        "def warm():\n"
+        "    open(os.environ['TCE_BENCH_SENTINEL'], 'w').close()\n"
+        + body)
+    real_popen = subprocess.Popen
+
+    def popen(cmd, env=None, **kw):
+        seen.append((cmd, dict(env), kw.get("start_new_session")))
+        return real_popen([sys.executable, str(script)], env=env, **kw)
+    monkeypatch.setattr(subprocess, "Popen", popen)
+    return seen
+
+
 def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
-        monkeypatch, capsys):
+        monkeypatch, capsys, tmp_path):
     bench = _bench()
-    seen = {}
     record = {"metric": "env-steps/sec", "value": 1.0, "n_gpus": 4}
-
-    class FakePopen:
-        def __init__(self, cmd, env=None, stdout=None, start_new_session=False):
-            seen["cmd"], seen["env"] = cmd, env
-            seen["own_session"] = start_new_session
-            self.returncode, self.pid = 0, 0
-
-        def communicate(self, timeout=None):
-            seen["timeout"] = timeout
-            out = "banner from a library\n" + json.dumps(record) + "\n"
-            return out.encode(), None
-    monkeypatch.setattr(subprocess, "Popen", FakePopen)
-    args = types.SimpleNamespace(gpus=4, steps=3, warmup=1,
-                                 no_cpu_baseline=True, with_split_f16=False,
-                                 no_configs=False, scaling="weak",
-                                 launch_timeout=77.0)
-    assert bench.self_launch(args) == 0
-    cmd = seen["cmd"]
+    seen = _fake_children(
+        monkeypatch, tmp_path,
+        "warm()\nprint('banner from a library')\nprint(%r)\n"
+        % json.dumps(record))
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    assert bench.self_launch(_args()) == 0
+    assert len(seen) == 1                       # no second attempt
+    cmd, env, own_session = seen[0]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
@@ -50,28 +68,62 @@ def test_self_launch_builds_the_torchrun_command_and_relays_the_line(
     script = cmd.index(os.path.join(REPO, "bench.py"))
     assert cmd[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1",
                                 "--no-cpu-baseline"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert seen["own_session"] and seen["timeout"] == 77.0
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["TCE_BENCH_LAUNCH_ATTEMPT"] == "1: as configured"
+    assert own_session
     out = capsys.readouterr()
     assert [json.loads(ln) for ln in out.out.splitlines()] == [record]
     assert "banner" in out.err
 
 
-def test_self_launch_reports_a_failed_child(monkeypatch):
+def test_self_launch_retries_a_child_set_that_dies_before_its_warmup(
+        monkeypatch, capsys, tmp_path):
+    """non-zero exit before "warmup done" -> a FRESH child
+    set with the other IPC mode, then one with the gradients on
+    torch.distributed; the line comes from the attempt that worked."""
     bench = _bench()
+    record = {"metric": "env-steps/sec", "value": 2.0}
+    seen = _fake_children(
+        monkeypatch, tmp_path,
+        "if ATTEMPT < 3:\n    sys.exit(7)\n"
+        "warm()\nprint(%r)\n" % json.dumps(record))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.delenv("TCE_EXCHANGE", raising=False)
+    assert bench.self_launch(_args(gpus=2)) == 0
+    envs = [e for _, e, _ in seen]
+    assert [e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs] == ["0", "1", "0"]
+    assert [e.get("TCE_EXCHANGE") for e in envs] == [None, None, "rccl"]
+    assert envs[2]["TCE_BENCH_LAUNCH_ATTEMPT"] == "3: TCE_EXCHANGE=rccl"
+    ports = [c[c.index("--master-port") + 1] for c, _, _ in seen]
+    assert len(seen) == 3 and all(int(p) > 0 for p in ports)
+    out = capsys.readouterr()
+    assert [json.loads(ln) for ln in out.out.splitlines()] == [record]
+    assert "starting a fresh child set" in out.err
 
-    class FakePopen:
-        returncode, pid = 3, 0
 
-        def __init__(self, *a, **k):
-            pass
+def test_self_launch_reports_a_failed_child(monkeypatch, tmp_path):
+    """Every attempt fails before its warm-up: the last exit code comes back;
+    a failure AFTER the warm-up is not a launch problem and is not retried."""
+    bench = _bench()
+    seen = _fake_children(monkeypatch, tmp_path, "sys.exit(3)\n")
+    assert bench.self_launch(_args(gpus=2, with_split_f16=True)) == 3
+    assert len(seen) == 3
+    seen = _fake_children(monkeypatch, tmp_path, "warm()\nsys.exit(5)\n")
+    assert bench.self_launch(_args(gpus=2)) == 5
+    assert len(seen) == 1
 
-        def communicate(self, timeout=None):
-            return b"", None
-    monkeypatch.setattr(subprocess, "Popen", FakePopen)
-    args = types.SimpleNamespace(gpus=2, steps=1, warmup=0,
-                                 no_cpu_baseline=False, with_split_f16=True)
-    assert bench.self_launch(args) == 3
+
+def test_self_launch_replaces_a_child_set_that_never_warms_up(
+        monkeypatch, tmp_path):
+    """No "warmup done" within --startup-timeout: killed, next attempt."""
+    bench = _bench()
+    seen = _fake_children(
+        monkeypatch, tmp_path,
+        "import time\n"
+        "if ATTEMPT == 1:\n    time.sleep(600)\n"
+        "warm()\nprint(json.dumps({'metric': 'm', 'value': 1}))\n")
+    assert bench.self_launch(_args(gpus=2, startup_timeout=2.0)) == 0
+    assert len(seen) == 2
 
 
 def test_self_launch_kills_a_hung_child_tree(tmp_path, monkeypatch):
@@ -92,9 +144,7 @@ def test_self_launch_kills_a_hung_child_tree(tmp_path, monkeypatch):
     def popen(cmd, **kw):                   # the launcher command -> the hanging script
         return real_popen([sys.executable, str(script)], **kw)
     monkeypatch.setattr(subprocess, "Popen", popen)
-    args = types.SimpleNamespace(gpus=2, steps=1, warmup=0,
-                                 no_cpu_baseline=True, with_split_f16=False,
-                                 launch_timeout=3.0)
+    args = _args(gpus=2, steps=1, warmup=0, launch_timeout=3.0)
     t = time.time()
     assert bench.self_launch(args) == 124
     assert time.time() - t < 30
@@ -115,6 +165,7 @@ def test_plain_shell_multi_gpu_invocation_never_touches_the_gpu():
     never raised the launch assertion the round-1 script died with."""
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TCE_BENCH_NO_RETRY"] = "1"         # (one attempt: the ranks stop at once)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"),
                         "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)

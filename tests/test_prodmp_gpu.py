@@ -180,22 +180,35 @@ def test_pair_logprob_golden_plumbing(ops, golden):
                                    rtol=2e-5, atol=2e-5)
         lp = ops.pair_log_prob(mp, a("traj"), a("mean"), a("L"), times,
                                a("t0"), a("y0"), a("v0"), a("pairs"))
-        # The fp32 likelihood is conditioning-limited (C = H Sigma H^T + 1e-4 I
-        # is nearly singular): the reference's own fp32 result is ~1e-4 off
-        # the fp64 value.  Parity bar: (1) close to the reference's fp32
-        # output, (2) at least as close to the fp64 truth as the reference is.
+        # north_star: 1e-5 on log-probs.  The float32 likelihood is
+        # conditioning-limited (C = H Sigma H^T + 1e-4 I is nearly singular):
+        # the reference's OWN float32 output sits 3 - 5e-6 of max |logp| away
+        # from the float64 value on this fixture, so the bar is set against the
+        # float64 truth: (1) |hip_f32 - truth| <= LOGP_REL of max |truth|
+        # (seen 5.3e-7 since the kernels form and factor C in double, round
+        # 6; LOGP_REL = 3e-6 keeps a regression visible, north_star's bound
+        # is 1e-5), (2) no further from the truth than the reference is,
+        # (3) within that distance of the reference's float32 output.
         ref32 = g[f"{tag}_logp"]
-        np.testing.assert_allclose(lp.cpu().numpy(), ref32, rtol=5e-4,
-                                   atol=5e-4)
         o64 = ProDMPOracle(dtype=torch.float64, **cfg)
         d = lambda k: T_(g[f"{tag}_{k}"]).double()
         truth = pair_log_prob(o64, d("traj"), d("mean"), d("L"), d("times"),
                               d("t0"), d("y0"), d("v0"),
                               T_(g[f"{tag}_pairs"])).numpy()
+        scale = np.abs(truth).max()
         err_ours = np.abs(lp.cpu().numpy() - truth).max()
         err_ref = np.abs(ref32 - truth).max()
-        assert err_ours <= 1.5 * err_ref + 1e-5 * np.abs(truth).max(), \
-            (err_ours, err_ref)
+        assert err_ours <= LOGP_REL * scale, (err_ours, scale)
+        assert err_ours <= err_ref, (err_ours, err_ref)
+        assert np.abs(lp.cpu().numpy() - ref32).max() <= \
+            err_ref + LOGP_REL * scale
+
+
+# |float32 kernel - float64 truth| <= LOGP_REL * max |truth| (north_star: 1e-5;
+# largest seen over every case of this file 9.8e-7, scripts/probe_logp_tol.py)
+LOGP_REL = 3e-6
+NORTH_STAR_LOGP_REL = 1e-5
+assert LOGP_REL <= NORTH_STAR_LOGP_REL
 
 
 _PL_NAMES = ["metaworld", "metaworld_nb5", "box_push", "table_tennis"]
@@ -260,6 +273,46 @@ def _pair_logprob_fwd_bwd_vs_oracle(ops, name, shared, uniform_t0, N):
                                atol=1e-7)
 
 
+@pytest.mark.parametrize("name,shared,uniform_t0,N,form", _PL_CASES + [
+    (n, False, True, 300, "static") for n in _PL_NAMES])
+def test_pair_logprob_float32_within_north_star_of_the_float64_truth(
+        ops, name, shared, uniform_t0, N, form):
+    """Every kernel form (per-env covariance, shared factor at 6 envs on the
+    general kernel, the fast path's register / run-time-shape kernels, equal
+    and differing init times) in FLOAT32 against the float64 oracle on the same
+    float32 inputs: north_star's 1e-5 of max |logp| (asserted at LOGP_REL)."""
+    from tce_rl_amd._lib import call
+    dtype = torch.float32
+    cfg = CFGS[name]
+    mp = make(name, dtype)[0]
+    o64 = ProDMPOracle(dtype=torch.float64, **cfg)
+    T = HORIZON[name]
+    mean, L, eps, t0, y0, v0 = inputs(name, N, dtype, 3, uniform_t0)
+    if shared:
+        L = L[:1].expand(N, -1, -1).contiguous()
+    times_cpu = O.get_times(t0, cfg["dt"], T)
+    tg = affine(times_cpu)
+    Lg = ops.expand_shared(L[0].cuda(), N) if shared else L.cuda()
+    w = ops.mvn_rsample(mean.cuda(), Lg, eps.cuda())
+    traj = ops.prodmp_traj(mp, tg, w, t0.cuda(), y0.cuda(), v0.cuda())
+    torch.manual_seed(1)
+    pairs = O.get_time_pairs(T, dict(num_select=25, fixed_interval=True))
+    call("tce_pair_env_static", int(form == "static"))
+    try:
+        lp = ops.pair_log_prob(mp, traj, mean.cuda(), Lg, tg, t0.cuda(),
+                               y0.cuda(), v0.cuda(), pairs.cuda())
+    finally:
+        call("tce_pair_env_static", 1)
+    n = min(N, 48)
+    dd = lambda x: x[:n].double()
+    truth = pair_log_prob(o64, traj.cpu()[:n].double(), dd(mean), dd(L),
+                          times_cpu[:n].double(), dd(t0), dd(y0), dd(v0),
+                          pairs)
+    err = float((lp.cpu()[:n].double() - truth).abs().max())
+    assert err <= LOGP_REL * float(truth.abs().max()), \
+        (err, float(truth.abs().max()))
+
+
 def test_pair_logprob_c2_size_properties(ops):
     """BASELINE C2 shape: N 4096, T 500, P 24, dof 4, nb 8 in fp32 -- oracle on
     a slice and shared-vs-per-env consistency on the whole batch."""
@@ -279,14 +332,25 @@ def test_pair_logprob_c2_size_properties(ops):
     lp_full = ops.pair_log_prob(mp, traj, mean.cuda(),
                                 Lsh.expand(N, -1, -1).contiguous().cuda(), tg,
                                 t0.cuda(), y0.cuda(), v0.cuda(), pairs.cuda())
+    # float64 truth on slices across the batch (first / middle / ragged last
+    # block): both paths within LOGP_REL of max |truth| (north_star: 1e-5)
+    o64 = ProDMPOracle(dtype=torch.float64, **CFGS[name])
+    worst = 0.0
+    for sl in (slice(0, 16), slice(2000, 2016), slice(4080, 4096)):
+        n = sl.stop - sl.start
+        times_cpu = O.get_times(t0[sl], CFGS[name]["dt"], T).double()
+        truth = pair_log_prob(o64, traj.cpu()[sl].double(), mean[sl].double(),
+                              Lsh.expand(n, -1, -1).double(), times_cpu,
+                              t0[sl].double(), y0[sl].double(),
+                              v0[sl].double(), pairs)
+        scale = float(truth.abs().max())
+        for got in (lp_shared, lp_full):
+            err = float((got.cpu()[sl].double() - truth).abs().max())
+            worst = max(worst, err / scale)
+            assert err <= LOGP_REL * scale, (err, scale)
     # shared-L fast path vs per-env general path: same math, different order
-    torch.testing.assert_close(lp_shared, lp_full, rtol=1e-4, atol=2e-3)
-    sl = slice(2000, 2008)
-    times_cpu = O.get_times(t0[sl], CFGS[name]["dt"], T)
-    ref = pair_log_prob(oracle, traj.cpu()[sl], mean[sl],
-                        Lsh.expand(8, -1, -1), times_cpu, t0[sl], y0[sl],
-                        v0[sl], pairs)
-    torch.testing.assert_close(lp_shared.cpu()[sl], ref, rtol=1e-5, atol=2e-4)
+    scale = float(lp_full.abs().max())
+    assert float((lp_shared - lp_full).abs().max()) <= 2 * LOGP_REL * scale
 
 
 def test_basis_table_cache_is_invalidated_by_new_or_modified_times():

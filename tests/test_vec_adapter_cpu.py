@@ -14,10 +14,30 @@ from tce_rl_amd.envs.vec_adapter import (VecEnvAdapter, make_bb_vec_env,
                                          _override_mp_config)
 
 
-def _adapter(task="table_tennis", N=5, dtype=torch.float32):
+def _adapter(task="table_tennis", N=5, dtype=torch.float32,
+             keys=("success", "final_distance")):
     vec = OracleVecEnv(task, N, dof=7, d_task=21, T=30, dt=0.008, seed=3)
     return vec, VecEnvAdapter(vec, dtype=dtype, device="cpu",
-                              last_element_keys=["success", "final_distance"])
+                              last_element_keys=list(keys))
+
+
+def test_event_flags_listed_as_metrics_stay_per_step():
+    """The reference's table-tennis configs list ``hit_ball`` among the task
+    metrics (mprl/config/table_tennis_4d/tcp/entire/shared.yaml:136) while
+    make_mdp_reward reads the whole per-step flag
+    (mprl/util/util_experiment.py:290-300): the adapter must not reduce it."""
+    vec, ad = _adapter(keys=("hit_ball", "success"))
+    ad.reset()
+    g = torch.Generator().manual_seed(0)
+    actions = 0.1 * torch.randn(5, 30, 14, generator=g)
+    infos = ad.step(actions)[3]
+    assert infos["hit_ball"].shape == (5, 30)
+    assert infos["hit_ball"].dtype == torch.bool
+    assert infos["success"].shape == (5,)
+    from tce_rl_amd.rl.sampler import _last_element
+    assert torch.equal(_last_element(infos["hit_ball"]),
+                       infos["hit_ball"][:, -1])
+    assert _last_element(infos["success"]) is infos["success"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

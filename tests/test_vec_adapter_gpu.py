@@ -32,14 +32,15 @@ def replay_fn(env_id, num_env, seed, render, mp_args, black_box=False, **kw):
     return ReplayVecEnv(syn, black_box)
 
 
-def _tce_agent(env, vec, norm, num_env=48, fn=replay_fn):
+def _tce_agent(env, vec, norm, num_env=48, fn=replay_fn,
+               metrics=("success", "final_distance")):
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
     cfg = tce_config(env, num_env=num_env, num_basis=5, epochs=2,
                      evaluation_interval=0, seed=3, num_env_test=8)
     sa = cfg["params"]["sampler"]["args"]
     sa["norm_step_obs"] = norm
-    sa["task_specified_metrics"] = ["success", "final_distance"]
+    sa["task_specified_metrics"] = list(metrics)
     if vec:
         sa["env_backend"], sa["vec_env_fn"] = "vec", fn
     torch.manual_seed(11)
@@ -53,6 +54,28 @@ def _same(a, b, exact, key):
         assert torch.equal(a, b), key
     else:
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5, msg=key)
+
+
+def test_hit_ball_as_a_task_metric_keeps_the_mdp_reward_right():
+    """``task_specified_metrics: [hit_ball, ...]`` as in the
+    reference's table-tennis YAMLs -- the per-step flag still reaches
+    make_mdp_reward in full, the logged metric is its last element, and the
+    dataset equals the direct path's."""
+    from tce_rl_amd import ops
+    m = ("hit_ball", "success")
+    direct = _tce_agent("table_tennis", False, False, metrics=m)
+    vec = _tce_agent("table_tennis", True, False, metrics=m)
+    out = []
+    for ag in (direct, vec):
+        torch.manual_seed(100)
+        out.append(ag.sampler.run(training=True, policy=ag.policy,
+                                  critic=ag.critic)[0])
+    d0, d1 = out
+    assert d0["hit_ball"].shape == d1["hit_ball"].shape == (48,)
+    assert torch.equal(d0["hit_ball"], d1["hit_ball"])
+    assert torch.equal(d0["step_rewards"], d1["step_rewards"])
+    with pytest.raises(ValueError, match="event flags"):
+        ops.mdp_reward(d0["step_rewards"], d0["hit_ball"] > 0)
 
 
 @pytest.mark.parametrize("env", ["metaworld", "table_tennis"])
