@@ -923,6 +923,32 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
                        float weight_decay, float adam_step, float grad_scale, void* xchg,
                        void* stream);
 
+/* One critic EPOCH in minibatches -- the reference's class default is
+ * num_minibatchs = 10 (mprl/rl/agent/temporal_correlated_agent.py:25,343-366,
+ * black_box_agent.py:25,124-127; generate_minibatches / select_batch,
+ * mprl/util/util_data_structure.py:362-391).  row_index int64 [R]: the epoch's
+ * permutation of the rows, drawn by the caller with numpy's global generator
+ * exactly as the reference draws it (np.random.shuffle of arange(R)); it is cut
+ * like np.array_split into num_minibatches consecutive pieces (the first
+ * R % num_minibatches pieces one row longer).  Per piece, in order, ONE optimizer
+ * step: forward + value loss (mean over the piece) + backward over the GATHERED
+ * rows (x, returns, old_values are read through the index in place -- nothing is
+ * copied), slab reduction, Adam.  stats: float [num_minibatches][4], zeroed by
+ * the caller: per piece {mean loss, |grad|^2, |grad|, |grad| clipped} ([2], [3]
+ * are written only with grad_clip > 0 or an exchange; otherwise the caller takes
+ * the root of [1]).  adam_step: the step count INCLUDING the first piece's
+ * update; grad_clip: clip_grad_norm (<= 0: none; needs num_params <= 2^17);
+ * the other arguments as in tce_mlp_critic_f32.  tce_mlpw_critic_minibatch_*:
+ * the same for the wide / float64 value nets (declared below). */
+int tce_mlp_critic_minibatch_f32(
+    const float* x, int64_t env_stride, int64_t row_stride, int T, int64_t R, int din,
+    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+    const float* b3, int act, const float* returns, const float* old_values, float clip,
+    const int64_t* row_index, int num_minibatches, float* partials, float* grad, float* stats,
+    int max_workgroups, float* adam_param, float* adam_m, float* adam_v, float* adam_state,
+    float lr, float beta1, float beta2, float eps, float weight_decay, float adam_step,
+    float grad_clip, float grad_scale, void* xchg, void* stream);
+
 /* ---- fused critic epoch for wide / double-precision value networks ---------
  * The contract of tce_mlp_critic_f32 for  D_in -> hidden -> hidden -> 1  with
  * hidden = 256 (float32; float64 with D_in <= 24) or hidden = 128 (float64):
@@ -960,6 +986,24 @@ int tce_mlpw_critic_f64(const double* x, int64_t env_stride, int64_t row_stride,
                         double* adam_v, double* adam_state, double lr, double beta1,
                         double beta2, double eps, double weight_decay, double adam_step,
                         double grad_scale, void* xchg, void* stream);
+int tce_mlpw_critic_minibatch_f32(
+    const float* x, int64_t env_stride, int64_t row_stride, int T, int64_t R, int din,
+    int hidden, const float* w1, const float* b1, const float* w2, const float* b2,
+    const float* w3, const float* b3, int act, const float* returns, const float* old_values,
+    float clip, const int64_t* row_index, int num_minibatches, float* workspace,
+    float* partials, float* grad, float* stats, int max_workgroups, float* adam_param,
+    float* adam_m, float* adam_v, float* adam_state, float lr, float beta1, float beta2,
+    float eps, float weight_decay, float adam_step, float grad_clip, float grad_scale,
+    void* xchg, void* stream);
+int tce_mlpw_critic_minibatch_f64(
+    const double* x, int64_t env_stride, int64_t row_stride, int T, int64_t R, int din,
+    int hidden, const double* w1, const double* b1, const double* w2, const double* b2,
+    const double* w3, const double* b3, int act, const double* returns,
+    const double* old_values, double clip, const int64_t* row_index, int num_minibatches,
+    double* workspace, double* partials, double* grad, double* stats, int max_workgroups,
+    double* adam_param, double* adam_m, double* adam_v, double* adam_state, double lr,
+    double beta1, double beta2, double eps, double weight_decay, double adam_step,
+    double grad_clip, double grad_scale, void* xchg, void* stream);
 
 /* The backward launch of tce_mlp_critic_f32 (same buffers and contract;
  * partials != NULL required) on the f16 matrix cores with SPLIT operands: every

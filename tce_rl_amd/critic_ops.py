@@ -156,6 +156,39 @@ class WideEpochRunner:
         return stats
 
 
+    def epoch_minibatches(self, states, returns, old_values, clip, row_index,
+                          num_minibatches, stats, adam, grad_clip=0.0,
+                          max_workgroups=0, xchg=None, grad_scale=1.0):
+        """One epoch in minibatches (tce_mlpw_critic_minibatch_*): see
+        EpochRunner.epoch_minibatches."""
+        xs, es, rs, T, R = _rows(states)
+        assert row_index.dtype == torch.int64 and row_index.numel() == R \
+            and row_index.is_contiguous()
+        assert stats.shape == (num_minibatches, 4) and stats.is_contiguous()
+        ret = returns.reshape(-1)
+        ret = ret if ret.is_contiguous() else ret.contiguous()
+        old = old_values.reshape(-1).contiguous() if clip > 0 else None
+        g = adam.param_groups[0]
+        first = adam.host_step + 1
+        adam.host_step += num_minibatches
+        adam._opt_called = True
+        ws = _wide_ws(self.mlp, -(-R // num_minibatches), True)
+        call(self.entry.replace("critic_", "critic_minibatch_"), ptr(xs), es,
+             rs, T, R, self.mlp.dim_in, self.H, *_weights(self.mlp),
+             _ACT[self.mlp.act_func_hidden_type], ptr(ret), ptr(old),
+             float(clip), ptr(row_index), int(num_minibatches), ptr(ws),
+             ptr(self.partials), ptr(self.flat), ptr(stats),
+             int(max_workgroups), ptr(adam.flat_param), ptr(adam.m),
+             ptr(adam.v), ptr(adam.dev_state), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+             float(g["weight_decay"]), float(first), float(grad_clip),
+             float(grad_scale), None if xchg is None else xchg.handle,
+             stream())
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return stats
+
+
 def make_runner(mlp, flat=None, arith="f32"):
     """The epoch runner for a supported value network."""
     if wide_supported(mlp):
@@ -228,6 +261,47 @@ class EpochRunner:
              *_weights(self.mlp), _ACT[self.mlp.act_func_hidden_type],
              ptr(ret), ptr(old), float(clip), None, ptr(self.partials),
              ptr(self.flat), ptr(stats), int(max_workgroups), *ad,
+             float(grad_scale), None if xchg is None else xchg.handle,
+             stream())
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return stats
+
+
+    def epoch_minibatches(self, states, returns, old_values, clip, row_index,
+                          num_minibatches, stats, adam, grad_clip=0.0,
+                          max_workgroups=0, xchg=None, grad_scale=1.0):
+        """One critic epoch of ``num_minibatches`` optimizer steps
+        (temporal_correlated_agent.py:343-366) as ONE C call
+        (tce_mlp_critic_minibatch_f32): ``row_index`` int64 [R] on the device =
+        the epoch's permutation (util_data_structure.py:378-391), cut like
+        np.array_split; the kernels read the gathered rows in place.  stats
+        [num_minibatches, 4] zeroed; adam: the FlatAdam whose steps are taken
+        (grad_clip > 0: clip + Adam as one launch per piece)."""
+        if self.arith != "f32":
+            raise NotImplementedError(
+                "minibatched critic epochs run on the exact-fp32 kernel only "
+                "(critic_arith=%s)" % self.arith)
+        xs, es, rs, T, R = _rows(states)
+        assert row_index.dtype == torch.int64 and row_index.numel() == R \
+            and row_index.is_contiguous()
+        assert stats.shape == (num_minibatches, 4) and stats.is_contiguous()
+        ret = returns.reshape(-1)
+        ret = ret if ret.is_contiguous() else ret.contiguous()
+        old = old_values.reshape(-1).contiguous() if clip > 0 else None
+        g = adam.param_groups[0]
+        first = adam.host_step + 1
+        adam.host_step += num_minibatches
+        adam._opt_called = True
+        call("tce_mlp_critic_minibatch_f32", ptr(xs), es, rs, T, R,
+             self.mlp.dim_in, *_weights(self.mlp),
+             _ACT[self.mlp.act_func_hidden_type], ptr(ret), ptr(old),
+             float(clip), ptr(row_index), int(num_minibatches),
+             ptr(self.partials), ptr(self.flat), ptr(stats),
+             int(max_workgroups), ptr(adam.flat_param), ptr(adam.m),
+             ptr(adam.v), ptr(adam.dev_state), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+             float(g["weight_decay"]), float(first), float(grad_clip),
              float(grad_scale), None if xchg is None else xchg.handle,
              stream())
         for p, v in zip(self.params, self.views):

@@ -45,6 +45,10 @@ extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m
                                  int64_t n, float* state, float* norms_out, float step, float lr,
                                  float beta1, float beta2, float eps, float weight_decay,
                                  float clip, float grad_scale, void* stream);
+extern "C" int tce_adam_once_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                                 float* state, float* norms_out, float step, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay,
+                                 float clip, float grad_scale, void* stream);
 
 namespace {
 
@@ -133,15 +137,21 @@ __device__ inline void stage_weights(const MlpArgs& a, const Lds<KPGE>& L, int t
 template <int KPGE>
 __device__ inline int64_t load_x(const MlpArgs& a, const RowCursor& cur, int g, float* dst) {
   const bool in = cur.r < a.R;
-  const int64_t ne = in ? cur.ne : cur.last_ne;
-  const int t = in ? cur.t : cur.last_t;
+  int64_t ne = in ? cur.ne : cur.last_ne;
+  int t = in ? cur.t : cur.last_t;
+  int64_t phys = in ? cur.r : a.R - 1;
+  if (a.row_index) {                       // (uniform) gathered rows of a minibatch
+    phys = a.row_index[phys];
+    ne = phys / a.T;
+    t = (int)(phys - ne * a.T);
+  }
   const float* xr = a.x + ne * a.env_stride + t * a.row_stride;
 #pragma unroll
   for (int s = 0; s < KPGE; ++s) {
     const int k = KPGE * g + s;
     dst[s] = xr[k < a.din ? k : a.din - 1];
   }
-  return in ? cur.r : a.R - 1;
+  return phys;
 }
 
 // Forward chain of one 16-row slice: h1 = act(W1 x + b1) (by position), h2 =
@@ -702,15 +712,15 @@ int64_t tce_mlp_critic_num_params(int din) { return mlp_num_params(din); }
 // adam_param != NULL: Adam step on (adam_param, adam_m, adam_v) [num_params]
 // fused into the gradient reduction (no clipping), adam_step = step count
 // including this update, written to adam_state[0].
-int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
-                       int64_t R, int din, const float* w1, const float* b1,
-                       const float* w2, const float* b2, const float* w3, const float* b3,
-                       int act, const float* returns, const float* old_values, float clip,
-                       float* values, float* partials, float* grad, float* stats,
-                       int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
-                       float* adam_state, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, float adam_step, float grad_scale, void* xchg,
-                       void* stream) {
+static int mlp_critic_impl(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                           int64_t R, int din, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* w3, const float* b3,
+                           int act, const float* returns, const float* old_values, float clip,
+                           float* values, float* partials, float* grad, float* stats,
+                           int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                           float* adam_state, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, float adam_step, float grad_scale, void* xchg,
+                           void* stream, const int64_t* row_index) {
   TCE_CHECK_ARG(x && w1 && b1 && w2 && b2 && w3 && b3 && R > 0 && T > 0,
                 "mlp_critic: null buffer / bad sizes");
   TCE_CHECK_ARG(din >= 1 && din <= MAX_DIN, "mlp_critic: 1 <= D_in <= 40");
@@ -721,8 +731,10 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
   TCE_CHECK_ARG(!(bwd && clip > 0.f && !old_values), "mlp_critic: old values missing");
   TCE_CHECK_ARG(!adam_param || (bwd && adam_m && adam_v && adam_state && adam_step >= 1.f),
                 "mlp_critic: fused Adam needs the backward pass and its state buffers");
+  TCE_CHECK_ARG(!row_index || (bwd && !values),
+                "mlp_critic: a row index goes with the backward pass only (no values output)");
   MlpArgs a{x, env_stride, row_stride, T, R, din, w1, b1, w2, b2, w3, b3,
-            returns, old_values, clip, values, partials, nullptr, nullptr};
+            returns, old_values, clip, values, partials, nullptr, nullptr, row_index};
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = ceil_div(R, ROWS_PER_TILE);
   int cap = tce_mlp_critic_grid();
@@ -749,6 +761,75 @@ int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, i
       return tce_xchg_adam_f32(xchg, adam_param, grad, adam_m, adam_v, P, adam_state, stats + 2,
                                adam_step, lr, beta1, beta2, eps, weight_decay, 0.f, grad_scale,
                                stream);
+  }
+  return 0;
+}
+
+int tce_mlp_critic_f32(const float* x, int64_t env_stride, int64_t row_stride, int T,
+                       int64_t R, int din, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3,
+                       int act, const float* returns, const float* old_values, float clip,
+                       float* values, float* partials, float* grad, float* stats,
+                       int max_workgroups, float* adam_param, float* adam_m, float* adam_v,
+                       float* adam_state, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float adam_step, float grad_scale, void* xchg,
+                       void* stream) {
+  return mlp_critic_impl(x, env_stride, row_stride, T, R, din, w1, b1, w2, b2, w3, b3, act,
+                         returns, old_values, clip, values, partials, grad, stats,
+                         max_workgroups, adam_param, adam_m, adam_v, adam_state, lr, beta1, beta2,
+                         eps, weight_decay, adam_step, grad_scale, xchg, stream, nullptr);
+}
+
+// One critic EPOCH in minibatches (the reference's class default is
+// num_minibatchs = 10: mprl/rl/agent/temporal_correlated_agent.py:25,343-366,
+// mprl/util/util_data_structure.py:378-391): row_index [R] = the epoch's
+// permutation of the rows (the caller draws it with numpy's global generator,
+// as the reference does), split like np.array_split into num_minibatches
+// consecutive pieces (the first R % k pieces one row longer); per piece ONE
+// optimizer step -- forward + value loss (mean over the piece) + backward over
+// the gathered rows, slab reduction, Adam -- in the permutation's order.
+// stats: float [num_minibatches][4], ZEROED BY THE CALLER: per piece {mean loss,
+// |grad|^2, |grad|, |grad| clipped} ([2], [3] only with grad_clip > 0 or an
+// exchange; else the caller takes sqrt of [1]).  adam_step: the step count
+// INCLUDING the first piece's update; grad_clip: clip_grad_norm (<= 0: none).
+int tce_mlp_critic_minibatch_f32(
+    const float* x, int64_t env_stride, int64_t row_stride, int T, int64_t R, int din,
+    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+    const float* b3, int act, const float* returns, const float* old_values, float clip,
+    const int64_t* row_index, int num_minibatches, float* partials, float* grad, float* stats,
+    int max_workgroups, float* adam_param, float* adam_m, float* adam_v, float* adam_state,
+    float lr, float beta1, float beta2, float eps, float weight_decay, float adam_step,
+    float grad_clip, float grad_scale, void* xchg, void* stream) {
+  TCE_CHECK_ARG(row_index && num_minibatches >= 1 && R >= num_minibatches,
+                "mlp_critic_minibatch: row index missing / more minibatches than rows");
+  TCE_CHECK_ARG(adam_param && adam_m && adam_v && adam_state && partials && grad && stats,
+                "mlp_critic_minibatch: optimizer / gradient buffers missing");
+  const int P = mlp_num_params(din);
+  TCE_CHECK_ARG(!(grad_clip > 0.f) || P <= (1 << 17),
+                "mlp_critic_minibatch: clipping needs num_params <= 2^17");
+  const bool fused = !(grad_clip > 0.f);
+  const int64_t base = R / num_minibatches, extra = R % num_minibatches;
+  int64_t off = 0;
+  for (int mb = 0; mb < num_minibatches; ++mb) {
+    const int64_t len = base + (mb < extra ? 1 : 0);
+    float* st4 = stats + 4 * mb;
+    const float step = adam_step + (float)mb;
+    int rc = mlp_critic_impl(x, env_stride, row_stride, T, len, din, w1, b1, w2, b2, w3, b3, act,
+                             returns, old_values, clip, nullptr, partials, grad, st4,
+                             max_workgroups, fused ? adam_param : nullptr, adam_m, adam_v,
+                             adam_state, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                             fused ? xchg : nullptr, stream, row_index + off);
+    if (rc) return rc;
+    if (!fused) {
+      rc = xchg ? tce_xchg_adam_f32(xchg, adam_param, grad, adam_m, adam_v, P, adam_state,
+                                    st4 + 2, step, lr, beta1, beta2, eps, weight_decay,
+                                    grad_clip, grad_scale, stream)
+                : tce_adam_once_f32(adam_param, grad, adam_m, adam_v, P, adam_state, st4 + 2,
+                                    step, lr, beta1, beta2, eps, weight_decay, grad_clip,
+                                    grad_scale, stream);
+      if (rc) return rc;
+    }
+    off += len;
   }
   return 0;
 }

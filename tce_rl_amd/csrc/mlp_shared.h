@@ -67,6 +67,10 @@ struct MlpArgs {
   // dL/dH2 [R][HID] instead of the value loss; w3 / b3 are not used.
   float* hout;
   const float* gh;
+  // minibatch: logical row r of this launch is row row_index[r] of x / ret /
+  // old_v (generate_minibatches + select_batch,
+  // mprl/util/util_data_structure.py:362-391); nullptr: rows in place
+  const int64_t* row_index;
 };
 
 __host__ __device__ inline int mlp_num_params(int din) {

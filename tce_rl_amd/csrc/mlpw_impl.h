@@ -134,6 +134,9 @@ struct WArgs {
   real *h1s, *dy2s, *dy1s;                // [R][H], position order (backward)
   real* partials;                         // [grid][P + 2]
   int P;
+  // minibatch: logical row r is row row_index[r] of x / ret / old_v (the
+  // workspace rows h1s / dy2s / dy1s stay logical); nullptr: rows in place
+  const int64_t* row_index;
 };
 
 // fp32 chain-kernel shape (scripts/mlpw_variant.py builds others to compare)
@@ -500,6 +503,7 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
   auto load_x = [&](int64_t tile, real* dst) {
     int64_t r = tile * C::TILE + wave * 16 + m;
     if (r >= a.R) r = a.R - 1;
+    if (a.row_index) r = a.row_index[r];
     const int64_t ne = r / a.T;
     const int t = (int)(r - ne * a.T);
     const real* xp = a.x + ne * a.env_stride + t * a.row_stride + KPG * g;
@@ -524,8 +528,10 @@ __global__ __launch_bounds__(WCfg<real>::NT, 1) void mlpw_chain_kernel(WArgs<rea
     for (int s = 0; s < KPG; ++s) xb[s] = rok ? xn[s] : real(0);
     real rt = 0, ov = 0;
     if (BWD) {
-      rt = a.ret[rok ? r : a.R - 1];
-      if (a.clip > real(0)) ov = a.old_v[rok ? r : a.R - 1];
+      int64_t rp = rok ? r : a.R - 1;
+      if (a.row_index) rp = a.row_index[rp];
+      rt = a.ret[rp];
+      if (a.clip > real(0)) ov = a.old_v[rp];
     }
     // (FUSE / every backward build: the next tile's rows are requested in the
     // last backward step -- KPG registers (fp64: twice that) less through the tile)
@@ -1077,8 +1083,9 @@ __global__ __launch_bounds__(512, 1) void mlpw_grad_kernel(WArgs<real> a) {
       const int64_t r = r0 + row;
       real val = 0;
       if (idx < KC * LD::XW && r < r_hi && f < din) {
-        const int64_t ne = r / a.T;
-        const int t = (int)(r - ne * a.T);
+        const int64_t rp = a.row_index ? a.row_index[r] : r;
+        const int64_t ne = rp / a.T;
+        const int t = (int)(rp - ne * a.T);
         val = a.x[ne * a.env_stride + t * a.row_stride + f];
       }
       sx[q] = val;

@@ -79,6 +79,11 @@ __device__ inline double* stats_partials(unsigned* ghist) {
 }
 
 // pass == PASSES: the final launch (grid 1)
+// The sums are taken about a representative value (cancellation in
+// s2 - n md^2); an infinite or NaN first element is no representative -- the
+// differences would all be inf - inf = NaN where torch returns +-inf.
+__device__ inline double stats_shift(double x0) { return isfinite(x0) ? x0 : 0.0; }
+
 template <typename real, bool STATS>
 __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict__ x, int64_t n,
                                                           int pass, unsigned* __restrict__ ghist,
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict
           mn = fmin(mn, __shfl_xor(mn, off, 64));
         }
         if (t == 0) {
-          const double dn = (double)n, shift = (double)x[0];
+          const double dn = (double)n, shift = stats_shift((double)x[0]);
           const double md = s1 / dn;
           out[0] = shift + md;
           // (max / min of a tensor with a NaN are NaN in torch: the NaN count decides)
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void median_pass_kernel(const real* __restrict
   const int shift = 8 * (K::PASSES - 1 - pass);
   unsigned nans = 0;
   const bool st = STATS && pass == 0;
-  const double shift0 = st ? (double)x[0] : 0.0;
+  const double shift0 = st ? stats_shift((double)x[0]) : 0.0;
   double s1 = 0, s2 = 0, mx = -INFINITY, mn = INFINITY;
   for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += (int64_t)gridDim.x * 256) {
     const real v = x[i];

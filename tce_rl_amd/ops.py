@@ -670,10 +670,11 @@ def stats5(x, out=None):
     as a float64 [5] tensor (csrc/select.hip: the radix select's first pass
     carries the sums and extrema) -- the five entries of generate_stats
     (util_numerical.py:130-164) in ONE chain of launches.  float32 / float64
-    as they are; bool / integer tensors as float32 (exact up to 2^24)."""
+    as they are; bool / integer tensors as float64 (step counts and lengths
+    summed over envs exceed float32's 2^24)."""
     x = x.detach()
     if x.dtype not in (torch.float32, torch.float64):
-        x = x.to(torch.float32)
+        x = x.to(torch.float64)
     x = _c(x).reshape(-1)
     s = stream()
     key = (x.device, s)

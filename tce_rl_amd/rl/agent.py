@@ -257,6 +257,15 @@ class AbstractAgent(ABC):
             if bad:
                 raise Exception("NAN %s detected" % name)
 
+    def _critic_minibatches_fused(self):
+        """Can ``num_minibatchs`` optimizer steps per epoch run inside the
+        matrix-core critic epochs (tce_mlp_critic_minibatch_f32 /
+        tce_mlpw_critic_minibatch_*: gathered rows, one C call per epoch)?
+        Always for one minibatch; else whenever the gradient needs no
+        torch.distributed all-reduce between the kernels."""
+        k = int(getattr(self, "num_minibatchs", 1) or 1)
+        return k == 1 or not self.dist.active or self.xchg_critic is not None
+
     def close(self):
         """Env shards: release the peer-visible exchange buffers (collective --
         every rank calls it at the same point, before the process group is
@@ -283,8 +292,11 @@ class _CriticEpochs:
         opt = self.opt = agent.critic_optimizer
         run = getattr(agent, "_critic_runner", None)
         arith = getattr(agent, "critic_arith", "f32")
-        if critic_ops.wide_supported(agent.critic.net):
-            arith = "f32"            # exact matrix cores of the net's own dtype
+        if critic_ops.wide_supported(agent.critic.net) or \
+                int(getattr(agent, "num_minibatchs", 1) or 1) > 1:
+            # exact matrix cores of the net's own dtype (the split-operand
+            # kernels have no gathered-row form)
+            arith = "f32"
         if run is None or run.mlp is not agent.critic.net or \
                 run.flat is not opt.flat_grad or run.arith != arith:
             run = agent._critic_runner = critic_ops.make_runner(
@@ -292,8 +304,16 @@ class _CriticEpochs:
         self.runner = run
         opt.bind_grads()
         self.E = agent.epochs_critic
-        # per epoch {mean loss, |g|^2 (accumulated by the kernel), |g|, |g| clipped}
-        self.rows = torch.zeros(self.E, 4, dtype=agent.critic.net.dtype,
+        # minibatches (the reference's class default is 10,
+        # temporal_correlated_agent.py:25,343-366): an epoch is ONE C call that
+        # takes `k` optimizer steps over gathered rows
+        self.k = int(getattr(agent, "num_minibatchs", 1) or 1)
+        self.n_rows = int(returns.numel())
+        self._perm_ring = []
+        # per optimizer step {mean loss, |g|^2 (accumulated by the kernel), |g|,
+        # |g| clipped}
+        self.rows = torch.zeros(self.E * self.k, 4,
+                                dtype=agent.critic.net.dtype,
                                 device=agent.device)
         # env shards: the exchange rides in the launch that applies Adam
         self.xchg = agent.xchg_critic if agent.dist.active else None
@@ -302,7 +322,47 @@ class _CriticEpochs:
             and not agent.clip_grad_norm > 0
         self.done = 0
 
+    def _permutation(self):
+        """The epoch's row permutation on the device.  "numpy" (default): the
+        reference's own draw -- np.random.shuffle of arange(n) on numpy's GLOBAL
+        generator (generate_minibatches, util_data_structure.py:378-391), i.e.
+        the same minibatches as the reference from the same seed; a sequential
+        Fisher-Yates on the host (~13 ns per row), uploaded through one of two
+        pinned buffers while the previous epoch runs.  "device":
+        torch.randperm on the GPU (the device generator) -- statistically the
+        same, not the reference's sequence; for runs where the host draw
+        (28 ms per epoch at 2 M rows) would be the step."""
+        ag, n = self.agent, self.n_rows
+        if getattr(ag, "minibatch_permutation", "numpy") == "device":
+            return torch.randperm(n, device=ag.device, dtype=torch.int64)
+        idx = np.arange(n)
+        np.random.shuffle(idx)
+        if len(self._perm_ring) < 2:
+            host = torch.empty(n, dtype=torch.int64).pin_memory()
+            self._perm_ring.append([host, None])
+        slot = self._perm_ring[0]
+        self._perm_ring.reverse()
+        if slot[1] is not None:
+            slot[1].synchronize()         # its previous upload has left the host
+        slot[0].numpy()[:] = idx
+        dev = slot[0].to(ag.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return dev
+
+    def _run_minibatched(self, n, max_workgroups):
+        ag, opt, k = self.agent, self.opt, self.k
+        for e in range(self.done, min(self.E, self.done + n)):
+            self.runner.epoch_minibatches(
+                self.x, self.returns, self.old_values, ag.clip_critic,
+                self._permutation(), k, self.rows[e * k:(e + 1) * k], opt,
+                grad_clip=ag.clip_grad_norm, max_workgroups=max_workgroups,
+                xchg=self.xchg, grad_scale=self.gscale)
+            self.done = e + 1
+
     def run(self, n, max_workgroups=0):
+        if self.k > 1:
+            return self._run_minibatched(n, max_workgroups)
         ag, opt, rows = self.agent, self.opt, self.rows
         for e in range(self.done, min(self.E, self.done + n)):
             fused = self.fuse_adam
@@ -570,7 +630,18 @@ class TemporalCorrelatedAgent(AbstractAgent):
 
     # ---- critic and policy updates side by side ------------------------------
     def _can_overlap(self):
-        return self.overlap_updates and self.num_minibatchs == 1
+        """Critic and policy updates side by side: both must be enqueued
+        without a host read in between -- one minibatch, or minibatches inside
+        the fused critic epochs (the policy update is full-batch always:
+        temporal_correlated_agent.py:381-639)."""
+        if not self.overlap_updates:
+            return False
+        if self.num_minibatchs == 1:
+            return True
+        from .. import critic_ops
+        return self.device.type == "cuda" and \
+            critic_ops.supported(self.critic.net) and \
+            self._critic_minibatches_fused()
 
     def _update_overlapped(self, dataset, side_work=None, lazy=False):
         """The critic and policy updates of one iteration touch disjoint
@@ -862,7 +933,7 @@ class TemporalCorrelatedAgent(AbstractAgent):
         returns = dataset["step_returns"]
         from .. import critic_ops
         fused = critic_ops.supported(self.critic.net) and \
-            self.num_minibatchs == 1
+            self._critic_minibatches_fused()
         if fused:
             finish = self._update_critic_fused(states[..., :-D2], returns,
                                                old_values, max_workgroups)
@@ -1331,17 +1402,19 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         matrix-core epochs of the TCE critics: box pushing's 256 x 2), None
         (op by op / HIP graph)."""
         from .. import critic_ops, pmlp_ops, smlp_ops
-        if not (self.small_net_kernels and self.num_minibatchs == 1):
+        if not self.small_net_kernels:
             return None
-        if smlp_ops.critic_supported(self):
+        one = self.num_minibatchs == 1       # (row kernels: full batch only)
+        if one and smlp_ops.critic_supported(self):
             return "smlp"
         if self.device.type != "cuda":
             return None
         net, opt = self.critic.net, self.critic_optimizer
         if critic_ops.supported(net) and smlp_ops._opt_matches(
-                opt, list(net.parameters())):
+                opt, list(net.parameters())) and \
+                self._critic_minibatches_fused():
             return "fused"
-        if pmlp_ops.critic_supported(self):
+        if one and pmlp_ops.critic_supported(self):
             return "pmlp"
         return None
 
@@ -1351,7 +1424,9 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         128 x 2 kernels) or None."""
         from .. import smlp_ops
         L_old = dataset["segment_params_L"]
-        if not (self.small_net_kernels and self.num_minibatchs == 1):
+        # (the policy update is full-batch whatever num_minibatchs says:
+        # black_box_agent.py:159-389 has no generate_minibatches)
+        if not self.small_net_kernels:
             return None
         if smlp_ops.policy_supported(self, L_old):
             return "smlp"
@@ -1366,7 +1441,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # stream, the policy's on the agent's second group from the main stream --
         # in the same host order on every rank, and nothing waits for the device)
         if self.lazy_metrics and self.overlap_updates and \
-                self.small_net_kernels and self.num_minibatchs == 1 and \
+                self.small_net_kernels and \
                 self.device.type == "cuda" and \
                 self.projection.initial_entropy is not None and \
                 self._critic_path() is not None and \
@@ -1388,8 +1463,9 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         # (the lazy step needs both updates on the hand-written kernels -- no
         # graph, no autograd, deferrable reads: known from here on)
         self._bb_small_policy = bool(small)
-        if self.overlap_updates and self.num_minibatchs == 1 and \
-                (small or (self.graph_epochs and not self.dist.active)):
+        if self.overlap_updates and \
+                (small or (self.num_minibatchs == 1 and self.graph_epochs
+                           and not self.dist.active)):
             # the two updates are independent chains of ~100 small launches per
             # epoch, replayed from HIP graphs: side by side on two streams
             main = torch.cuda.current_stream()

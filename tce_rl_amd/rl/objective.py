@@ -374,7 +374,7 @@ class BBDirectEpoch:
 
     @staticmethod
     def supported(agent, states, L_old):
-        return bb_supported(agent, L_old) and agent.num_minibatchs == 1 and \
+        return bb_supported(agent, L_old) and \
             DirectEpoch.kind(agent, states) is not None
 
     def __init__(self, agent, states, context):

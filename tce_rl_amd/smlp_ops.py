@@ -145,7 +145,7 @@ def policy_supported(agent, L_old):
     net = pol.mean_net
     return (supported(net, HEAD_BB_POLICY) and not pol.contextual_cov
             and type(proj) is KLProjectionLayer and not proj.entropy_first
-            and ops.split_L(L_old)[1] == 0 and agent.num_minibatchs == 1
+            and ops.split_L(L_old)[1] == 0
             and _opt_matches(agent.policy_optimizer,
                              list(net.parameters()) +
                              [pol.variance_net.variable]))

@@ -86,6 +86,22 @@ def test_stats5_bool_int_and_nan():
     x[17] = float("nan")
     got = ops.stats5(x).cpu()
     assert torch.isnan(got).all()                # as torch: every entry NaN
+    # integers above float32's 2^24 keep their value ...
+    big = torch.tensor([2 ** 24 + 1, 2 ** 24 + 3, 2 ** 24 + 5], device="cuda")
+    assert ops.stats5(big).cpu()[:4].tolist() == [
+        2.0 ** 24 + 3, 2.0 ** 24 + 5, 2.0 ** 24 + 1, 2.0 ** 24 + 3]
+    # ... and an infinite FIRST element is not taken as the sums' shift:
+    # mean / max as torch gives them (inf), not NaN
+    y = torch.randn(4000, device="cuda", dtype=torch.float64)
+    y[0] = float("inf")
+    got = ops.stats5(y).cpu()
+    assert got[0].item() == float("inf") and got[1].item() == float("inf")
+    assert got[2].item() == y[1:].min().item()
+    # an outlier first element: the variance does not cancel away
+    z = torch.randn(100000, device="cuda", dtype=torch.float64)
+    z[0] = 1e6
+    torch.testing.assert_close(ops.stats5(z).cpu()[4], z.std().cpu(),
+                               rtol=1e-9, atol=0)
 
 
 def test_device_stats_uses_the_fused_chain():
