@@ -381,6 +381,17 @@ int tce_rms_normalize_f32(const float* x, float* y, int64_t total, int D,
                           const float* mean, const float* var, float eps, void* stream);
 int tce_rms_normalize_f64(const double* x, double* y, int64_t total, int D,
                           const double* mean, const double* var, double eps, void* stream);
+
+/* select_batch (mprl/util/util_data_structure.py:362-375) for the black-box
+ * critic's minibatches (black_box_agent.py:124-131): x_out [n, din] =
+ * x[idx[i], :din] (rows of x at x_stride elements), a_out [n] = a[idx[i]],
+ * b_out [n] = b[idx[i]] (b / b_out nullable); one launch. */
+int tce_gather_rows_f32(const float* x, int64_t x_stride, const float* a, const float* b,
+                        const int64_t* idx, int64_t n, int din, float* x_out, float* a_out,
+                        float* b_out, void* stream);
+int tce_gather_rows_f64(const double* x, int64_t x_stride, const double* a, const double* b,
+                        const int64_t* idx, int64_t n, int din, double* x_out, double* a_out,
+                        double* b_out, void* stream);
 int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,

@@ -9,6 +9,7 @@ TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Used by
 ``mprl/rl/agent/temporal_correlated_agent.py:38-100,323-639`` and
 ``mprl/rl/sampler/temporal_correlated_sampler.py:91-344``.
 """
+import numpy as np
 import torch
 
 from . import env_oracle as E
@@ -307,7 +308,7 @@ class OracleBBRL:
                  act, std_only, min_std, out_layer_gain, lr, epochs, mean_bound,
                  cov_bound, tr_coeff, set_variance, norm_advantages=True,
                  clip_advantages=0.0, clip_critic=0.0, dtype=torch.float32,
-                 balance=False, weight_decay=0.0):
+                 balance=False, weight_decay=0.0, num_minibatchs=1):
         mpa = dict(mp_args)
         mpa.pop("dtype", None), mpa.pop("device", None)
         self.mp = ProDMPOracle(dtype=dtype, **mpa)
@@ -342,6 +343,8 @@ class OracleBBRL:
         self.norm_advantages, self.clip_advantages = norm_advantages, \
             clip_advantages
         self.clip_critic = clip_critic
+        # critic minibatches (black_box_agent.py:124-131; class default 10)
+        self.num_minibatchs = int(num_minibatchs)
         self.forced_reset = self.forced_eps = None
         self.last = {}
 
@@ -379,11 +382,20 @@ class OracleBBRL:
                          segment_advantage=adv)
         no_beta = torch.tensor(-float("inf"), dtype=self.dtype)  # no entropy control
         for _ in range(self.epochs):
-            v = self._mlp(self.cnet, obs).squeeze(-1)
-            loss = O.value_loss(v, reward, values, self.clip_critic)
-            self.c_opt.zero_grad(set_to_none=True)
-            loss.backward()
-            self.c_opt.step()
+            if self.num_minibatchs == 1:   # the permutation leaves a full-batch mean
+                splits = [slice(None)]
+            else:   # generate_minibatches (util_data_structure.py:378-391)
+                idx = np.arange(N)
+                np.random.shuffle(idx)
+                splits = [torch.as_tensor(x) for x in
+                          np.array_split(idx, self.num_minibatchs)]
+            for sel in splits:
+                v = self._mlp(self.cnet, obs[sel]).squeeze(-1)
+                loss = O.value_loss(v, reward[sel], values[sel],
+                                    self.clip_critic)
+                self.c_opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self.c_opt.step()
         params = list(self.pnet) + [self.var]
 
         def grad_norm():                 # util.grad_norm_clip(0.0, params)[0]

@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void mdp_reward_kernel(real* __restrict__ r,
 
 }  // namespace
 
+// select_batch (mprl/util/util_data_structure.py:362-375) for the row kernels of
+// the black-box critic: x_out[i, :] = x[idx[i], :din], a_out[i] = a[idx[i]],
+// b_out[i] = b[idx[i]] (b nullable) -- one launch per minibatch; the envs of a
+// black-box batch are a few MB, so gathered copies cost nothing (the big TCE
+// critics read the index inside their epoch kernels instead: csrc/mlp.hip).
+template <typename real>
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const real* __restrict__ x, int64_t x_stride, const real* __restrict__ a,
+    const real* __restrict__ b, const int64_t* __restrict__ idx, int64_t n, int din,
+    real* __restrict__ x_out, real* __restrict__ a_out, real* __restrict__ b_out) {
+  const int64_t total = n * din;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / din;
+    const int f = (int)(e - i * din);
+    x_out[e] = x[idx[i] * x_stride + f];
+  }
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx[i];
+    a_out[i] = a[r];
+    if (b) b_out[i] = b[r];
+  }
+}
+
 extern "C" {
 
 #define TCE_RMS_BLOCKS 1024
@@ -183,6 +206,19 @@ int64_t tce_rms_num_partials(void) { return TCE_RMS_BLOCKS; }
     const int64_t nb = tmin<int64_t>(ceil_div(total, 256), 8192);                  \
     hipLaunchKernelGGL(rms_normalize_kernel<REAL>, dim3((unsigned)nb), dim3(256),  \
                        0, (hipStream_t)stream, x, y, total, D, mean, var, eps);    \
+    TCE_LAUNCH_CHECK();                                                            \
+    return 0;                                                                      \
+  }                                                                                \
+  int tce_gather_rows_##SFX(const REAL* x, int64_t x_stride, const REAL* a,        \
+                            const REAL* b, const int64_t* idx, int64_t n, int din, \
+                            REAL* x_out, REAL* a_out, REAL* b_out, void* stream) { \
+    TCE_CHECK_ARG(x && a && idx && x_out && a_out && (!b || b_out) && n > 0 &&     \
+                      din > 0,                                                     \
+                  "gather_rows: bad arguments");                                   \
+    const int64_t nb = tmin<int64_t>(ceil_div(n * din, 256), 4096);                \
+    hipLaunchKernelGGL(gather_rows_kernel<REAL>, dim3((unsigned)nb), dim3(256), 0, \
+                       (hipStream_t)stream, x, x_stride, a, b, idx, n, din, x_out, \
+                       a_out, b_out);                                              \
     TCE_LAUNCH_CHECK();                                                            \
     return 0;                                                                      \
   }                                                                                \

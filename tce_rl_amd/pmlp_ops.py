@@ -111,7 +111,8 @@ def critic_supported(agent):
     critic, mprl/config/table_tennis_4d/bbrl/entire/shared.yaml:90-91)."""
     from .smlp_ops import _opt_matches
     net, opt = agent.critic.net, agent.critic_optimizer
-    return (net.dim_out == 1 and supported(net) and agent.num_minibatchs == 1
+    from .smlp_ops import minibatches_ok
+    return (net.dim_out == 1 and supported(net) and minibatches_ok(agent)
             and _opt_matches(opt, list(net.parameters()))
             and opt.flat_param.numel() <= (1 << 17)
             and opt.flat_param.data_ptr() % 16 == 0)
@@ -133,20 +134,27 @@ def critic_update(agent, states, returns, old_values):
     old = old_values.reshape(-1).contiguous() if agent.clip_critic > 0 \
         else None
     cache = net.__dict__.setdefault("_tce_pmlp_ws", {})
-    ws = cache.get(("ws", N))
-    if ws is None:
-        # zeroed once: the loss kernel re-arms its ticket itself (one batch
-        # size at a time: a workspace of another N is let go)
-        for k in [k for k in cache if k != "partials"]:
-            del cache[k]
-        ws = cache[("ws", N)] = torch.zeros(
-            lib.tce_pmlp_critic_ws_len(N, H), dtype=dt, device=dev)
+
+    def workspace(n):
+        ws = cache.get(("ws", n))
+        if ws is None:
+            # zeroed once: the loss kernel re-arms its ticket itself (a few
+            # batch sizes at a time -- the two piece lengths of a minibatched
+            # epoch --, older ones are let go)
+            old_keys = [k for k in cache if k != "partials"]
+            if len(old_keys) > 2:
+                for k in old_keys:
+                    del cache[k]
+            ws = cache[("ws", n)] = torch.zeros(
+                lib.tce_pmlp_critic_ws_len(n, H), dtype=dt, device=dev)
+        return ws
     partials = cache.get("partials")
     if partials is None:
         P = lib.tce_pmlp_num_params(din, H, NL, 1)
         partials = cache["partials"] = torch.empty(
             lib.tce_pmlp_max_slabs() * P, dtype=dt, device=dev)
-    rec = torch.zeros(E, 3, dtype=dt, device=dev)
+    kmb = int(agent.num_minibatchs)
+    rec = torch.zeros(E * kmb, 3, dtype=dt, device=dev)
     g = opt.param_groups[0]
     opt.bind_grads()
     # env shards: the Adam launch adds the peers' gradients (agent.xchg_critic);
@@ -154,18 +162,36 @@ def critic_update(agent, states, returns, old_values):
     xch = agent.xchg_critic if agent.dist.active else None
     sharded = agent.dist.active and xch is None
     gscale = 1.0 / agent.dist.world if xch is not None else 1.0
+
+    def one(xr, rr, orr, rec_row):
+        n = xr.shape[0]
+        call("tce_pmlp_critic_epoch_" + sfx(dt), ptr(xr), xr.stride(0),
+             ptr(rr), ptr(orr), n, din, H, NL,
+             _ACT[net.act_func_hidden_type], float(agent.clip_critic),
+             ptr(opt.flat_param), ptr(opt.flat_grad), ptr(opt.m), ptr(opt.v),
+             ptr(opt.dev_state), float(g["lr"]), float(g["betas"][0]),
+             float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+             float(agent.clip_grad_norm), gscale, int(not sharded),
+             float(opt.host_step), ptr(workspace(n)), ptr(partials),
+             ptr(rec_row), None if xch is None else xch.handle, stream())
+    if kmb > 1:
+        # one optimizer step per piece of the epoch's permutation
+        # (black_box_agent.py:124-146) on a gathered copy of its rows
+        from .smlp_ops import gather_rows, minibatch_pieces
+        assert not sharded
+        row = 0
+        for _ in range(E):
+            for idx in minibatch_pieces(N, kmb, dev):
+                opt.host_step += 1
+                one(*gather_rows(net, x[:, :din], ret, old, idx), rec[row])
+                row += 1
+        opt._opt_called = True
+        return rec
     for e in range(E):
         if not sharded:
             opt.host_step += 1
             opt._opt_called = True            # for LinearLR's order check
-        call("tce_pmlp_critic_epoch_" + sfx(dt), ptr(x), x.stride(0), ptr(ret),
-             ptr(old), N, din, H, NL, _ACT[net.act_func_hidden_type],
-             float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
-             ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
-             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-             float(g["weight_decay"]), float(agent.clip_grad_norm), gscale,
-             int(not sharded), float(opt.host_step), ptr(ws), ptr(partials),
-             ptr(rec[e]), None if xch is None else xch.handle, stream())
+        one(x, ret, old, rec[e])
         if sharded:
             # the loss is the shard's own mean (as on the other sharded paths);
             # sum of the shards' gradients, then clip + Adam + the two norms

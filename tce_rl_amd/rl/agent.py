@@ -1404,8 +1404,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
         from .. import critic_ops, pmlp_ops, smlp_ops
         if not self.small_net_kernels:
             return None
-        one = self.num_minibatchs == 1       # (row kernels: full batch only)
-        if one and smlp_ops.critic_supported(self):
+        if smlp_ops.critic_supported(self):
             return "smlp"
         if self.device.type != "cuda":
             return None
@@ -1414,7 +1413,7 @@ class BlackBoxAgent(TemporalCorrelatedAgent):
                 opt, list(net.parameters())) and \
                 self._critic_minibatches_fused():
             return "fused"
-        if one and pmlp_ops.critic_supported(self):
+        if pmlp_ops.critic_supported(self):
             return "pmlp"
         return None
 

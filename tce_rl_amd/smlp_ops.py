@@ -80,9 +80,56 @@ def _workspace(owner, key, n, dtype=torch.float32):
     return buf
 
 
+def minibatches_ok(agent):
+    """The row kernels take the critic's minibatches (black_box_agent.py:
+    124-131; class default 10) as gathered copies of the rows, one epoch call
+    per piece -- whenever the step needs no torch.distributed all-reduce
+    between the kernels."""
+    return agent.num_minibatchs == 1 or not agent.dist.active or \
+        agent.xchg_critic is not None
+
+
+def minibatch_pieces(n, k, device):
+    """generate_minibatches (mprl/util/util_data_structure.py:378-391): the
+    epoch's permutation from numpy's GLOBAL generator -- the reference's own
+    draw, so the same pieces from the same seed -- as device index tensors."""
+    import numpy as np
+    idx = np.arange(n)
+    np.random.shuffle(idx)
+    dev = torch.as_tensor(idx, device=device)
+    out, off = [], 0
+    for i in range(k):
+        ln = n // k + (1 if i < n % k else 0)
+        out.append(dev[off:off + ln])
+        off += ln
+    return out
+
+
+def gather_rows(owner, x, a, b, idx):
+    """select_batch: (x[idx], a[idx], b[idx]) as contiguous copies in buffers
+    kept on `owner` (tce_gather_rows_*: one launch, no aten indexing)."""
+    from ._lib import sfx
+    n, din = idx.numel(), x.shape[1]
+    cache = owner.__dict__.setdefault("_tce_gather", {})
+    key = (n, din, x.dtype)
+    bufs = cache.get(key)
+    if bufs is None:
+        if len(cache) > 4:
+            cache.clear()
+        bufs = cache[key] = (
+            torch.empty(n, din, dtype=x.dtype, device=x.device),
+            torch.empty(n, dtype=x.dtype, device=x.device),
+            torch.empty(n, dtype=x.dtype, device=x.device))
+    xo, ao, bo = bufs
+    call("tce_gather_rows_" + sfx(x.dtype), ptr(x), x.stride(0), ptr(a),
+         ptr(b), ptr(idx), n, din, ptr(xo), ptr(ao),
+         None if b is None else ptr(bo), stream())
+    return xo, ao, (None if b is None else bo)
+
+
 def critic_supported(agent):
     net = agent.critic.net
-    return supported(net, HEAD_VALUE) and agent.num_minibatchs == 1 and \
+    return supported(net, HEAD_VALUE) and minibatches_ok(agent) and \
         _opt_matches(agent.critic_optimizer, list(net.parameters()))
 
 
@@ -96,14 +143,18 @@ def critic_update(agent, states, returns, old_values):
     ret = returns.reshape(-1).contiguous()
     old = old_values.reshape(-1).contiguous() if agent.clip_critic > 0 \
         else None
-    ws = _workspace(net, ("ws", N), lib.tce_smlp_ws_len(N, net.dim_in, H, 1))
-    rec = torch.zeros(E, 3, dtype=torch.float32, device=x.device)
+    k = int(agent.num_minibatchs)
+    rec = torch.zeros(E * k, 3, dtype=torch.float32, device=x.device)
     g = opt.param_groups[0]
     opt.bind_grads()
 
-    def launch(epochs, do_adam, rec_rows, scale, xch=None):
-        call("tce_smlp_critic_epochs_f32", ptr(x), x.stride(0), ptr(ret),
-             ptr(old), N, net.dim_in, H, _ACT[net.act_func_hidden_type],
+    def launch(epochs, do_adam, rec_rows, scale, xch=None, rows=None):
+        xr, rr, orr = (x, ret, old) if rows is None else rows
+        n = xr.shape[0]
+        ws = _workspace(net, ("ws", n),
+                        lib.tce_smlp_ws_len(n, net.dim_in, H, 1))
+        call("tce_smlp_critic_epochs_f32", ptr(xr), xr.stride(0), ptr(rr),
+             ptr(orr), n, net.dim_in, H, _ACT[net.act_func_hidden_type],
              float(agent.clip_critic), ptr(opt.flat_param), ptr(opt.flat_grad),
              ptr(opt.m), ptr(opt.v), ptr(opt.dev_state), float(g["lr"]),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
@@ -111,6 +162,27 @@ def critic_update(agent, states, returns, old_values):
              int(do_adam), opt.host_step + 1, epochs, ptr(ws), ptr(rec_rows),
              None if xch is None else xch.handle, stream())
     xch = agent.xchg_critic if agent.dist.active else None
+    if k > 1:
+        # one optimizer step per piece of the epoch's permutation
+        # (black_box_agent.py:124-146), each the row kernels' one-epoch call on
+        # a gathered copy of its rows
+        scale = 1.0 / agent.dist.world if xch is not None else 1.0
+        row = 0
+        for _ in range(E):
+            for idx in minibatch_pieces(N, k, x.device):
+                launch(1, True, rec[row:row + 1], scale, xch,
+                       rows=gather_rows(net, x[:, :net.dim_in], ret, old, idx))
+                opt.host_step += 1
+                row += 1
+        opt._opt_called = True
+        if xch is None:
+            before = rec[:, 1].sqrt()
+            after = before
+            if agent.clip_grad_norm > 0:
+                after = before * torch.clamp(
+                    agent.clip_grad_norm / (before + 1e-6), max=1.0)
+            rec[:, 1], rec[:, 2] = before, after
+        return rec
     if not agent.dist.active or xch is not None:
         # (env shards: a small launch behind the slab reduction adds the peers'
         # gradients and applies Adam -- the E epochs stay ONE call)

@@ -554,7 +554,8 @@ def test_bbrl_kept_graphs_equal_fresh_graphs_over_iterations():
             assert abs(res[k] - out[2][0][k]) <= 1e-6 * abs(out[2][0][k]) + 1e-8
 
 
-@pytest.mark.parametrize("mode", ["small", "op_by_op", "fused"])
+@pytest.mark.parametrize("mode", ["small", "op_by_op", "fused",
+                                  "small_minibatch3"])
 def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
     """One BlackBoxAgent.step() (a16) against the CPU oracle step on the same
     weights, env state and parameter noise: on the hand-written row kernels of
@@ -565,6 +566,12 @@ def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
     N, EPOCHS = 24, 3
     agent, d_in = build_bbrl(N, EPOCHS)
     agent.evaluation_interval = 0
+    # small_minibatch3: the critic's minibatches (black_box_agent.py:124-131;
+    # the class default is 10) on the row kernels, gathered pieces of numpy's
+    # permutation -- same path assertions as "small"
+    nmb = 3 if mode == "small_minibatch3" else 1
+    mode = "small" if nmb > 1 else mode
+    agent.num_minibatchs = nmb
     agent.small_net_kernels = mode == "small"
     agent.fused_policy_objective = mode == "fused"   # tce_bb_policy_objective_*
     calls = {"c": 0, "p": 0}
@@ -577,7 +584,7 @@ def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
     # check, black_box_agent.py:218-284; the other two paths do not have it)
     oracle = OracleBBRL(BB_MP, N, d_in, [32, 32], [32, 32], "relu", True, 1e-5,
                         0.01, 3e-4, EPOCHS, 0.005, 0.0005, 1.0, True,
-                        balance=mode == "small")
+                        balance=mode == "small", num_minibatchs=nmb)
     with torch.no_grad():
         for po, pg in zip(oracle.pnet, agent.policy.mean_net.parameters()):
             po.copy_(pg.cpu())
@@ -607,7 +614,9 @@ def test_bbrl_step_matches_cpu_oracle(mode, monkeypatch):
                          if torch.is_tensor(v) and k != "segment_params_L"})
         return out
     agent.process_dataset = grab
+    np.random.seed(5)                       # (the minibatch permutations)
     res = dict(agent.step())
+    np.random.seed(5)
     oracle.step()
     ref = oracle.last
     _check_bbrl_metrics(res, oracle, 2e-4, balance=mode == "small")
@@ -685,9 +694,9 @@ BBRL_MID = {
 }
 
 
-@pytest.mark.parametrize("balance", [False, True])
+@pytest.mark.parametrize("balance,nmb", [(False, 1), (True, 1), (False, 4)])
 @pytest.mark.parametrize("shape", sorted(BBRL_MID))
-def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
+def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, nmb, monkeypatch):
     """One BlackBoxAgent.step() with the reference's OTHER black-box nets -- box
     pushing's 128 x 2 policy / 256 x 2 critic, table tennis's 256 x 1 / 256 x 1
     (full covariance, leaky relu, weight decay) -- against the CPU oracle: the
@@ -709,6 +718,10 @@ def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
         clip_critic=cfg["clip_critic"], balance_check=25 if balance else False,
         lr_policy=LR, lr_critic=LR)
     agent.evaluation_interval = 0
+    # nmb 4: the critic's minibatches (class default 10) on the same kernels --
+    # the matrix-core epochs read the permutation in place, the row kernels of
+    # csrc/pmlp.hip take gathered pieces
+    agent.num_minibatchs = nmb
     assert agent.num_iterations == 0           # the first step is 1 = 1 mod 25
     # which implementation ran
     calls = {"direct": 0, "pmlp_critic": 0, "linear": 0}
@@ -727,7 +740,8 @@ def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
                         hid(cfg["critic_hidden"]), cfg["act"], cfg["std_only"],
                         1e-5, 0.01, LR, EPOCHS, 0.005, 0.0005, 1.0, True,
                         clip_critic=cfg["clip_critic"], dtype=dt,
-                        balance=balance, weight_decay=cfg["wd"])
+                        balance=balance, weight_decay=cfg["wd"],
+                        num_minibatchs=nmb)
     with torch.no_grad():
         for po, pg in zip(oracle.pnet, agent.policy.mean_net.parameters()):
             po.copy_(pg.cpu())
@@ -757,7 +771,9 @@ def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
                          if torch.is_tensor(v) and k != "segment_params_L"})
         return out
     agent.process_dataset = grab
+    np.random.seed(5)                       # (the minibatch permutations)
     res = dict(agent.step())
+    np.random.seed(5)
     oracle.step()
     ref = oracle.last
     f64 = dt == torch.float64
@@ -776,7 +792,9 @@ def test_bbrl_midsize_nets_match_cpu_oracle(shape, balance, monkeypatch):
     _close("segment_advantage", captured["segment_advantage"],
            ref["segment_advantage"], t(1e-5, 1e-9))
     for pg, po in zip(agent.critic.net.parameters(), oracle.cnet):
-        _close("critic", pg.detach().cpu(), po.detach(), t(5e-6, 1e-8))
+        # (minibatches: nmb x the Adam steps, on 6-row pieces)
+        _close("critic", pg.detach().cpu(), po.detach(),
+               t(5e-6 * nmb, 1e-8 * nmb))
     for pg, po in zip(agent.policy.mean_net.parameters(), oracle.pnet):
         # (balance: 10 x the step size, twice the steps -- Adam's step is
         # lr * m / (sqrt(v) + eps), deviations scale with lr)
