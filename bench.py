@@ -532,6 +532,27 @@ OTHER_CONFIGS = [
                  "epoch carried as two f16 parts (22 bits), fp32 accumulate, "
                  "on v_mfma_f32_16x16x32_f16 (csrc/mlp16.hip); parity-tested to "
                  "the fp32 kernel's own error bounds, but narrower than fp32")),
+    # the reference's CLASS DEFAULT num_minibatchs = 10 (every shipped YAML sets 1):
+    # 50 epochs x 10 optimizer steps on gathered rows, one C call per epoch
+    # (tce_mlp_critic_minibatch_f32).  Twice: with the reference's own permutation
+    # draw (numpy's global MT19937 Fisher-Yates over 2 M rows on the host --
+    # sequential by construction, ~28 ms per epoch: that entry is HOST-bound and
+    # says so) and with torch.randperm on the device
+    ("C2_minibatch10", dict(
+        kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
+        dtype="float32", num_minibatchs=10, steps=2, warmup=2,
+        workload="configs[1] with the reference's class default num_minibatchs "
+                 "= 10 (temporal_correlated_agent.py:25,343-366): 500 critic "
+                 "steps per iteration on gathered 204 800-row pieces, the "
+                 "permutations drawn as the reference draws them "
+                 "(np.random.shuffle on the host: the step is bound by that "
+                 "draw, see host_permutation_ms_per_step)")),
+    ("C2_minibatch10_device_perm", dict(
+        kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
+        dtype="float32", num_minibatchs=10, minibatch_permutation="device",
+        workload="the same with agent option minibatch_permutation=device "
+                 "(torch.randperm on the GPU: statistically the same pieces, "
+                 "not numpy's sequence)")),
     # the multi-GPU configs at their FULL size on this one GPU (they fit: 288 GB):
     # the denominators of the strong-scaling curves (N GPUs x N-th of the envs)
     ("C4_bbrl_full_16384", dict(
@@ -561,6 +582,9 @@ def build_config_agent(spec, seed=0):
                          evaluation_interval=0)
         if spec.get("critic_arith"):
             cfg["params"]["agent"]["args"]["critic_arith"] = spec["critic_arith"]
+    for k in ("num_minibatchs", "minibatch_permutation"):
+        if k in spec:
+            cfg["params"]["agent"]["args"][k] = spec[k]
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)
     return exp.agent
@@ -608,6 +632,18 @@ def _run_config(name, spec, steps, warmup):
            "ms_per_step": round(el / steps * 1e3, 2),
            "env_steps_per_sec": round(N * T * steps / el, 1),
            "sampling_ms": round(samp / steps * 1e3, 2)}
+    if spec.get("num_minibatchs", 1) > 1:
+        out["num_minibatchs"] = spec["num_minibatchs"]
+        out["minibatch_permutation"] = spec.get("minibatch_permutation",
+                                                "numpy")
+        if out["minibatch_permutation"] == "numpy":
+            import numpy as np
+            rows_mb = N * T if spec["kind"] == "tce" else N
+            tp = time.perf_counter()
+            for _ in range(3):
+                np.random.shuffle(np.arange(rows_mb))
+            out["host_permutation_ms_per_step"] = round(
+                (time.perf_counter() - tp) / 3 * 1e3 * spec["epochs"], 1)
     if bal_ms is not None:
         bc = agent.balance_check
         out["balance_check_iteration_ms"] = round(bal_ms, 2)

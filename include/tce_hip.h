@@ -1176,6 +1176,29 @@ int tce_pmlp_critic_epoch_f64(const double* x, int64_t x_stride, const double* r
  * to 4); proj_ctx: double [tce_kl_cov_proj_ctx_len(K)], zeroed by the caller
  * once per update; mean_new_out / proj_mean_out (nullable) [N,K]: the last
  * epoch's means. */
+/* Generic dense layer on the exact 16x16x4 matrix instructions (csrc/glin.hip)
+ * for MLP shapes none of the fused families covers -- the reference sizes its
+ * nets from arbitrary YAML numbers (mprl/util/util_hyperparams.py:8-46) and the
+ * contextual covariance head is a second MLP with K (K + 1) / 2 outputs
+ * (mprl/rl/policy/abstract_policy.py:96-109).  1 <= D_in, D_out <=
+ * tce_glin_max_dim() (4096).  forward: y [R][D_out] = x W^T + bias (x rows at
+ * x_stride elements, W torch Linear layout [D_out][D_in], bias nullable; the
+ * activation stays with the caller).  backward: grad_x [R][D_in] = grad_y W
+ * (nullable), grad_W [D_out][D_in] = grad_y^T x (the rows split over the chip,
+ * partial tiles summed in a fixed order), grad_b [D_out] = column sums of grad_y
+ * (nullable); ws: tce_glin_ws_len(R, D_in, D_out) elements. */
+int tce_glin_max_dim(void);
+int64_t tce_glin_ws_len(int64_t R, int din, int dout);
+int tce_glin_forward_f32(const float* x, int64_t x_stride, int64_t R, int din, int dout,
+                         const float* W, const float* bias, float* y, void* stream);
+int tce_glin_forward_f64(const double* x, int64_t x_stride, int64_t R, int din, int dout,
+                         const double* W, const double* bias, double* y, void* stream);
+int tce_glin_backward_f32(const float* x, int64_t x_stride, const float* grad_y, const float* W,
+                          int64_t R, int din, int dout, float* grad_x, float* grad_W,
+                          float* grad_b, float* ws, void* stream);
+int tce_glin_backward_f64(const double* x, int64_t x_stride, const double* grad_y,
+                          const double* W, int64_t R, int din, int dout, double* grad_x,
+                          double* grad_W, double* grad_b, double* ws, void* stream);
 /* Skinny linear layer on rows, y [N][dout] = x [N][din] A (+ bias): transposed
  * != 0: A = W^T for a torch Linear weight W [dout][din] (MLP.forward's output
  * layer, mprl/util/util_nn.py:225-246); transposed == 0: A = W for W

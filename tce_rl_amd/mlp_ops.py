@@ -1,11 +1,17 @@
 """MLP forward / backward dispatch.
 
-Library-GEMM path: the dense layers go through torch.nn.functional.linear
-(hipBLASLt / rocBLAS on ROCm -- plain library GEMMs) with torch autograd.  It is
-the reference-precision path for every MLP shape; the fused MFMA kernels of
-csrc/mlp.hip replace it for the critic's large-batch epochs (critic_ops), the
-row kernels of csrc/smlp.hip / csrc/pmlp.hip for the forward passes of the
-rollout (no autograd) of the small and of the policy-sized nets.
+The fused kernel families take the shapes they are built for: csrc/mlp.hip /
+mlpw the critic's large-batch epochs (critic_ops), the row kernels of
+csrc/smlp.hip / csrc/pmlp.hip the rollout forwards and the fused epochs of the
+small and the policy-sized nets.  EVERYTHING ELSE under autograd -- net widths
+the reference's YAMLs may ask for (mprl/util/util_hyperparams.py:8-46), the
+contextual covariance head (abstract_policy.py:96-109), the output layer behind
+the fused 128 x 2 hidden layers -- runs layer by layer on the generic dense
+layer of csrc/glin.hip (``HipLinear``: exact fp32 / fp64 matrix instructions,
+forward, input gradient, split-row weight gradient), since round 6.  Library
+GEMMs (torch.nn.functional.linear) remain only past that kernel's limits
+(a layer wider than 4096, a dtype other than float32 / float64): counted per
+shape and announced once.
 """
 import torch
 import torch.nn.functional as F
@@ -34,13 +40,9 @@ def _count_library(mlp, kind):
         import warnings
         warnings.warn(
             "tce_rl_amd: %s of the MLP %s -> %s -> %s (%s, %s) runs on library "
-            "GEMMs + torch autograd -- correct, but several times slower per "
-            "epoch.  Either its shape has no hand-written kernel family "
-            "(csrc/mlp.hip 128 x 2 fp32, mlpw 256 x 2 / fp64 value nets, smlp "
-            "32 / 64 x 2, pmlp 128 x 1 / 128 x 2 / 256 x 1) or the hand-written "
-            "epoch was switched off (fused_policy_objective / "
-            "direct_policy_epoch / small_net_kernels = false, a contextual "
-            "covariance, num_minibatchs > 1)"
+            "GEMMs + torch autograd -- correct, but off the hand-written path: "
+            "a layer wider than the generic dense kernel's limit "
+            "(csrc/glin.hip: 4096) or a dtype other than float32 / float64"
             % ("the output layer" if kind != "library" else "every layer",
                mlp.dim_in, list(mlp.hidden_layers), mlp.dim_out, mlp.dtype,
                mlp.act_func_hidden_type),
@@ -81,6 +83,70 @@ class _Linear(torch.autograd.Function):
         return gx, gw, g2.sum(0)
 
 
+class HipLinear(torch.autograd.Function):
+    """y = x W^T + b on csrc/glin.hip (tce_glin_forward_* / tce_glin_backward_*):
+    the dense layer of MLP.forward (mprl/util/util_nn.py:225-246) under
+    autograd without a library GEMM -- forward, dx = dy W, dW = dy^T x (the rows
+    split over the chip, partial tiles summed in a fixed order), db."""
+
+    @staticmethod
+    def supported(x, w):
+        from . import _lib
+        lim = _lib.load().tce_glin_max_dim()
+        return (x.is_cuda and x.dtype == w.dtype
+                and x.dtype in (torch.float32, torch.float64)
+                and w.shape[0] <= lim and w.shape[1] <= lim
+                and x.shape[-1] == w.shape[1] and x.numel() > 0)
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from ._lib import call, ptr, sfx, stream
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        wc = w if w.is_contiguous() else w.contiguous()
+        R, din = x2.shape
+        dout = wc.shape[0]
+        y = torch.empty(R, dout, dtype=x.dtype, device=x.device)
+        call("tce_glin_forward_" + sfx(x.dtype), ptr(x2), x2.stride(0), R, din,
+             dout, ptr(wc), ptr(b), ptr(y), stream())
+        ctx.save_for_backward(x2, wc)
+        ctx.has_bias = b is not None
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], dout)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from ._lib import call, ptr, sfx, stream
+        x2, w = ctx.saved_tensors
+        R, din = x2.shape
+        dout = w.shape[0]
+        g2 = g.reshape(R, dout)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = torch.empty(R, din, dtype=g.dtype, device=g.device) \
+            if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(dout, dtype=g.dtype, device=g.device) \
+            if ctx.has_bias else None
+        ws = torch.empty(_lib.load().tce_glin_ws_len(R, din, dout),
+                         dtype=g.dtype, device=g.device)
+        call("tce_glin_backward_" + sfx(g.dtype), ptr(x2), x2.stride(0),
+             ptr(g2), ptr(w), R, din, dout, ptr(gx), ptr(gw), ptr(gb), ptr(ws),
+             stream())
+        return (None if gx is None else gx.reshape(ctx.in_shape)), gw, gb
+
+
+def _linear(mlp, x, layer, kind):
+    """One dense layer under autograd: the generic hand-written kernel, the
+    library GEMM (counted) past its limits."""
+    if HipLinear.supported(x, layer.weight):
+        return HipLinear.apply(x, layer.weight, layer.bias)
+    _count_library(mlp, kind)
+    return _Linear.apply(x, layer.weight, layer.bias)
+
+
 def forward(mlp, x):
     if not x.is_cuda:
         raise RuntimeError("tce_rl_amd MLPs run on a HIP device only")
@@ -105,13 +171,11 @@ def forward(mlp, x):
         # both hidden layers (forward and backward) in the fused MFMA kernels,
         # only the output layer is a library GEMM
         h2 = critic_ops.hidden_forward(mlp, x)
-        _count_library(mlp, "hidden+library_out")
-        return F.linear(h2, layers[-1].weight, layers[-1].bias)
-    _count_library(mlp, "library")
+        return _linear(mlp, h2, layers[-1], "hidden+library_out")
     act = _ACT[mlp.act_func_hidden_type]
     for i in range(len(mlp.hidden_layers)):
-        x = act(_Linear.apply(x, layers[i].weight, layers[i].bias))
-    x = _Linear.apply(x, layers[-1].weight, layers[-1].bias)
+        x = act(_linear(mlp, x, layers[i], "library"))
+    x = _linear(mlp, x, layers[-1], "library")
     if mlp.act_func_last_type is not None:
         x = _ACT[mlp.act_func_last_type](x)
     return x

@@ -417,6 +417,17 @@ class TemporalCorrelatedAgent(AbstractAgent):
         self.clip_critic = float(kwargs.get("clip_critic", 0.0))
         self.clip_grad_norm = float(kwargs.get("clip_grad_norm", 0.0))
         self.num_minibatchs = kwargs.get("num_minibatchs", 10)
+        # who draws the critic's minibatch permutations: "numpy" = the
+        # reference's own draw on numpy's global generator
+        # (util_data_structure.py:389-390: same pieces from the same seed; a
+        # sequential host shuffle), "device" = torch.randperm on the GPU
+        # (statistically the same, not the reference's sequence)
+        self.minibatch_permutation = kwargs.get("minibatch_permutation",
+                                                "numpy")
+        if self.minibatch_permutation not in ("numpy", "device"):
+            raise NotImplementedError(
+                "minibatch_permutation=%r (numpy | device)"
+                % (self.minibatch_permutation,))
         self.norm_advantages = kwargs.get("norm_advantages", False)
         self.clip_advantages = kwargs.get("clip_advantages", False)
         self.entropy_penalty_coef = float(

@@ -935,6 +935,8 @@ def test_agent_options_match_cpu_oracle(opts, monkeypatch):
     overlap = opts.pop("overlap_updates", True)
     spy = _PathSpy(monkeypatch)
     mb_calls = []
+    if "_contextual" in opts or "_std_only" in opts:
+        mlp_ops.LIBRARY_CALLS.clear()
     if "num_minibatchs" in opts:
         orig = critic_ops.EpochRunner.epoch_minibatches
 
@@ -947,6 +949,11 @@ def test_agent_options_match_cpu_oracle(opts, monkeypatch):
     agent, oracle, res = _agent_vs_oracle(overlap, fused, graph, "metaworld",
                                           5, iterations=2, rel_scale=2.0,
                                           **opts)
+    if "_contextual" in opts or "_std_only" in opts:
+        # the contextual covariance head (a second MLP,
+        # abstract_policy.py:96-109) and the mean net's output layer run on
+        # the generic dense layer of csrc/glin.hip under autograd
+        assert not mlp_ops.LIBRARY_CALLS, dict(mlp_ops.LIBRARY_CALLS)
     if "num_minibatchs" in opts:
         # the reference's minibatched critic update
         # (temporal_correlated_agent.py:343-366; class default 10) on the

@@ -64,12 +64,13 @@ def test_c_abi_reports_bad_arguments():
 
 
 def test_limits_fall_back_or_raise_cleanly():
-    from tce_rl_amd import critic_ops, ops
+    from tce_rl_amd import critic_ops, mlp_ops, ops
     from tce_rl_amd.nn import MLP
+    mlp_ops.LIBRARY_CALLS.clear()
     wide = MLP("ValueFunction", 41, 1, [128, 128], "orthogonal", 1.0, "relu",
                None, torch.float32, torch.device("cuda"))
     assert not critic_ops.supported(wide)                  # D_in > 40
-    y = wide(torch.randn(5000, 41, device="cuda"))         # library path
+    y = wide(torch.randn(5000, 41, device="cuda"))         # generic dense layers
     assert y.shape == (5000, 1) and torch.isfinite(y).all()
     f64 = MLP("ValueFunction", 20, 1, [128, 128], "orthogonal", 1.0, "relu",
               None, torch.float64, torch.device("cuda"))
@@ -77,8 +78,11 @@ def test_limits_fall_back_or_raise_cleanly():
     odd = MLP("ValueFunction", 20, 1, [192, 192], "orthogonal", 1.0, "relu",
               None, torch.float32, torch.device("cuda"))
     assert not critic_ops.supported(odd)                   # widths 128 / 256 only
-    y = odd(torch.randn(5000, 20, device="cuda"))          # library path
+    y = odd(torch.randn(5000, 20, device="cuda"))          # generic dense layers
     assert y.shape == (5000, 1) and torch.isfinite(y).all()
+    # (shapes outside the fused families stay on
+    # hand-written kernels -- csrc/glin.hip -- under autograd)
+    assert not mlp_ops.LIBRARY_CALLS, dict(mlp_ops.LIBRARY_CALLS)
     big64 = MLP("ValueFunction", 40, 1, [256, 256], "orthogonal", 1.0, "relu",
                 None, torch.float64, torch.device("cuda"))
     assert not critic_ops.supported(big64)                 # fp64 x 256: D_in <= 24
