@@ -112,10 +112,11 @@ def kernel_time_cold_us(fn, launches=5):
     return sorted(ts)[len(ts) // 2]
 
 
-PMC_TAGS = ("r05", "r04", "r03", "r02", "r01e", "r01c")
-# (r05: the timed window only -- scripts/profiles_r05.sh, rocpd_stats.py
+PMC_TAGS = ("r06", "r05", "r04", "r03", "r02", "r01e", "r01c")
+# (r05 / r06: the timed window only -- scripts/profiles_r06.sh, rocpd_stats.py
 # --between-markers 1 2 --by-grid; earlier rounds: the whole run)
-STATS_CSV = ("r05_bench_kernel_stats_by_grid.csv", "r04_bench_kernel_stats.csv",
+STATS_CSV = ("r06_bench_kernel_stats_by_grid.csv",
+             "r05_bench_kernel_stats_by_grid.csv", "r04_bench_kernel_stats.csv",
              "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv")
 
 
@@ -136,10 +137,10 @@ def pmc_lookup(kernel):
 
 def mfma_busy(kernel):
     """(matrix-pipe utilisation of `kernel` alone on the chip, source file) from
-    the COMMITTED counter pass profiles/r04_pmc_mfma.json
+    the COMMITTED counter pass profiles/r06_pmc_mfma.json (else r04's)
     (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD) -- read from
     the file, not measured in this run; (None, None) if absent."""
-    for tag in ("r04",):
+    for tag in ("r06", "r04"):
         try:
             rel = os.path.join("profiles", tag + "_pmc_mfma.json")
             with open(os.path.join(REPO, rel)) as f:
@@ -263,6 +264,13 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
     for p, gr in zip(net.parameters(), saved):
         p.grad = gr
     flops = 6.0 * (din * 128 + 128 * 128 + 128) * N * T
+    # what the kernel EXECUTES per row: the forward pass
+    # 2 (din H + H H + H), dH1 = W2^T dY2 and dW2 (2 H H each), dW1 with db1 as
+    # a column of ones (2 (din + 1) H), dw3 (2 H) -- no input gradient of layer
+    # 1, which SURVEY 8d's "3 x forward" convention counts; mfma_busy (the
+    # matrix pipe's busy cycles, counters) is to be held against frac_executed
+    flops_exec = 2.0 * (din * 128 + 128 * 128 + 128 + 2 * 128 * 128 +
+                        (din + 1) * 128 + 128) * N * T
     # the timed steps hold envs_in_step envs per rank (4096 unless --scaling strong)
     flops_step = flops * (envs_in_step or N) / N
     us_step = critic_ms_in_step * 1e3 / EPOCHS
@@ -290,6 +298,9 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
               else round(flops / profiled_us(DOMINANT)[0] / 1e6
                          / F32_MFMA_PEAK_TF, 4),
               "algorithmic_flops": flops_step,
+              "executed_flops": flops_exec * (envs_in_step or N) / N,
+              "frac_executed": round(flops_exec * (envs_in_step or N) / N
+                                     / us_step / 1e6 / F32_MFMA_PEAK_TF, 4),
               "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
     if getattr(agent, "critic_arith", "f32") == "bf16x3":
         # --critic-arith bf16x3: the timed steps ran csrc/mlpb.hip; algorithmic
@@ -772,11 +783,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline():
+def cpu_baseline(full_size=False):
     """The CPU oracle (torch-CPU restatement of the reference path, kind
     'port') on a bounded sample: 64 envs (the reference's own cluster runs use
     16 - 38), full 50 + 50 epochs; three untimed warm-up steps, then the median
-    of ten timed steps.  ~20 s of CPU work."""
+    of ten timed steps.  ~20 s of CPU work.
+
+    full_size (``--cpu-full``): additionally ONE oracle step at the headline's
+    4096 envs on the host cores of this run (BASELINE.md section 3's "same
+    inputs in the same run"; minutes of CPU work, hence a flag) -- reported as
+    ``full_size`` beside the sample."""
     from tce_rl_amd.config import tce_config
     from oracle.agent_oracle import OracleTCE      # checker / baseline only
     n = 64
@@ -812,9 +828,25 @@ def cpu_baseline():
                 "env-steps/s" % (d["cores"], d["cpu"], d["value"]))
     except (OSError, KeyError, ValueError):
         pass
+    in_run = None
+    if full_size:
+        print("[bench] cpu_baseline: one oracle step at %d envs (minutes)"
+              % NUM_ENV, file=sys.stderr, flush=True)
+        cfg_f = tce_config("metaworld", num_env=NUM_ENV, num_basis=NUM_BASIS,
+                           epochs=EPOCHS, device="cpu")
+        of = OracleTCE(cfg_f["params"], NUM_ENV)
+        t = time.perf_counter()
+        steps_f = of.step()                         # (no warm-up: minutes each)
+        dt_f = time.perf_counter() - t
+        in_run = {"value": round(steps_f / dt_f, 1), "unit": "env-steps/s",
+                  "cores": threads, "seconds_per_step": round(dt_f, 1),
+                  "sample": "ONE torch-CPU oracle agent.step() at the "
+                            "headline's %d envs (T 500, 50 + 50 epochs), no "
+                            "warm-up, in this run" % NUM_ENV}
+        del of
     return {"value": round(steps / dt, 1), "unit": "env-steps/s",
             "cores": threads, "kind": "port", "cpu": cpu_model(),
-            "visible_cores": avail,
+            "visible_cores": avail, "full_size": in_run,
             "sample": "torch-CPU oracle agent.step() at %d envs (T 500, 50 "
                       "critic + 50 policy epochs): 3 warm-up steps, median of "
                       "10 timed steps = %.2f s (min %.2f, max %.2f)%s"
@@ -995,6 +1027,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="cpu_baseline additionally times ONE oracle step at "
+                         "the headline's 4096 envs on this run's host cores "
+                         "(~3.5 min; BASELINE.md section 3's definition)")
     ap.add_argument("--with-split-f16", action="store_true",
                     help="add a second timed region with the agent option "
                          "critic_arith=f16x2 (split-f16 critic kernel: an "
@@ -1271,7 +1307,7 @@ def main():
                                 "error vs fp64 at C2: 1.65e-6 (exact-fp32 kernel: 2.02e-6; "
                                 "tests/test_mlpb_gpu.py)"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_full)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if is_dist:

@@ -26,6 +26,7 @@
 // issued up front (one wave per SIMD may use the whole register file) and
 // each pass waits only for its own, so HBM streaming overlaps the chain.
 #include "common.h"
+#include <stdlib.h>
 
 // Keep mul and add un-fused: the scan must round exactly like the reference's
 // separate torch ops.
@@ -103,7 +104,7 @@ __device__ inline void store4(E* __restrict__ row, int t, int T, const E* x) {
 // around loads and hipcc emits counted vmcnt waits (a wave-uniform branch
 // around a load makes it wait vmcnt(0) at the join, which serialises the
 // stream).  NP_STATIC == 0: generic runtime pass count / multi-tile path.
-template <typename real, bool USE_GAE, bool VEC, int NP_STATIC>
+template <typename real, bool USE_GAE, bool VEC, int NP_STATIC, int PF = 4>
 __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
     const real* __restrict__ rewards, const real* __restrict__ values,
     const uint8_t* __restrict__ dones, const uint8_t* __restrict__ tl_dones,
@@ -138,9 +139,11 @@ __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
                                  : min(GAE_MAXP, (T - t0 + GAE_PSTEPS - 1) / GAE_PSTEPS);
     // ---- software pipeline: the loads of pass p - PF are issued before the
     // chain of pass p, so HBM streaming runs PF passes ahead of the chain
-    // (issuing the whole tile up front only fills the memory queues and
-    // stalls the in-order wave before it can start computing)
-    constexpr int PF = 4;
+    // (PF = 4: with ONE wave per SIMD -- 4096 envs = 1024 waves -- issuing the
+    // whole tile up front only fills the memory queues and stalls the in-order
+    // wave before it can start computing; PF = 8 = the whole tile: with several
+    // waves per SIMD -- 32768 envs -- the other waves compute meanwhile and the
+    // deeper queue is what a cold HBM stream needs, gae_launch picks)
     Vec4<real> rv[GAE_MAXP], vv[GAE_MAXP];
     Vec4<uint8_t> dn[GAE_MAXP], tl[GAE_MAXP];
     // V just above the tile (V_{t+1} of its last step) and V_T
@@ -420,6 +423,18 @@ __global__ __launch_bounds__(256) void segment_accrew_kernel(
     out[n * P + p] = (out[n * P + p] - mean) / d;
 }
 
+inline int gae_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <typename real>
 int gae_launch(const real* rewards, const real* values, const uint8_t* dones,
                const uint8_t* tl_dones, real* adv, real* ret,
@@ -434,10 +449,22 @@ int gae_launch(const real* rewards, const real* values, const uint8_t* dones,
                 "gae: segment outputs missing");
   const int64_t nblocks = ceil_div(N, GAE_ENVS_PER_BLOCK);
   TCE_CHECK_ARG(nblocks < (1ll << 31), "gae: too many envs");
+  // several waves per SIMD: prefetch the whole tile (see the kernel)
+  static const int pf_env = getenv("TCE_GAE_PF") ? atoi(getenv("TCE_GAE_PF")) : 0;
+  const bool deep = pf_env ? pf_env >= 8 : nblocks >= 2 * gae_cu_count();
 #define GAE_GO(G, V, NPS)                                                     \
-  hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS>), dim3((unsigned)nblocks), \
-                     dim3(GAE_BT), 0, stream, rewards, values, dones, tl_dones, \
-                     adv, ret, N, T, gamma, lam)
+  do {                                                                        \
+    if (deep)                                                                 \
+      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 8>),                \
+                         dim3((unsigned)nblocks), dim3(GAE_BT), 0, stream,    \
+                         rewards, values, dones, tl_dones, adv, ret, N, T,    \
+                         gamma, lam);                                         \
+    else                                                                      \
+      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 4>),                \
+                         dim3((unsigned)nblocks), dim3(GAE_BT), 0, stream,    \
+                         rewards, values, dones, tl_dones, adv, ret, N, T,    \
+                         gamma, lam);                                         \
+  } while (0)
   const bool vec = (T % 4 == 0);
   const int np = (int)ceil_div(T, GAE_PSTEPS);
   if (use_gae && vec && np <= GAE_MAXP) {

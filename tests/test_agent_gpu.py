@@ -954,6 +954,9 @@ def test_agent_options_match_cpu_oracle(opts, monkeypatch):
         # abstract_policy.py:96-109) and the mean net's output layer run on
         # the generic dense layer of csrc/glin.hip under autograd
         assert not mlp_ops.LIBRARY_CALLS, dict(mlp_ops.LIBRARY_CALLS)
+        want = "op_by_op" if "_contextual" in opts else "direct"
+        assert agent.last_policy_plan.kind == want
+        assert agent.last_critic_plan.kind == "fused-narrow"
     if "num_minibatchs" in opts:
         # the reference's minibatched critic update
         # (temporal_correlated_agent.py:343-366; class default 10) on the
@@ -961,6 +964,11 @@ def test_agent_options_match_cpu_oracle(opts, monkeypatch):
         # policy epochs on DirectEpoch, no library GEMM, no autograd gather
         assert mb_calls == [opts["num_minibatchs"]] * 6
         assert (spy.direct, spy.node) == (6, 0)
+        # ... and the agent's own named plans say the same (rl/tce_agent.py:
+        # critic_plan / policy_plan are THE path selection)
+        assert tuple(agent.last_critic_plan) == (
+            "fused-narrow", opts["num_minibatchs"], True, True)
+        assert agent.last_policy_plan.kind == "direct"
         assert not mlp_ops.LIBRARY_CALLS, dict(mlp_ops.LIBRARY_CALLS)
     for k in ("critic_loss_mean", "surrogate_loss_mean", "policy_loss_mean",
               "entropy_mean", "trust_region_loss_mean",
