@@ -360,7 +360,7 @@ def roofline(agent, critic_ms_in_step, with_f16=False, envs_in_step=None):
                 "bf16x3 (configs.C2_bf16x3_critic times whole steps with it); "
                 "bound by the VALU work of the three-way splits and the LDS "
                 "reads that share the issue port with the MFMAs at one wave per "
-                "SIMD (DESIGN section 4), not by the matrix cores"}
+                "SIMD (KERNELS.md), not by the matrix cores"}
 
     def gae_case(n):
         r = torch.randn(n, T, device="cuda", generator=g)

@@ -54,8 +54,8 @@
 //   of the next step, the epilogue of the previous row block and the three-way
 //   splits ride between the MFMAs of the current step (sched_group_barrier).
 //   One wave per SIMD is issue-bound: an MFMA holds the port ~10 cycles, a VALU
-//   instruction beside it costs ~5 (scripts/probe_mfma_fill.hip) -- DESIGN.md
-//   section 4 has the cycle budget of a tile and what was tried.
+//   instruction beside it costs ~5 (scripts/probe_mfma_fill.hip) -- KERNELS.md
+//   has the cycle budget of a tile and what was tried.
 #include "mlp_shared.h"
 
 extern "C" int tce_xchg_adam_f32(void* xchg, float* param, float* grad, float* m, float* v,
