@@ -548,7 +548,7 @@ OTHER_CONFIGS = [
     # (tce_mlp_critic_minibatch_f32).  Twice: with the reference's own permutation
     # draw (numpy's global MT19937 Fisher-Yates over 2 M rows on the host --
     # sequential by construction, ~28 ms per epoch: that entry is HOST-bound and
-    # says so) and with torch.randperm on the device
+    # says so) and with a keyed Feistel permutation computed on the device
     ("C2_minibatch10", dict(
         kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
         dtype="float32", num_minibatchs=10, steps=2, warmup=2,
@@ -562,8 +562,8 @@ OTHER_CONFIGS = [
         kind="tce", env="metaworld", num_env=4096, num_basis=5, epochs=50,
         dtype="float32", num_minibatchs=10, minibatch_permutation="device",
         workload="the same with agent option minibatch_permutation=device "
-                 "(torch.randperm on the GPU: statistically the same pieces, "
-                 "not numpy's sequence)")),
+                 "(a keyed Feistel permutation computed on the GPU, "
+                 "tce_feistel_permutation: not numpy's sequence)")),
     # the multi-GPU configs at their FULL size on this one GPU (they fit: 288 GB):
     # the denominators of the strong-scaling curves (N GPUs x N-th of the envs)
     ("C4_bbrl_full_16384", dict(

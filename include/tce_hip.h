@@ -392,6 +392,12 @@ int tce_gather_rows_f32(const float* x, int64_t x_stride, const float* a, const 
 int tce_gather_rows_f64(const double* x, int64_t x_stride, const double* a, const double* b,
                         const int64_t* idx, int64_t n, int din, double* x_out, double* a_out,
                         double* b_out, void* stream);
+/* out [n] (int64) = a keyed pseudo-random PERMUTATION of 0 .. n-1 without a sort
+ * (balanced Feistel network + cycle walking, every element on its own): the
+ * critic's minibatch permutation (mprl/util/util_data_structure.py:378-391)
+ * drawn on the device -- agent option minibatch_permutation: device; the default
+ * is the reference's own numpy draw on the host. */
+int tce_feistel_permutation(int64_t* out, int64_t n, uint64_t key, void* stream);
 int tce_mdp_reward_f32(float* rewards, const uint8_t* event_flags, int64_t N, int T,
                        void* stream);
 int tce_mdp_reward_f64(double* rewards, const uint8_t* event_flags, int64_t N, int T,

@@ -16,7 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "tce_hip.h")
 _lib = None
 
 _CTYPES = {
-    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float,
     "double": ctypes.c_double, "void": None,
 }
 

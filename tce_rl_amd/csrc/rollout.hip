@@ -145,6 +145,51 @@ __global__ __launch_bounds__(256) void mdp_reward_kernel(real* __restrict__ r,
 
 }  // namespace
 
+// A keyed pseudo-random permutation of [0, n) WITHOUT a sort (agent option
+// minibatch_permutation: device -- the critic's minibatch permutations drawn on
+// the GPU instead of by numpy's sequential Fisher-Yates on the host,
+// mprl/util/util_data_structure.py:378-391): out[i] = pi(i), pi = a balanced
+// Feistel network on 2 h bits (2^(2h) >= n the smallest such power of four)
+// restricted to [0, n) by cycle walking -- every element is computed on its own,
+// O(1) expected rounds (the domain is < 4 n), no library call, 8 B written per
+// row.  (Bijective-shuffle construction; not uniform over all n! permutations,
+// as no 64-bit-keyed generator is -- what minibatching needs is that every row
+// lands in an unpredictable piece, which tests/test_minibatch_gpu.py checks.)
+__device__ inline unsigned feistel_round(unsigned r, unsigned k) {
+  unsigned x = (r ^ k) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void feistel_permutation_kernel(int64_t* __restrict__ out,
+                                                                  int64_t n, int h,
+                                                                  unsigned long long key) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long mask = (1ull << h) - 1ull;
+  unsigned keys[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    keys[q] = feistel_round((unsigned)(key >> (8 * (q & 3))) + 0x632BE5ABu * (unsigned)q,
+                            (unsigned)(key >> 32) ^ (0x7F4A7C15u * (unsigned)(q + 1)));
+  unsigned long long x = (unsigned long long)i;
+  do {
+    unsigned long long l = x >> h, r = x & mask;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned long long f = (unsigned long long)feistel_round((unsigned)r, keys[q]) & mask;
+      const unsigned long long nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = (l << h) | r;
+  } while (x >= (unsigned long long)n);        // cycle walking: stays a bijection on [0, n)
+  out[i] = (int64_t)x;
+}
+
 // select_batch (mprl/util/util_data_structure.py:362-375) for the row kernels of
 // the black-box critic: x_out[i, :] = x[idx[i], :din], a_out[i] = a[idx[i]],
 // b_out[i] = b[idx[i]] (b nullable) -- one launch per minibatch; the envs of a
@@ -169,6 +214,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
 }
 
 extern "C" {
+
+int tce_feistel_permutation(int64_t* out, int64_t n, uint64_t key, void* stream) {
+  TCE_CHECK_ARG(out && n > 0 && n < (1ll << 62), "feistel_permutation: bad arguments");
+  int h = 1;
+  while (h < 31 && (1ll << (2 * h)) < n) ++h;
+  TCE_CHECK_ARG((1ll << (2 * h)) >= n, "feistel_permutation: n above 2^62");
+  hipLaunchKernelGGL(feistel_permutation_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, out, n, h, (unsigned long long)key);
+  TCE_LAUNCH_CHECK();
+  return 0;
+}
 
 #define TCE_RMS_BLOCKS 1024
 

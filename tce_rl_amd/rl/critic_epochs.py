@@ -57,13 +57,20 @@ class CriticEpochs:
         generator (generate_minibatches, util_data_structure.py:378-391), i.e.
         the same minibatches as the reference from the same seed; a sequential
         Fisher-Yates on the host (~13 ns per row), uploaded through one of two
-        pinned buffers while the previous epoch runs.  "device":
-        torch.randperm on the GPU (the device generator) -- statistically the
-        same, not the reference's sequence; for runs where the host draw
-        (28 ms per epoch at 2 M rows) would be the step."""
+        pinned buffers while the previous epoch runs.  "device": a keyed
+        pseudo-random permutation computed on the GPU (tce_feistel_permutation:
+        Feistel network + cycle walking, no sort, no library call) -- not the
+        reference's sequence; for runs where the host draw (16 - 28 ms per epoch
+        at 2 M rows) would be the step."""
         ag, n = self.agent, self.n_rows
         if getattr(ag, "minibatch_permutation", "numpy") == "device":
-            return torch.randperm(n, device=ag.device, dtype=torch.int64)
+            from .._lib import call, ptr, stream
+            # (the key from numpy's global generator: ONE draw per epoch where
+            # the reference's shuffle makes n; seeding it seeds the pieces)
+            key = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+            out = torch.empty(n, dtype=torch.int64, device=ag.device)
+            call("tce_feistel_permutation", ptr(out), n, key, stream())
+            return out
         ring = ag.__dict__.setdefault("_perm_ring", [])
         if len(ring) < 2 or ring[0][0].numel() != n:
             if ring and ring[0][0].numel() != n:

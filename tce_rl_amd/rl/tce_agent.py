@@ -46,8 +46,9 @@ class TemporalCorrelatedAgent(AbstractAgent):
         # who draws the critic's minibatch permutations: "numpy" = the
         # reference's own draw on numpy's global generator
         # (util_data_structure.py:389-390: same pieces from the same seed; a
-        # sequential host shuffle), "device" = torch.randperm on the GPU
-        # (statistically the same, not the reference's sequence)
+        # sequential host shuffle), "device" = a keyed Feistel permutation
+        # computed on the GPU (tce_feistel_permutation; not the reference's
+        # sequence)
         self.minibatch_permutation = kwargs.get("minibatch_permutation",
                                                 "numpy")
         if self.minibatch_permutation not in ("numpy", "device"):

@@ -178,3 +178,75 @@ def test_minibatch_arguments_are_checked():
     with pytest.raises(NotImplementedError, match="exact-fp32"):
         b3.epoch_minibatches(x, ret, ret, 0.0,
                              torch.arange(20, device="cuda"), 2, rows[:2], opt)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 4096, (1 << 20) + 7, 2048000])
+def test_device_permutation_is_a_permutation(n):
+    """``minibatch_permutation: device`` -- tce_feistel_permutation: a keyed
+    bijection on [0, n) (Feistel network + cycle walking), every element on its
+    own: each index exactly once, the same key the same permutation, another
+    key another one, and rows spread over the pieces like a shuffle's."""
+    from tce_rl_amd._lib import call, ptr, stream
+
+    def draw(key):
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        call("tce_feistel_permutation", ptr(out), n, key, stream())
+        return out
+    a = draw(12345)
+    assert torch.equal(torch.sort(a).values, torch.arange(n, device="cuda"))
+    assert torch.equal(a, draw(12345))
+    if n >= 17:
+        b = draw(12346)
+        assert not torch.equal(a, b)
+        assert torch.equal(torch.sort(b).values, torch.arange(n, device="cuda"))
+    if n >= 4096:
+        # no structure a minibatch would inherit: of the first tenth of the
+        # rows about a tenth lands in each tenth of the permutation
+        # (binomial: 5 sigma), few fixed points, neighbours are torn apart
+        k = n // 10
+        first = (a[:k * 10].reshape(10, k) < k).sum(1).double()
+        sigma = (k * 0.1 * 0.9) ** 0.5
+        assert float((first - 0.1 * k).abs().max()) <= 5 * sigma + 1
+        assert int((a == torch.arange(n, device="cuda")).sum()) <= 8
+        assert float(((a[1:] - a[:-1]).abs() == 1).double().mean()) < 1e-3
+
+
+def test_device_permutation_positions_are_uniform_over_keys():
+    """Where row 0 lands, over 4000 keys: uniform over the ten pieces
+    (chi-square, 9 degrees of freedom, 99.9 % quantile 27.9)."""
+    from tce_rl_amd._lib import call, ptr, stream
+    n, keys = 1000, 4000
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    where = []
+    for key in range(keys):
+        call("tce_feistel_permutation", ptr(out), n, 7919 * key + 3, stream())
+        where.append(out.argmin())            # the position that holds row 0
+    pos = torch.stack(where).cpu().numpy()
+    counts = np.bincount(pos * 10 // n, minlength=10)
+    chi2 = float(((counts - keys / 10) ** 2 / (keys / 10)).sum())
+    assert chi2 < 27.9, (chi2, counts)
+
+
+def test_agent_with_device_drawn_minibatches_is_repeatable():
+    """Two TCE agents with num_minibatchs = 4, minibatch_permutation = device,
+    the same seeds (numpy's generator keys the permutations): identical
+    parameters after two steps, on the fused minibatch epochs."""
+    from tce_rl_amd.config import tce_config
+    from tce_rl_amd.mp_exp import MPExperiment
+    out = []
+    for _ in range(2):
+        cfg = tce_config("metaworld", num_env=32, num_basis=5, epochs=3,
+                         evaluation_interval=0, seed=1)
+        a = cfg["params"]["agent"]["args"]
+        a["num_minibatchs"], a["minibatch_permutation"] = 4, "device"
+        torch.manual_seed(4)
+        np.random.seed(9)
+        exp = MPExperiment()
+        exp.initialize(cfg, 0, None)
+        for _ in range(2):
+            dict(exp.agent.step())
+        assert exp.agent.last_critic_plan.kind == "fused-narrow"
+        assert exp.agent.last_critic_plan.minibatches == 4
+        out.append(torch.cat([p.detach().reshape(-1) for p in
+                              exp.agent.critic.parameters]).clone())
+    assert torch.equal(out[0], out[1])
