@@ -68,29 +68,47 @@ __device__ inline double dpp_mov(double old, double v) {
 // branch-free (hipcc waits vmcnt(0) wherever two load paths merge):
 //   VEC  (T % 4 == 0): one 16-byte access at a base clamped into the row; a
 //        lane is then either wholly inside the row or wholly past it;
-//   !VEC (any T): four element accesses with clamped indices.
+//   VEC + RAG (T % 4 != 0, T >= 4; round 6: table tennis's T = 350): the same
+//        16-byte access; the ONE lane of a row that straddles its end gets the
+//        clamped base's elements shifted into place by selects (elements past
+//        the end are never used: the caller masks them), and stores its valid
+//        elements one by one;
+//   !VEC (T < 4): four element accesses with clamped indices.
 template <typename E>
 struct Vec4 { E v[4]; };
-template <bool VEC, typename E>
+template <bool VEC, bool RAG, typename E>
 __device__ inline Vec4<E> load4(const E* __restrict__ row, int t, int last) {
   typedef E vec __attribute__((ext_vector_type(4), aligned(sizeof(E))));
   Vec4<E> o;
   if (VEC) {
-    const vec x = *reinterpret_cast<const vec*>(row + min(t, last - 3));
-    o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w;
+    const int base = min(t, last - 3);
+    const vec x = *reinterpret_cast<const vec*>(row + base);
+    if (!RAG) {
+      o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w;
+    } else {
+      const int s = t - base;                  // 0 inside the row, 1 .. 3 for the straddling lane
+      o.v[0] = s == 0 ? x.x : (s == 1 ? x.y : (s == 2 ? x.z : x.w));
+      o.v[1] = s == 0 ? x.y : (s == 1 ? x.z : x.w);
+      o.v[2] = s == 0 ? x.z : x.w;
+      o.v[3] = x.w;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o.v[i] = row[min(t + i, last)];
   }
   return o;
 }
-template <bool VEC, typename E>
+template <bool VEC, bool RAG, typename E>
 __device__ inline void store4(E* __restrict__ row, int t, int T, const E* x) {
   typedef E vec __attribute__((ext_vector_type(4), aligned(sizeof(E))));
   if (VEC) {
-    if (t < T) {
+    if (RAG ? t + 3 < T : t < T) {
       vec o = {x[0], x[1], x[2], x[3]};
       *reinterpret_cast<vec*>(row + t) = o;
+    } else if (RAG) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (t + i < T) row[t + i] = x[i];
     }
   } else {
 #pragma unroll
@@ -104,7 +122,7 @@ __device__ inline void store4(E* __restrict__ row, int t, int T, const E* x) {
 // around loads and hipcc emits counted vmcnt waits (a wave-uniform branch
 // around a load makes it wait vmcnt(0) at the join, which serialises the
 // stream).  NP_STATIC == 0: generic runtime pass count / multi-tile path.
-template <typename real, bool USE_GAE, bool VEC, int NP_STATIC, int PF = 4>
+template <typename real, bool USE_GAE, bool VEC, int NP_STATIC, int PF = 4, bool RAG = false>
 __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
     const real* __restrict__ rewards, const real* __restrict__ values,
     const uint8_t* __restrict__ dones, const uint8_t* __restrict__ tl_dones,
@@ -157,10 +175,10 @@ __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
         if (q >= 0 && q < GAE_MAXP && q < np) {        // wave-uniform
           const int qi = q < 0 ? 0 : (q >= GAE_MAXP ? GAE_MAXP - 1 : q);
           const int t = t0 + q * GAE_PSTEPS + col * GAE_VEC;
-          vv[qi] = load4<VEC>(vrow, t, T - 1);   // V_T comes from vT
-          rv[qi] = load4<VEC>(rrow, t, T - 1);
-          dn[qi] = load4<VEC>(drow, t, T - 1);
-          tl[qi] = load4<VEC>(lrow, t, T - 1);
+          vv[qi] = load4<VEC, RAG>(vrow, t, T - 1);   // V_T comes from vT
+          rv[qi] = load4<VEC, RAG>(rrow, t, T - 1);
+          dn[qi] = load4<VEC, RAG>(drow, t, T - 1);
+          tl[qi] = load4<VEC, RAG>(lrow, t, T - 1);
         }
       }
       const int p = pp < GAE_MAXP ? pp : GAE_MAXP - 1;
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           real vnext = (i < 3) ? vv[p].v[(i < 3) ? i + 1 : 3] : vn3;
-          if (!VEC && t + i + 1 >= T) vnext = vT;
+          if ((!VEC || RAG) && t + i + 1 >= T) vnext = vT;
           const real nd = dn[p].v[i] ? real(0) : real(1);
           const real ntl = tl[p].v[i] ? real(0) : real(1);
           const real disc = gamma * nd;
@@ -219,8 +237,8 @@ __global__ __launch_bounds__(GAE_BT) void gae_dpp_kernel(
             rt[i] = USE_GAE ? (x[i] + vv[p].v[i]) : x[i];
             av[i] = rt[i] - vv[p].v[i];
           }
-          store4<VEC>(orow, t, T, rt);
-          store4<VEC>(arow, t, T, av);
+          store4<VEC, RAG>(orow, t, T, rt);
+          store4<VEC, RAG>(arow, t, T, av);
         }
       }
     }
@@ -452,36 +470,52 @@ int gae_launch(const real* rewards, const real* values, const uint8_t* dones,
   // several waves per SIMD: prefetch the whole tile (see the kernel)
   static const int pf_env = getenv("TCE_GAE_PF") ? atoi(getenv("TCE_GAE_PF")) : 0;
   const bool deep = pf_env ? pf_env >= 8 : nblocks >= 2 * gae_cu_count();
-#define GAE_GO(G, V, NPS)                                                     \
+#define GAE_GO(G, V, NPS, R)                                                  \
   do {                                                                        \
     if (deep)                                                                 \
-      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 8>),                \
+      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 8, R>),             \
                          dim3((unsigned)nblocks), dim3(GAE_BT), 0, stream,    \
                          rewards, values, dones, tl_dones, adv, ret, N, T,    \
                          gamma, lam);                                         \
     else                                                                      \
-      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 4>),                \
+      hipLaunchKernelGGL((gae_dpp_kernel<real, G, V, NPS, 4, R>),             \
                          dim3((unsigned)nblocks), dim3(GAE_BT), 0, stream,    \
                          rewards, values, dones, tl_dones, adv, ret, N, T,    \
                          gamma, lam);                                         \
   } while (0)
   const bool vec = (T % 4 == 0);
+  const bool rag = !vec && T >= 4;          // 16-byte accesses for rows of any length >= 4
   const int np = (int)ceil_div(T, GAE_PSTEPS);
   if (use_gae && vec && np <= GAE_MAXP) {
     switch (np) {
-      case 1: GAE_GO(true, true, 1); break;
-      case 2: GAE_GO(true, true, 2); break;
-      case 3: GAE_GO(true, true, 3); break;
-      case 4: GAE_GO(true, true, 4); break;
-      case 5: GAE_GO(true, true, 5); break;
-      case 6: GAE_GO(true, true, 6); break;
-      case 7: GAE_GO(true, true, 7); break;
-      default: GAE_GO(true, true, 8); break;
+      case 1: GAE_GO(true, true, 1, false); break;
+      case 2: GAE_GO(true, true, 2, false); break;
+      case 3: GAE_GO(true, true, 3, false); break;
+      case 4: GAE_GO(true, true, 4, false); break;
+      case 5: GAE_GO(true, true, 5, false); break;
+      case 6: GAE_GO(true, true, 6, false); break;
+      case 7: GAE_GO(true, true, 7, false); break;
+      default: GAE_GO(true, true, 8, false); break;
+    }
+  } else if (use_gae && rag && np <= GAE_MAXP) {
+    switch (np) {
+      case 1: GAE_GO(true, true, 1, true); break;
+      case 2: GAE_GO(true, true, 2, true); break;
+      case 3: GAE_GO(true, true, 3, true); break;
+      case 4: GAE_GO(true, true, 4, true); break;
+      case 5: GAE_GO(true, true, 5, true); break;
+      case 6: GAE_GO(true, true, 6, true); break;
+      case 7: GAE_GO(true, true, 7, true); break;
+      default: GAE_GO(true, true, 8, true); break;
     }
   } else if (use_gae) {
-    if (vec) GAE_GO(true, true, 0); else GAE_GO(true, false, 0);
+    if (vec) GAE_GO(true, true, 0, false);
+    else if (rag) GAE_GO(true, true, 0, true);
+    else GAE_GO(true, false, 0, false);
   } else {
-    if (vec) GAE_GO(false, true, 0); else GAE_GO(false, false, 0);
+    if (vec) GAE_GO(false, true, 0, false);
+    else if (rag) GAE_GO(false, true, 0, true);
+    else GAE_GO(false, false, 0, false);
   }
 #undef GAE_GO
   TCE_LAUNCH_CHECK();

@@ -836,13 +836,20 @@ def test_fused_objective_reports_the_same_metrics(ent_coef):
         assert a[k] == pytest.approx(b[k], rel=2e-3, abs=2e-6), k
 
 
-def test_training_improves_reward_within_the_trust_region():
+@pytest.mark.parametrize("minibatches", [None, ("numpy", 10), ("device", 10)])
+def test_training_improves_reward_within_the_trust_region(minibatches):
     """A short training run on the synthetic reach-like task: the exploration
-    reward rises steadily while every update stays inside the KL bounds."""
+    reward rises steadily while every update stays inside the KL bounds --
+    with the shipped YAMLs' one minibatch, and with the reference's class
+    default of 10 (temporal_correlated_agent.py:25) on the fused minibatch
+    epochs, permutations drawn by numpy on the host / by the device kernel."""
     from tce_rl_amd.config import tce_config
     from tce_rl_amd.mp_exp import MPExperiment
     cfg = tce_config("metaworld", num_env=256, num_basis=5, epochs=20,
                      evaluation_interval=0, iterations=40)
+    if minibatches:
+        a = cfg["params"]["agent"]["args"]
+        a["minibatch_permutation"], a["num_minibatchs"] = minibatches
     exp = MPExperiment()
     exp.initialize(cfg, 0, None)
     rewards, covs, means = [], [], []
@@ -857,6 +864,9 @@ def test_training_improves_reward_within_the_trust_region():
     assert max(means) <= p["mean_bound"] * 1.02
     assert np.mean(rewards[-5:]) > 0.6 * np.mean(rewards[:5])   # rewards are < 0
     assert rewards[-1] > rewards[0]
+    if minibatches:
+        assert tuple(exp.agent.last_critic_plan) == ("fused-narrow", 10, True,
+                                                     True)
 
 
 @pytest.mark.parametrize("shape", ["box_push", "table_tennis"])

@@ -31,8 +31,16 @@ def test_gae_golden_bit_exact(ops, golden):
         assert np.array_equal(ret.cpu().numpy(), g[f"ret_{c}"]), c
 
 
-@pytest.mark.parametrize("N,T", [(1, 1), (3, 7), (5, 513), (9, 1100),
-                                 (130, 500)])
+# (T % 4 != 0 with T >= 4 takes the 16-byte accesses with the straddling lane
+# shifted -- round 6 --, T < 4 the element path, T > 512 several tiles; 350 =
+# table tennis's horizon, 4097 envs x 350: several waves per SIMD = whole-tile
+# prefetch; every residue of T mod 4 and every compile-time pass count)
+@pytest.mark.parametrize("N,T", [(1, 1), (2, 2), (3, 3), (3, 4), (3, 5),
+                                 (3, 6), (3, 7), (5, 65), (4, 127), (7, 130),
+                                 (5, 258), (6, 322), (11, 350), (4, 387),
+                                 (3, 449), (5, 511), (5, 513), (9, 1100),
+                                 (9, 1101), (4, 1027), (130, 500),
+                                 (4097, 350), (4100, 101)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_gae_vs_oracle_ragged(ops, N, T, dtype):
     g = torch.Generator().manual_seed(N * 1000 + T)
