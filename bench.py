@@ -1144,6 +1144,16 @@ def main():
         return [max(e[i] for e in every) for i in range(len(vals))], \
             [e[0] for e in every]
 
+    # (rehearsal hook of the launcher's retry path, tests/test_bench_dist_gpu.py:
+    # TCE_BENCH_DIE_BEFORE_WARMUP="1,2" makes the ranks of launch attempts 1 and
+    # 2 exit with code 3 here -- after the process group and the exchanges are
+    # up, before the warm-up -- as a child set would that cannot map its peers)
+    die = os.environ.get("TCE_BENCH_DIE_BEFORE_WARMUP", "")
+    if die and os.environ.get("TCE_BENCH_LAUNCH_ATTEMPT", "0")[0] in \
+            die.split(","):
+        print("[bench] rank %d: dying before the warm-up (rehearsal)" % rank,
+              file=sys.stderr, flush=True)
+        os._exit(3)
     for _ in range(args.warmup):
         agent.step()
     barrier()
